@@ -1,0 +1,195 @@
+"""CPU ORACLE of EIGen's fitness path -- TEST INFRASTRUCTURE, not product code.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package (as the checker / reported baseline, never as the thing measured or shipped).  The product
+package ``evolutionary_illusion_generator_amd`` never imports it.
+
+Stages and what pins them:
+
+============  =========================================  ==========================================
+stage         restatement                                pinned by
+============  =========================================  ==========================================
+grids         ``oracle.grids`` (scalar, per pixel)       reference import -> tests/golden/grids.npz
+post-process  ``oracle.cppn.postprocess``                reference import -> tests/golden/postprocess.npz
+scorers       ``oracle.scores``                          reference import -> tests/golden/scores.json
+orchestration ``oracle.pipeline``                        reference import -> tests/golden/orchestration.json
+CPPN eval     ``oracle.cppn`` (PyTorch-NEAT semantics)   PARITY UNPINNED (submodule absent)
+PredNet       ``oracle/eig_oracle.c`` + ``prednet_torch`` PARITY UNPINNED (submodule + chainer absent)
+LK flow       ``oracle/eig_oracle.c``                    PARITY UNPINNED (submodule + OpenCV absent)
+============  =========================================  ==========================================
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+GATES = ("i", "f", "c", "o")
+
+
+def build(force=False):
+    """Compile oracle/eig_oracle.c -> oracle/libeig_oracle.so (gcc, see oracle/Makefile)."""
+    so = os.path.join(_HERE, "libeig_oracle.so")
+    src = os.path.join(_HERE, "eig_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libeig_oracle.so"])
+    return so
+
+
+class LKParams(ctypes.Structure):
+    """Parameters of Optical_Flow_Analyzer.lucas_kanade (OpenCV tutorial values, UPSTREAM-RECALL)."""
+    _fields_ = [("max_corners", ctypes.c_int), ("quality_level", ctypes.c_double),
+                ("min_distance", ctypes.c_double), ("block_size", ctypes.c_int),
+                ("win", ctypes.c_int), ("max_level", ctypes.c_int), ("max_iter", ctypes.c_int),
+                ("epsilon", ctypes.c_double), ("min_eig_thr", ctypes.c_double)]
+
+    def __init__(self, max_corners=100, quality_level=0.3, min_distance=7.0, block_size=7, win=15,
+                 max_level=2, max_iter=10, epsilon=0.03, min_eig_thr=1e-4):
+        super().__init__(max_corners, quality_level, min_distance, block_size, win, max_level, max_iter,
+                         epsilon, min_eig_thr)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libeig_oracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        _LIB.eig_oracle_prednet_rollout.restype = ctypes.c_int
+        _LIB.eig_oracle_lucas_kanade.restype = ctypes.c_int
+        _LIB.eig_oracle_good_features.restype = ctypes.c_int
+        _LIB.eig_oracle_conv_chain.restype = ctypes.c_int
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def tensor_names(n_layers):
+    """Order of the weight-tensor table consumed by eig_oracle.c:bind_tensors (chainer npz key names
+    of chainer_prednet with the ``predictor/`` prefix stripped)."""
+    names = []
+    for l in range(n_layers):
+        if l > 0:
+            names += ["ConvA%d/W" % l, "ConvA%d/b" % l]
+        names += ["ConvP%d/W" % l, "ConvP%d/b" % l]
+        for g in GATES:
+            names.append("ConvLSTM%d/x_%s0/W" % (l, g))
+            if l < n_layers - 1:
+                names.append("ConvLSTM%d/x_%s1/W" % (l, g))
+            names.append("ConvLSTM%d/h_%s/W" % (l, g))
+            names.append("ConvLSTM%d/h_%s/b" % (l, g))
+        for g in ("i", "f", "o"):
+            names.append("ConvLSTM%d/c_%s/W" % (l, g))
+    return names
+
+
+def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=False, return_float=False):
+    """Roll ``img`` (uint8 [C0,H,W]) through PredNet; returns uint8 frames [n_repeat+n_ext, C0, H, W]."""
+    L = len(channels)
+    names = tensor_names(L)
+    arrs = [np.ascontiguousarray(weights[n], dtype=np.float32) for n in names]
+    tab = (ctypes.POINTER(ctypes.c_float) * len(arrs))(*[_p(a, ctypes.c_float) for a in arrs])
+    ch = np.asarray(channels, dtype=np.int32)
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.shape == (channels[0], h, w), img.shape
+    T = n_repeat + n_ext
+    out = np.zeros((T, channels[0], h, w), dtype=np.uint8)
+    p0 = np.zeros((T, channels[0], h, w), dtype=np.float32) if return_float else None
+    rc = lib().eig_oracle_prednet_rollout(
+        ctypes.c_int(L), _p(ch, ctypes.c_int), ctypes.c_int(w), ctypes.c_int(h), tab, _p(img, ctypes.c_uint8),
+        ctypes.c_int(n_repeat), ctypes.c_int(n_ext), ctypes.c_int(int(requant)), _p(out, ctypes.c_uint8),
+        _p(p0, ctypes.c_float) if return_float else None)
+    if rc != 0:
+        raise ValueError("eig_oracle_prednet_rollout failed (size must be divisible by 2^(L-1))")
+    return (out, p0) if return_float else out
+
+
+def conv_chain(sources, ups, weights, H, W):
+    """out[o,y,x] = canonical fmaf chain over the listed sources.  sources[i]: [Cin_i, Hs, Ws] float32,
+    ups[i] in {0,1} (1 = source is half resolution, unpooled x2), weights[i]: [Cout, Cin_i, 3, 3]."""
+    ns = len(sources)
+    srcs = [np.ascontiguousarray(s, dtype=np.float32) for s in sources]
+    ws = [np.ascontiguousarray(x, dtype=np.float32) for x in weights]
+    cout = ws[0].shape[0]
+    st = (ctypes.POINTER(ctypes.c_float) * ns)(*[_p(a, ctypes.c_float) for a in srcs])
+    wt = (ctypes.POINTER(ctypes.c_float) * ns)(*[_p(a, ctypes.c_float) for a in ws])
+    cin = np.asarray([s.shape[0] for s in srcs], dtype=np.int32)
+    up = np.asarray(ups, dtype=np.int32)
+    out = np.zeros((cout, H, W), dtype=np.float32)
+    lib().eig_oracle_conv_chain(ctypes.c_int(ns), st, _p(cin, ctypes.c_int), _p(up, ctypes.c_int), wt,
+                                ctypes.c_int(cout), ctypes.c_int(H), ctypes.c_int(W), _p(out, ctypes.c_float))
+    return out
+
+
+def det_math(x):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    e, s, t = (np.zeros_like(x) for _ in range(3))
+    lib().eig_oracle_det_math(_p(x, ctypes.c_float), ctypes.c_int(x.size), _p(e, ctypes.c_float),
+                              _p(s, ctypes.c_float), _p(t, ctypes.c_float))
+    return e, s, t
+
+
+def gray(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    c, h, w = img.shape
+    out = np.zeros((h, w), dtype=np.uint8)
+    lib().eig_oracle_gray(_p(img, ctypes.c_uint8), ctypes.c_int(c), ctypes.c_int(h), ctypes.c_int(w), _p(out, ctypes.c_uint8))
+    return out
+
+
+def pyr_down(g):
+    g = np.ascontiguousarray(g, dtype=np.uint8)
+    h, w = g.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), dtype=np.uint8)
+    lib().eig_oracle_pyr_down(_p(g, ctypes.c_uint8), ctypes.c_int(h), ctypes.c_int(w), _p(out, ctypes.c_uint8))
+    return out
+
+
+def min_eig(g, block=7):
+    g = np.ascontiguousarray(g, dtype=np.uint8)
+    h, w = g.shape
+    out = np.zeros((h, w), dtype=np.float32)
+    lib().eig_oracle_min_eig(_p(g, ctypes.c_uint8), ctypes.c_int(h), ctypes.c_int(w), ctypes.c_int(block), _p(out, ctypes.c_float))
+    return out
+
+
+def good_features(g, params=None):
+    params = params or LKParams()
+    g = np.ascontiguousarray(g, dtype=np.uint8)
+    h, w = g.shape
+    pts = np.zeros((max(params.max_corners, 1), 2), dtype=np.float32)
+    n = lib().eig_oracle_good_features(_p(g, ctypes.c_uint8), ctypes.c_int(h), ctypes.c_int(w), ctypes.byref(params), _p(pts, ctypes.c_float))
+    return pts[:n].copy()
+
+
+def pyr_lk(g0, g1, pts, params=None):
+    params = params or LKParams()
+    g0 = np.ascontiguousarray(g0, dtype=np.uint8)
+    g1 = np.ascontiguousarray(g1, dtype=np.uint8)
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    h, w = g0.shape
+    n = pts.shape[0]
+    nxt = np.zeros((max(n, 1), 2), dtype=np.float32)
+    st = np.zeros(max(n, 1), dtype=np.uint8)
+    if n:
+        lib().eig_oracle_pyr_lk(_p(g0, ctypes.c_uint8), _p(g1, ctypes.c_uint8), ctypes.c_int(h), ctypes.c_int(w),
+                                ctypes.byref(params), _p(pts, ctypes.c_float), ctypes.c_int(n), _p(nxt, ctypes.c_float), _p(st, ctypes.c_uint8))
+    return nxt[:n], st[:n]
+
+
+def lucas_kanade(img0, img1, params=None):
+    """img0/img1: uint8 [C,H,W].  Returns float32 [n,4] rows [x0, y0, dx, dy] (possibly n == 0)."""
+    params = params or LKParams()
+    img0 = np.ascontiguousarray(img0, dtype=np.uint8)
+    img1 = np.ascontiguousarray(img1, dtype=np.uint8)
+    c, h, w = img0.shape
+    vec = np.zeros((max(params.max_corners, 1), 4), dtype=np.float32)
+    n = lib().eig_oracle_lucas_kanade(_p(img0, ctypes.c_uint8), _p(img1, ctypes.c_uint8), ctypes.c_int(c), ctypes.c_int(h),
+                                      ctypes.c_int(w), ctypes.byref(params), _p(vec, ctypes.c_float))
+    return vec[:n].copy()

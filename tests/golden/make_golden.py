@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Generate golden fixtures by IMPORTING the reference (only possible in the build container).
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; writes tests/golden/*.npz|json)
+
+The reference modules import packages that are absent here (empty submodules chainer_prednet /
+optical_flow / pytorch_neat, plus cv2, neat, google.colab).  They are replaced by inert stubs in
+sys.modules so that the reference's OWN pure-python/numpy functions can be executed:
+  * fitness_calculator.py:18-215  scorers (plausibility_ratio, strength_number,
+    horizontal_symmetry_score, swarm_score, rotation_symmetry_score) and :505-548 calculate_fitness
+  * generate_illusion.py:38-117,196-317 fill_circle / create_grid
+  * generate_illusion.py:372-460 get_image_from_cppn (with an injected fake create_cppn whose
+    output planes are seeded arrays stored in the fixture)
+  * generate_illusion.py:478-673 get_fitnesses_neat score combination, with test_prednet stubbed
+    out and lucas_kanade returning seeded vectors stored in the fixture.
+Only inputs and expected outputs are stored -- no reference source text.
+"""
+import json
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def install_stubs(state):
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Enum:  # TransformationType placeholder
+        pass
+
+    mod("chainer_prednet"); mod("chainer_prednet.PredNet"); mod("chainer_prednet.utilities")
+    mod("chainer_prednet.PredNet.call_prednet", test_prednet=lambda **kw: state.setdefault("prednet_calls", []).append(kw))
+    mod("chainer_prednet.utilities.mirror_images", mirror=None, mirror_multiple=None, TransformationType=_Enum)
+    mod("cv2", imread=lambda p: None, cvtColor=None, COLOR_RGB2BGR=0, COLOR_GRAY2BGR=1)
+    mod("google"); mod("google.colab"); mod("google.colab.patches", cv2_imshow=lambda img: None)
+    mod("neat")
+
+    def lucas_kanade(f0, f1, out_dir, save=True, verbose=0, save_name=""):
+        state.setdefault("lk_calls", []).append((f0, f1, save_name))
+        i = len(state["lk_calls"]) - 1
+        if save_name:  # the reference later copies this file (generate_illusion.py:655-657)
+            os.makedirs(os.path.dirname(save_name), exist_ok=True)
+            open(save_name, "wb").close()
+        v = state["lk_vectors"][i]
+        return {"vectors": [list(map(float, r)) for r in v]}
+
+    mod("optical_flow"); mod("optical_flow.optical_flow", lucas_kanade=lucas_kanade, draw_tracks=None, save_data=None)
+    mod("pytorch_neat"); mod("pytorch_neat.pytorch_neat")
+
+    def create_cppn(genome, config, leaf_names, node_names):
+        planes = state["planes"][genome.key]
+
+        def mk(c):
+            def f(x=None, y=None):
+                import torch
+                if x is not None and len(x) != planes.shape[1]:  # 800x800 'enhanced' render: content irrelevant
+                    return torch.zeros(len(x), dtype=torch.float64)
+                return torch.tensor(planes[c])
+            return f
+        return [mk(c) for c in range(len(planes))]
+
+    mod("pytorch_neat.pytorch_neat.cppn", create_cppn=create_cppn)
+    mod("pytorch_neat.pytorch_neat.multi_env_eval", MultiEnvEvaluator=None)
+    mod("pytorch_neat.pytorch_neat.neat_reporter", LogReporter=None)
+    mod("pytorch_neat.pytorch_neat.recurrent_net", RecurrentNet=None)
+
+
+class FakeGenome:
+    def __init__(self, key):
+        self.key = key
+        self.fitness = None
+
+
+def vec_set(rng, n, w, h, mag):
+    v = np.zeros((n, 4))
+    v[:, 0] = rng.integers(1, w - 1, n)
+    v[:, 1] = rng.integers(1, h - 1, n)
+    v[:, 2:] = rng.normal(0, mag, (n, 2))
+    return v
+
+
+def main():
+    state = {}
+    install_stubs(state)
+    sys.path.insert(0, REF)
+    import fitness_calculator as fc
+    import generate_illusion as gi
+
+    rng = np.random.default_rng(20260928)
+
+    # ---------------- grids (a1) ----------------
+    grids = {}
+    for name, st, w, h in [("circles_64x64", gi.StructureType.Circles, 64, 64),
+                           ("circles_160x120", gi.StructureType.Circles, 160, 120),
+                           ("circles_96x64", gi.StructureType.Circles, 96, 64),
+                           ("circlesfree_64x64", gi.StructureType.CirclesFree, 64, 64),
+                           ("circlesfree_80x60", gi.StructureType.CirclesFree, 80, 60),
+                           ("free_64x64", gi.StructureType.Free, 64, 64),
+                           ("free_160x120", gi.StructureType.Free, 160, 120),
+                           ("bands_160x120", gi.StructureType.Bands, 160, 120),
+                           ("bands_80x40", gi.StructureType.Bands, 80, 40)]:
+        g = gi.create_grid(st, w, h, 10)
+        grids[name + "_x"] = np.asarray(g["x_mat"], dtype=np.float64)
+        grids[name + "_y"] = np.asarray(g["y_mat"], dtype=np.float64)
+    eg = gi.enhanced_image_grid(120, 120, gi.StructureType.Circles)
+    grids["enhanced_circles_120x120_x"] = eg["x_mat"]
+    grids["enhanced_circles_120x120_y"] = eg["y_mat"]
+    np.savez_compressed(os.path.join(OUT, "grids.npz"), **grids)
+
+    # ---------------- image post-processing (a2) ----------------
+    post = {}
+    w, h = 48, 32
+    grid = gi.create_grid(gi.StructureType.Circles, w, h, 10)
+    post["grid_x"] = grid["x_mat"]; post["grid_y"] = grid["y_mat"]
+    cases = []
+    for ci, (c_dim, gradient, bg) in enumerate([(3, 1, 1), (3, 1, 0), (3, 0, 1), (1, 1, 1), (1, 0, 1), (1, 0, 0)]):
+        nplanes = 3 if c_dim == 3 else 1
+        planes = rng.normal(0.5, 0.9, (nplanes, w * h))
+        # sprinkle exact / edge values: wrap-around, negatives, >1, halves, nan, inf
+        edge = np.array([0.0, 1.0, 1.004, -0.5, 2.0, 0.5, 0.25, 0.75, 1.0 / 255, 254.5 / 255, np.nan, np.inf, -np.inf, 1e9, -1e9, 3.999 / 4,
+                         3000000123.0 / 255, -3000000123.0 / 255, 5000000321.0 / 255, 2147483000.0 / 255, -2147483900.0 / 255,
+                         1e19, -1e19, 300.7 / 255, -300.7 / 255, 65535.9 / 255, 1.5, 2.5, 0.5000001, 1e-320])
+        fg = np.flatnonzero(np.asarray(grid["x_mat"]).reshape(-1) != -1)  # probes must sit on non-background pixels
+        planes[:, fg[:edge.size]] = edge
+        g = FakeGenome(1000 + ci)
+        state.setdefault("planes", {})[g.key] = planes
+        img = gi.get_image_from_cppn(grid, g, c_dim, w, h, None, bg=bg, gradient=gradient)
+        arr = np.asarray(img)
+        post["case%d_planes" % ci] = planes
+        post["case%d_img" % ci] = arr
+        cases.append({"c_dim": c_dim, "gradient": gradient, "bg": bg})
+    np.savez_compressed(os.path.join(OUT, "postprocess.npz"), **post)
+    with open(os.path.join(OUT, "postprocess.json"), "w") as f:
+        json.dump({"w": w, "h": h, "cases": cases}, f, indent=1)
+
+    # ---------------- scorers (a7-a13) ----------------
+    sc = {"cases": []}
+    w, h = 160, 120
+    sets = []
+    for n, mag in [(1, 0.1), (2, 0.1), (5, 0.05), (24, 0.1), (25, 0.1), (26, 0.12), (40, 0.08), (75, 0.15), (100, 0.2), (60, 0.01)]:
+        sets.append(vec_set(rng, n, w, h, mag))
+    # a structured rotating field (high rotation symmetry), a centred vector (distance 0), duplicates
+    ang = np.linspace(0, 2 * np.pi, 36, endpoint=False)
+    rot = np.stack([80 + 40 * np.cos(ang), 60 + 40 * np.sin(ang), -0.1 * np.sin(ang), 0.1 * np.cos(ang)], 1)
+    sets.append(rot)
+    sets.append(np.concatenate([rot, [[80.0, 60.0, 0.05, 0.02]], rot[:3]], 0))
+    sets.append(np.array([[0.0, 0.0, -1000.0, 0.0]]))  # the "no vectors" sentinel, generate_illusion.py:554
+    for v in sets:
+        case = {"vectors": v.tolist()}
+        for lim in (0.15, 0.3, 0.4):
+            ratio, good = fc.plausibility_ratio(v, lim)
+            case["plaus_%g" % lim] = [ratio, len(good)]
+            if len(good) > 0:
+                gv = np.asarray(good)
+                case["strength_%g" % lim] = float(fc.strength_number(good, lim))
+                case["hsym_%g" % lim] = float(fc.horizontal_symmetry_score(good, [0, h / 4 * 2]))
+                case["rot_%g" % lim] = float(fc.rotation_symmetry_score(good, w, h, [0, h / 2]))
+                case["swarm_%g" % lim] = float(fc.swarm_score(good))
+        for st in (fc.StructureType.Bands, fc.StructureType.Circles, fc.StructureType.CirclesFree, fc.StructureType.Free):
+            try:
+                case["fitness_%d" % int(st)] = float(fc.calculate_fitness(st, v, "x.png", w, h))
+            except UnboundLocalError:
+                case["fitness_%d" % int(st)] = "UnboundLocalError"
+        sc["cases"].append(case)
+    sc["w"] = w; sc["h"] = h
+    with open(os.path.join(OUT, "scores.json"), "w") as f:
+        json.dump(sc, f)
+
+    # ---------------- get_fitnesses_neat orchestration (a13, B1) ----------------
+    orch = {"runs": []}
+    cwd = os.getcwd()
+    for st, c_dim in [(gi.StructureType.Circles, 3), (gi.StructureType.Free, 1), (gi.StructureType.CirclesFree, 1)]:
+        w, h = 40, 32
+        pop = [(100 + i, FakeGenome(100 + i)) for i in range(6)]
+        planes = {}
+        for _, g in pop:
+            planes[g.key] = rng.uniform(0, 1, (c_dim, w * h))
+        state["planes"] = planes
+        nvec = [30, 0, 26, 5, 40, 25]
+        lkv = [vec_set(rng, n, w, h, 0.1) if n else np.zeros((0, 4)) for n in nvec]
+        state["lk_vectors"] = lkv
+        state["lk_calls"] = []; state["prednet_calls"] = []
+        with tempfile.TemporaryDirectory() as td:
+            os.chdir(td)
+            try:
+                gi.get_fitnesses_neat(st, pop, "model.npz", None, w, h, [c_dim, 4, 8, 16], c_dim=c_dim, best_dir=td, gradient=1)
+            finally:
+                os.chdir(cwd)
+        kw = state["prednet_calls"][0]
+        orch["runs"].append({
+            "structure": int(st), "c_dim": c_dim, "w": w, "h": h,
+            "lk_vectors": [v.tolist() for v in lkv],
+            "fitness": [float(g.fitness) for _, g in pop],
+            "lk_files": [[os.path.basename(a), os.path.basename(b)] for a, b, _ in state["lk_calls"]],
+            "prednet_kwargs": {k: kw[k] for k in ("size", "channels", "skip_save_frames", "extension_start", "extension_duration", "reset_at", "c_dim")},
+            "sequence_len": len(kw["sequence_list"][0]),
+        })
+    with open(os.path.join(OUT, "orchestration.json"), "w") as f:
+        json.dump(orch, f)
+    print("golden fixtures written to", OUT)
+
+
+if __name__ == "__main__":
+    main()
