@@ -1,0 +1,777 @@
+// eigen_engine.hip -- C ABI (include/eigen_engine.h) of the MI355X fitness engine: handle, device workspaces,
+// weight packing, kernel launch sequencing.  All compute is in the HIP kernels of conv_mfma.h / cppn_kernel.h /
+// flow_kernels.h / score_kernels.h; there is no CPU fallback anywhere in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/eigen_engine.h"
+#include "conv_mfma.h"
+#include "cppn_kernel.h"
+#include "flow_kernels.h"
+#include "score_kernels.h"
+
+using namespace eig;
+
+static thread_local std::string g_err;
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIPCHK(x)                                                                                      \
+    do {                                                                                               \
+        hipError_t _e = (x);                                                                           \
+        if (_e != hipSuccess) return fail(EIGEN_ERR_HIP, "%s:%d %s -> %s", __FILE__, __LINE__, #x, hipGetErrorString(_e)); \
+    } while (0)
+
+namespace {
+
+struct ConvOp {
+    int epi = 0, NI = 4, TW = 16, layer = 0;
+    int nsrc = 0;
+    int src_C[3] = {0, 0, 0}, src_up[3] = {0, 0, 0};
+    int H = 0, W = 0, Cout = 0, n_nblk = 0, krows = 0;
+    float* d_wpk = nullptr;
+    double macs = 0;  // algorithmic multiply-accumulates per image (real channels only)
+    double ms = 0;    // profiling accumulator
+    int launches = 0;
+};
+
+struct Layer {
+    int C = 0, H = 0, W = 0;
+    float* h[2] = {nullptr, nullptr};
+    float *c = nullptr, *P = nullptr, *E = nullptr;
+    float *bias_lstm = nullptr, *peep = nullptr, *biasA = nullptr, *biasP = nullptr;
+    ConvOp convA, lstm, convP;
+};
+
+template <typename T> struct DevBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc((void**)&p, n * sizeof(T)) != hipSuccess) return -1;
+        cap = n;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+}  // namespace
+
+struct eigen_engine {
+    eigen_config cfg;
+    int L = 0, B = 0, C0 = 0, H = 0, W = 0, K = 0;
+    Layer layer[EIGEN_MAX_LAYERS];
+    bool have_weights = false, have_grid = false;
+    int n_planes = 0;
+    double* d_planes = nullptr;
+    // genome staging
+    DevBuf<int32_t> g_node_off, g_edge_off, g_edge_src, g_out_node;
+    DevBuf<uint8_t> g_node_act;
+    DevBuf<double> g_node_bias, g_node_resp, g_edge_w;
+    // images / frames
+    uint8_t* d_images = nullptr;  // [B][C0][H][W]
+    uint8_t* d_frames = nullptr;  // [B][3][C0][H][W]
+    // flow
+    int n_levels = 1;             // pyramid levels that exist (max_level + 1)
+    int lvH[FLOW_MAX_LEVELS], lvW[FLOW_MAX_LEVELS];
+    uint8_t* d_gray[2][FLOW_MAX_LEVELS] = {{nullptr}};
+    short2* d_deriv[FLOW_MAX_LEVELS] = {nullptr};
+    float* d_eig = nullptr;
+    unsigned long long* d_cand = nullptr;
+    float *d_corners = nullptr, *d_next = nullptr, *d_vectors = nullptr;
+    uint8_t* d_status = nullptr;
+    int *d_ncorners = nullptr, *d_counts = nullptr;
+    double* d_fitness = nullptr;
+    // timing
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pev0 = nullptr, pev1 = nullptr;
+    bool profile_convs = false;
+    double ms[6] = {0, 0, 0, 0, 0, 0};
+    int hflip = 0;  // which h buffer holds the current R
+};
+
+// ------------------------------------------------------------------------------------------------ helpers
+static int pad4(int c) { return (c + 3) & ~3; }
+
+static void choose_ni(int Cout, bool lstm, int* NI, int* n_nblk)
+{
+    if (lstm) { *NI = 4; *n_nblk = (Cout + 15) / 16; return; }
+    int best = 1; double beste = -1;
+    for (int ni = 1; ni <= 4; ++ni) {
+        const int nb = (Cout + 16 * ni - 1) / (16 * ni);
+        const double eff = (double)Cout / (nb * 16.0 * ni) + 1e-3 * ni;  // ties -> larger tile
+        if (eff > beste) { beste = eff; best = ni; }
+    }
+    *NI = best; *n_nblk = (Cout + 16 * best - 1) / (16 * best);
+}
+
+static int choose_tw(int H, int W)
+{
+    auto util = [&](int tw) {
+        const int th = (tw == 16) ? 16 : 8;
+        const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
+        return (double)H * W / ((double)ty * th * tx * tw);
+    };
+    return (util(16) + 1e-9 >= util(8)) ? 16 : 8;
+}
+
+// Pack OIHW weights of one fused conv into [n_nblk][krows][NB]; row = (source, channel (padded to 4), tap).
+// srcw[s][g] points at [Cout][Cin_s][3][3]; g = 0 for plain convs, 0..3 (i,f,c,o) for the LSTM.
+static std::vector<float> pack_weights(const ConvOp& op, const float* const srcw[3][4], bool lstm)
+{
+    const int NB = op.NI * 16;
+    std::vector<float> out((size_t)op.n_nblk * op.krows * NB, 0.0f);
+    for (int nb = 0; nb < op.n_nblk; ++nb) {
+        size_t row = 0;
+        for (int s = 0; s < op.nsrc; ++s) {
+            const int Cin = op.src_C[s], Cp = pad4(Cin);
+            for (int c = 0; c < Cp; ++c)
+                for (int tap = 0; tap < 9; ++tap, ++row) {
+                    if (c >= Cin) continue;
+                    float* dst = &out[((size_t)nb * op.krows + row) * NB];
+                    for (int n = 0; n < NB; ++n) {
+                        int g = 0, o;
+                        if (lstm) { g = n / 16; o = nb * 16 + (n % 16); }
+                        else o = nb * NB + n;
+                        if (o >= op.Cout) continue;
+                        dst[n] = srcw[s][g][((size_t)o * Cin + c) * 9 + tap];
+                    }
+                }
+        }
+    }
+    return out;
+}
+
+template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st)
+{
+    constexpr int lds = conv_lds_bytes<NI, TW>();
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI>), dim3(grid), dim3(256), lds, st, a);
+    return hipGetLastError();
+}
+
+template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& a, int grid, hipStream_t st)
+{
+    if (TW == 16) {
+        switch (NI) {
+            case 1: return launch_inst<1, 16, EPI>(a, grid, st);
+            case 2: return launch_inst<2, 16, EPI>(a, grid, st);
+            case 3: return launch_inst<3, 16, EPI>(a, grid, st);
+            default: return launch_inst<4, 16, EPI>(a, grid, st);
+        }
+    }
+    switch (NI) {
+        case 1: return launch_inst<1, 8, EPI>(a, grid, st);
+        case 2: return launch_inst<2, 8, EPI>(a, grid, st);
+        case 3: return launch_inst<3, 8, EPI>(a, grid, st);
+        default: return launch_inst<4, 8, EPI>(a, grid, st);
+    }
+}
+
+static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batch, hipStream_t st)
+{
+    const int TH = (op.TW == 16) ? 16 : 8;
+    const int NIMG = 256 / (TH * op.TW);
+    a.H = op.H; a.W = op.W; a.B = batch;
+    a.tilesX = (op.W + op.TW - 1) / op.TW;
+    a.tilesY = (op.H + TH - 1) / TH;
+    a.n_nblk = op.n_nblk; a.krows = op.krows; a.wpk = op.d_wpk; a.Cout = op.Cout;
+    a.nsrc = op.nsrc;
+    for (int s = 0; s < op.nsrc; ++s) { a.src[s].C = op.src_C[s]; a.src[s].Cpad = pad4(op.src_C[s]); a.src[s].up = op.src_up[s]; }
+    const int grid = op.n_nblk * ((batch + NIMG - 1) / NIMG) * a.tilesX * a.tilesY;
+    if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
+    hipError_t r;
+    switch (op.epi) {
+        case EPI_LSTM: r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st) : launch_inst<4, 8, EPI_LSTM>(a, grid, st); break;
+        case EPI_CONVA: r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st); break;
+        case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st); break;
+        default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st); break;
+    }
+    if (e->profile_convs && r == hipSuccess) {
+        (void)hipEventRecord(e->pev1, st);
+        (void)hipEventSynchronize(e->pev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e->pev0, e->pev1);
+        op.ms += ms; op.launches++;
+    }
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------------ ABI
+extern "C" {
+
+int eigen_abi_version(void) { return EIGEN_ABI_VERSION; }
+const char* eigen_last_error(void) { return g_err.c_str(); }
+
+void eigen_config_defaults(eigen_config* c)
+{
+    c->n_repeat = 20; c->n_ext = 2; c->requant_feedback = 0;
+    c->lk_max_corners = 100; c->lk_block_size = 7; c->lk_win = 15; c->lk_max_level = 2; c->lk_max_iter = 10;
+    c->reserved0 = 0;
+    c->lk_quality_level = 0.3; c->lk_min_distance = 7.0; c->lk_epsilon = 0.03; c->lk_min_eig_thr = 1e-4;
+}
+
+int eigen_destroy(eigen_engine* e)
+{
+    if (!e) return EIGEN_OK;
+    (void)hipSetDevice(e->cfg.device);
+    for (int l = 0; l < e->L; ++l) {
+        Layer& y = e->layer[l];
+        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk};
+        for (float* p : ptrs) if (p) (void)hipFree(p);
+    }
+    if (e->d_planes) (void)hipFree(e->d_planes);
+    e->g_node_off.release(); e->g_edge_off.release(); e->g_edge_src.release(); e->g_out_node.release();
+    e->g_node_act.release(); e->g_node_bias.release(); e->g_node_resp.release(); e->g_edge_w.release();
+    void* misc[] = {e->d_images, e->d_frames, e->d_eig, e->d_cand, e->d_corners, e->d_next, e->d_vectors, e->d_status,
+                    e->d_ncorners, e->d_counts, e->d_fitness};
+    for (void* p : misc) if (p) (void)hipFree(p);
+    for (int i = 0; i < 2; ++i)
+        for (int l = 0; l < FLOW_MAX_LEVELS; ++l) if (e->d_gray[i][l]) (void)hipFree(e->d_gray[i][l]);
+    for (int l = 0; l < FLOW_MAX_LEVELS; ++l) if (e->d_deriv[l]) (void)hipFree(e->d_deriv[l]);
+    for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+    if (e->pev0) (void)hipEventDestroy(e->pev0);
+    if (e->pev1) (void)hipEventDestroy(e->pev1);
+    delete e;
+    return EIGEN_OK;
+}
+
+int eigen_create(const eigen_config* cfg, eigen_engine** out)
+{
+    if (!cfg || !out) return fail(EIGEN_ERR_INVALID, "null argument");
+    *out = nullptr;
+    const int L = cfg->n_layers;
+    if (L < 1 || L > EIGEN_MAX_LAYERS) return fail(EIGEN_ERR_INVALID, "n_layers %d out of range", L);
+    if (cfg->width <= 0 || cfg->height <= 0 || (cfg->width % (1 << (L - 1))) || (cfg->height % (1 << (L - 1))))
+        return fail(EIGEN_ERR_INVALID, "image %dx%d must be divisible by 2^(layers-1)=%d (2x2 pooling per PredNet layer)",
+                    cfg->width, cfg->height, 1 << (L - 1));
+    if (cfg->channels[0] != 1 && cfg->channels[0] != 3) return fail(EIGEN_ERR_INVALID, "channels[0] (c_dim) must be 1 or 3");
+    if (cfg->max_batch < 1) return fail(EIGEN_ERR_INVALID, "max_batch must be >= 1");
+    if (cfg->lk_max_corners < 1 || cfg->lk_max_corners > SCORE_T) return fail(EIGEN_ERR_INVALID, "lk_max_corners must be in 1..%d", SCORE_T);
+    if (cfg->lk_win < 3 || cfg->lk_win > 16) return fail(EIGEN_ERR_INVALID, "lk_win must be in 3..16");
+    if (cfg->lk_block_size < 1 || cfg->lk_block_size > EIG_MAXB) return fail(EIGEN_ERR_INVALID, "lk_block_size must be in 1..%d", EIG_MAXB);
+    if (cfg->lk_max_level < 0 || cfg->lk_max_level >= FLOW_MAX_LEVELS) return fail(EIGEN_ERR_INVALID, "lk_max_level must be in 0..%d", FLOW_MAX_LEVELS - 1);
+    if (cfg->n_repeat < 1 || cfg->n_ext < 0) return fail(EIGEN_ERR_INVALID, "n_repeat >= 1 and n_ext >= 0 required");
+    for (int l = 0; l < L; ++l) if (cfg->channels[l] < 1) return fail(EIGEN_ERR_INVALID, "channels[%d] < 1", l);
+    HIPCHK(hipSetDevice(cfg->device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg->device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(EIGEN_ERR_INVALID, "device %d is %s; this library is built for gfx950 (MI355X) only", cfg->device, prop.gcnArchName);
+
+    eigen_engine* e = new eigen_engine();
+    e->cfg = *cfg;
+    e->L = L; e->B = cfg->max_batch; e->C0 = cfg->channels[0]; e->H = cfg->height; e->W = cfg->width; e->K = cfg->lk_max_corners;
+    const size_t B = (size_t)e->B;
+#define ALLOC(ptr, n)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = hipMalloc((void**)&(ptr), (n));                                            \
+        if (_e != hipSuccess) { eigen_destroy(e); return fail(EIGEN_ERR_HIP, "hipMalloc(%zu) for %s: %s", (size_t)(n), #ptr, hipGetErrorString(_e)); } \
+    } while (0)
+    for (int l = 0; l < L; ++l) {
+        Layer& y = e->layer[l];
+        y.C = cfg->channels[l]; y.H = e->H >> l; y.W = e->W >> l;
+        const size_t n = B * y.C * y.H * y.W * sizeof(float);
+        ALLOC(y.h[0], n); ALLOC(y.h[1], n); ALLOC(y.c, n); ALLOC(y.P, n); ALLOC(y.E, 2 * n);
+    }
+    const size_t HW = (size_t)e->H * e->W;
+    ALLOC(e->d_images, B * e->C0 * HW);
+    ALLOC(e->d_frames, B * 3 * e->C0 * HW);
+    // flow pyramids: a level exists only while both dims stay > winSize (buildOpticalFlowPyramid)
+    e->lvH[0] = e->H; e->lvW[0] = e->W; e->n_levels = 1;
+    for (int l = 1; l <= cfg->lk_max_level; ++l) {
+        const int hd = (e->lvH[l - 1] + 1) / 2, wd = (e->lvW[l - 1] + 1) / 2;
+        if (wd <= cfg->lk_win || hd <= cfg->lk_win) break;
+        e->lvH[l] = hd; e->lvW[l] = wd; e->n_levels = l + 1;
+    }
+    for (int l = 0; l < e->n_levels; ++l) {
+        const size_t n = B * e->lvH[l] * e->lvW[l];
+        ALLOC(e->d_gray[0][l], n); ALLOC(e->d_gray[1][l], n);
+        ALLOC(e->d_deriv[l], n * sizeof(short2));
+    }
+    ALLOC(e->d_eig, B * HW * sizeof(float));
+    ALLOC(e->d_cand, B * HW * sizeof(unsigned long long));
+    ALLOC(e->d_corners, B * e->K * 2 * sizeof(float));
+    ALLOC(e->d_next, B * e->K * 2 * sizeof(float));
+    ALLOC(e->d_vectors, B * e->K * 4 * sizeof(float));
+    ALLOC(e->d_status, B * e->K);
+    ALLOC(e->d_ncorners, B * sizeof(int));
+    ALLOC(e->d_counts, B * sizeof(int));
+    ALLOC(e->d_fitness, B * sizeof(double));
+#undef ALLOC
+    for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipEventCreate(&e->pev0));
+    HIPCHK(hipEventCreate(&e->pev1));
+    *out = e;
+    return EIGEN_OK;
+}
+
+int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_tensors)
+{
+    if (!e || !t) return fail(EIGEN_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const int L = e->L;
+    int expect = 0;
+    for (int l = 0; l < L; ++l) expect += (l > 0 ? 2 : 0) + 2 + 4 * (l < L - 1 ? 4 : 3) + 3;
+    if (n_tensors != expect) return fail(EIGEN_ERR_INVALID, "expected %d weight tensors for %d layers, got %d", expect, L, n_tensors);
+    int k = 0;
+    auto upload = [&](float** dst, const float* src, size_t n) -> int {
+        if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+        if (hipMalloc((void**)dst, n * sizeof(float)) != hipSuccess) return -1;
+        return hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice) == hipSuccess ? 0 : -1;
+    };
+    for (int l = 0; l < L; ++l) {
+        Layer& y = e->layer[l];
+        const int C = y.C;
+        const float *convA_w = nullptr, *convA_b = nullptr;
+        if (l > 0) { convA_w = t[k++]; convA_b = t[k++]; }
+        const float* convP_w = t[k++];
+        const float* convP_b = t[k++];
+        const float *wx0[4], *wx1[4] = {nullptr, nullptr, nullptr, nullptr}, *wh[4], *bh[4];
+        for (int g = 0; g < 4; ++g) {
+            wx0[g] = t[k++];
+            if (l < L - 1) wx1[g] = t[k++];
+            wh[g] = t[k++];
+            bh[g] = t[k++];
+        }
+        const float* peep[3] = {t[k], t[k + 1], t[k + 2]};
+        k += 3;
+        for (int i = 0; i < k; ++i) if (!t[i]) return fail(EIGEN_ERR_INVALID, "weight tensor %d is NULL", i);
+
+        // ---- ConvA_l: E_{l-1} (2 C_{l-1} ch at the finer resolution) -> C_l, fused relu / 2x2 max-pool / error unit
+        if (l > 0) {
+            ConvOp& op = y.convA;
+            op = ConvOp();
+            op.epi = EPI_CONVA; op.layer = l; op.nsrc = 1; op.src_C[0] = 2 * e->layer[l - 1].C; op.src_up[0] = 0;
+            op.H = e->layer[l - 1].H; op.W = e->layer[l - 1].W; op.Cout = C;
+            choose_ni(C, false, &op.NI, &op.n_nblk);
+            op.TW = choose_tw(op.H, op.W);
+            op.krows = pad4(op.src_C[0]) * 9;
+            op.macs = (double)op.H * op.W * C * op.src_C[0] * 9;
+            const float* sw[3][4] = {{convA_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
+            std::vector<float> pk = pack_weights(op, sw, false);
+            if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.biasA, convA_b, C)) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d)", l);
+        }
+        // ---- ConvLSTM_l: sources E_l, unpooled R_{l+1}, h_l ; 4 gates fused on N
+        {
+            ConvOp& op = y.lstm;
+            op = ConvOp();
+            op.epi = EPI_LSTM; op.layer = l; op.H = y.H; op.W = y.W; op.Cout = C;
+            op.nsrc = 0;
+            op.src_C[op.nsrc] = 2 * C; op.src_up[op.nsrc] = 0; op.nsrc++;
+            if (l < L - 1) { op.src_C[op.nsrc] = e->layer[l + 1].C; op.src_up[op.nsrc] = 1; op.nsrc++; }
+            op.src_C[op.nsrc] = C; op.src_up[op.nsrc] = 0; op.nsrc++;
+            choose_ni(C, true, &op.NI, &op.n_nblk);
+            op.TW = choose_tw(op.H, op.W);
+            op.krows = 0; op.macs = 0;
+            for (int s = 0; s < op.nsrc; ++s) { op.krows += pad4(op.src_C[s]) * 9; op.macs += (double)y.H * y.W * 4 * C * op.src_C[s] * 9; }
+            const float* sw[3][4];
+            int s = 0;
+            for (int g = 0; g < 4; ++g) sw[s][g] = wx0[g];
+            s++;
+            if (l < L - 1) { for (int g = 0; g < 4; ++g) sw[s][g] = wx1[g]; s++; }
+            for (int g = 0; g < 4; ++g) sw[s][g] = wh[g];
+            std::vector<float> pk = pack_weights(op, sw, true);
+            std::vector<float> bias(4 * (size_t)C);
+            for (int g = 0; g < 4; ++g) memcpy(&bias[(size_t)g * C], bh[g], sizeof(float) * C);
+            const size_t chw = (size_t)C * y.H * y.W;
+            std::vector<float> pp(3 * chw);
+            for (int g = 0; g < 3; ++g) memcpy(&pp[g * chw], peep[g], sizeof(float) * chw);
+            if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.bias_lstm, bias.data(), bias.size()) || upload(&y.peep, pp.data(), pp.size()))
+                return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d)", l);
+        }
+        // ---- ConvP_l
+        {
+            ConvOp& op = y.convP;
+            op = ConvOp();
+            op.epi = EPI_CONVP; op.layer = l; op.nsrc = 1; op.src_C[0] = C; op.src_up[0] = 0;
+            op.H = y.H; op.W = y.W; op.Cout = C;
+            choose_ni(C, false, &op.NI, &op.n_nblk);
+            op.TW = choose_tw(op.H, op.W);
+            op.krows = pad4(C) * 9;
+            op.macs = (double)y.H * y.W * C * C * 9;
+            const float* sw[3][4] = {{convP_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
+            std::vector<float> pk = pack_weights(op, sw, false);
+            if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.biasP, convP_b, C)) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvP%d)", l);
+        }
+    }
+    e->have_weights = true;
+    return EIGEN_OK;
+}
+
+double eigen_prednet_flops_per_step(const eigen_engine* e)
+{
+    if (!e) return 0;
+    double macs = 0;
+    for (int l = 0; l < e->L; ++l) {
+        const Layer& y = e->layer[l];
+        const int C = y.C;
+        const double hw = (double)y.H * y.W;
+        if (l > 0) macs += (double)e->layer[l - 1].H * e->layer[l - 1].W * C * 2.0 * e->layer[l - 1].C * 9;
+        double cin = 3.0 * C + (l < e->L - 1 ? e->layer[l + 1].C : 0);
+        macs += hw * 4 * C * cin * 9;
+        macs += hw * C * C * 9;
+    }
+    return 2.0 * macs;
+}
+
+int eigen_set_grid(eigen_engine* e, const double* h_planes, int32_t n_planes)
+{
+    if (!e || !h_planes) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (n_planes < 1 || n_planes > 4) return fail(EIGEN_ERR_INVALID, "n_planes must be 1..4");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    const size_t n = (size_t)n_planes * e->H * e->W;
+    if (e->d_planes) { (void)hipFree(e->d_planes); e->d_planes = nullptr; }
+    HIPCHK(hipMalloc((void**)&e->d_planes, n * sizeof(double)));
+    HIPCHK(hipMemcpy(e->d_planes, h_planes, n * sizeof(double), hipMemcpyHostToDevice));
+    e->n_planes = n_planes;
+    e->have_grid = true;
+    return EIGEN_OK;
+}
+
+int eigen_render_cppn(eigen_engine* e, const eigen_genome_batch* g, int32_t bg, int32_t gradient, uint8_t* d_images, void* stream)
+{
+    if (!e || !g || !d_images) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (!e->have_grid) return fail(EIGEN_ERR_STATE, "eigen_set_grid has not been called");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const int G = g->n_genomes;
+    if (G < 1) return fail(EIGEN_ERR_INVALID, "n_genomes < 1");
+    const int mode = (gradient == 1) ? 0 : (e->C0 == 1 ? 1 : 2);
+    const int need_out = (mode == 0) ? e->C0 : 1;
+    if (g->c_out < need_out) return fail(EIGEN_ERR_INVALID, "genome batch provides %d outputs per genome, %d needed", g->c_out, need_out);
+    const int total_nodes = g->node_off[G];
+    const int total_edges = g->edge_off[total_nodes];
+    int max_nodes = 0, max_edges = 0;
+    for (int i = 0; i < G; ++i) {
+        const int nn = g->node_off[i + 1] - g->node_off[i];
+        const int ne = g->edge_off[g->node_off[i + 1]] - g->edge_off[g->node_off[i]];
+        if (nn < 1) return fail(EIGEN_ERR_INVALID, "genome %d has no nodes", i);
+        max_nodes = std::max(max_nodes, nn); max_edges = std::max(max_edges, ne);
+    }
+    for (int i = 0; i < total_edges; ++i)
+        if (g->edge_src[i] < -(e->n_planes + 1)) return fail(EIGEN_ERR_INVALID, "edge %d references leaf %d but only %d planes are set", i, -g->edge_src[i] - 1, e->n_planes);
+    const size_t lds = (size_t)max_nodes * CPPN_THREADS * 8 + (size_t)max_nodes * 16 + (size_t)max_edges * 8 + (size_t)(max_nodes + 1) * 4 + (size_t)max_edges * 4 + max_nodes + 64;
+    if (lds > 160 * 1024) return fail(EIGEN_ERR_CAPACITY, "genome with %d nodes / %d edges needs %zu B of LDS (> 160 KiB)", max_nodes, max_edges, lds);
+    if (e->g_node_off.ensure(G + 1) || e->g_edge_off.ensure(total_nodes + 1) || e->g_node_act.ensure(total_nodes) ||
+        e->g_node_bias.ensure(total_nodes) || e->g_node_resp.ensure(total_nodes) || e->g_edge_src.ensure(std::max(total_edges, 1)) ||
+        e->g_edge_w.ensure(std::max(total_edges, 1)) || e->g_out_node.ensure((size_t)G * g->c_out))
+        return fail(EIGEN_ERR_HIP, "hipMalloc for the genome batch failed");
+    HIPCHK(hipMemcpyAsync(e->g_node_off.p, g->node_off, sizeof(int32_t) * (G + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->g_edge_off.p, g->edge_off, sizeof(int32_t) * (total_nodes + 1), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->g_node_act.p, g->node_act, total_nodes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->g_node_bias.p, g->node_bias, sizeof(double) * total_nodes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(e->g_node_resp.p, g->node_resp, sizeof(double) * total_nodes, hipMemcpyHostToDevice, st));
+    if (total_edges) {
+        HIPCHK(hipMemcpyAsync(e->g_edge_src.p, g->edge_src, sizeof(int32_t) * total_edges, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemcpyAsync(e->g_edge_w.p, g->edge_w, sizeof(double) * total_edges, hipMemcpyHostToDevice, st));
+    }
+    HIPCHK(hipMemcpyAsync(e->g_out_node.p, g->out_node, sizeof(int32_t) * G * g->c_out, hipMemcpyHostToDevice, st));
+    CppnArgs a;
+    a.node_off = e->g_node_off.p; a.edge_off = e->g_edge_off.p; a.node_act = e->g_node_act.p;
+    a.node_bias = e->g_node_bias.p; a.node_resp = e->g_node_resp.p; a.edge_src = e->g_edge_src.p; a.edge_w = e->g_edge_w.p;
+    a.out_node = e->g_out_node.p; a.planes = e->d_planes; a.n_planes = e->n_planes; a.N = e->H * e->W;
+    a.c_out = g->c_out; a.c_dim = e->C0; a.bg = bg; a.mode = mode; a.max_nodes = max_nodes; a.out = d_images;
+    (void)hipFuncSetAttribute((const void*)cppn_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(cppn_render_kernel, dim3((a.N + CPPN_THREADS - 1) / CPPN_THREADS, G), dim3(CPPN_THREADS), lds, st, a);
+    HIPCHK(hipGetLastError());
+    return EIGEN_OK;
+}
+
+int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batch, int32_t n_steps, int32_t first_out_step,
+                          uint8_t* d_frames, void* stream)
+{
+    if (!e || !d_images || !d_frames) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (!e->have_weights) return fail(EIGEN_ERR_STATE, "eigen_set_prednet_weights has not been called");
+    if (batch < 1 || batch > e->B) return fail(EIGEN_ERR_CAPACITY, "batch %d exceeds max_batch %d", batch, e->B);
+    if (n_steps < 1 || n_steps > e->cfg.n_repeat + e->cfg.n_ext) return fail(EIGEN_ERR_INVALID, "n_steps %d out of range", n_steps);
+    if (first_out_step < 0 || first_out_step >= n_steps) return fail(EIGEN_ERR_INVALID, "first_out_step %d out of range", first_out_step);
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const int L = e->L;
+    const size_t HW = (size_t)e->H * e->W;
+    const int n_out = n_steps - first_out_step;
+    for (int l = 0; l < L; ++l) {  // reset_state()
+        Layer& y = e->layer[l];
+        const size_t n = (size_t)batch * y.C * y.H * y.W * sizeof(float);
+        HIPCHK(hipMemsetAsync(y.h[0], 0, n, st));
+        HIPCHK(hipMemsetAsync(y.c, 0, n, st));
+        HIPCHK(hipMemsetAsync(y.P, 0, n, st));
+    }
+    int cur = 0;  // h[cur] holds the state of the previous step
+    hipLaunchKernelGGL(e0_init_kernel, dim3(1024), dim3(256), 0, st, d_images, e->layer[0].E, e->C0, (int)HW, batch);
+    HIPCHK(hipGetLastError());
+    for (int t = 0; t < n_steps; ++t) {
+        // bottom-up: E_l from E_{l-1} and the previous prediction P_l
+        for (int l = 1; l < L; ++l) {
+            Layer& y = e->layer[l];
+            ConvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.src[0].ptr = e->layer[l - 1].E;
+            a.bias = y.biasA; a.P = y.P; a.E = y.E;
+            HIPCHK(launch_conv(e, y.convA, a, batch, st));
+        }
+        // top-down: R_l, then P_l
+        for (int l = L - 1; l >= 0; --l) {
+            Layer& y = e->layer[l];
+            {
+                ConvArgs a;
+                memset(&a, 0, sizeof(a));
+                int s = 0;
+                a.src[s++].ptr = y.E;
+                if (l < L - 1) a.src[s++].ptr = e->layer[l + 1].h[cur ^ 1];  // R_{l+1} of THIS step
+                a.src[s++].ptr = y.h[cur];
+                a.bias = y.bias_lstm; a.c_state = y.c; a.h_out = y.h[cur ^ 1]; a.peep = y.peep;
+                HIPCHK(launch_conv(e, y.lstm, a, batch, st));
+            }
+            {
+                ConvArgs a;
+                memset(&a, 0, sizeof(a));
+                a.src[0].ptr = y.h[cur ^ 1];
+                a.bias = y.biasP; a.Pout = y.P; a.clip = (l == 0) ? 1 : 0;
+                if (l == 0) {
+                    if (t + 1 < n_steps) {  // error units of the next step
+                        a.E0 = y.E;
+                        a.img = (t + 1 < e->cfg.n_repeat) ? d_images : nullptr;
+                        a.requant = e->cfg.requant_feedback;
+                    }
+                    if (t >= first_out_step) {
+                        a.frame = d_frames + (size_t)(t - first_out_step) * e->C0 * HW;
+                        a.frame_bstride = (long long)n_out * e->C0 * HW;
+                    }
+                }
+                HIPCHK(launch_conv(e, y.convP, a, batch, st));
+            }
+        }
+        cur ^= 1;
+    }
+    e->hflip = cur;
+    return EIGEN_OK;
+}
+
+int eigen_flow(eigen_engine* e, const uint8_t* d_img0, int64_t stride0, const uint8_t* d_img1, int64_t stride1, int32_t batch,
+               float* d_vectors, int32_t* d_counts, void* stream)
+{
+    if (!e || !d_img0 || !d_img1 || !d_vectors || !d_counts) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (batch < 1 || batch > e->B) return fail(EIGEN_ERR_CAPACITY, "batch %d exceeds max_batch %d", batch, e->B);
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const int H = e->H, W = e->W, HW = H * W;
+    const eigen_config& c = e->cfg;
+    hipLaunchKernelGGL(gray_kernel, dim3((HW + 255) / 256, batch), dim3(256), 0, st, d_img0, (long long)stride0, e->C0, HW, e->d_gray[0][0], batch);
+    hipLaunchKernelGGL(gray_kernel, dim3((HW + 255) / 256, batch), dim3(256), 0, st, d_img1, (long long)stride1, e->C0, HW, e->d_gray[1][0], batch);
+    for (int l = 1; l < e->n_levels; ++l)
+        for (int i = 0; i < 2; ++i)
+            hipLaunchKernelGGL(pyrdown_kernel, dim3((e->lvH[l] * e->lvW[l] + 255) / 256, batch), dim3(256), 0, st, e->d_gray[i][l - 1],
+                               e->lvH[l - 1], e->lvW[l - 1], e->d_gray[i][l], e->lvH[l], e->lvW[l]);
+    for (int l = 0; l < e->n_levels; ++l)
+        hipLaunchKernelGGL(scharr_kernel, dim3((e->lvH[l] * e->lvW[l] + 255) / 256, batch), dim3(256), 0, st, e->d_gray[0][l], e->lvH[l], e->lvW[l], e->d_deriv[l]);
+    const double sc = 1.0 / ((double)(1 << 2) * c.lk_block_size * 255.0);
+    const float SC = (float)(sc * sc);
+    hipLaunchKernelGGL(mineig_kernel, dim3((W + EIG_T - 1) / EIG_T, (H + EIG_T - 1) / EIG_T, batch), dim3(256), 0, st, e->d_gray[0][0], H, W,
+                       c.lk_block_size, SC, e->d_eig);
+    hipLaunchKernelGGL(corner_select_kernel, dim3(batch), dim3(1024), 0, st, e->d_eig, H, W, c.lk_quality_level, (float)c.lk_min_distance,
+                       c.lk_max_corners, e->d_cand, e->d_corners, e->d_ncorners);
+    LKArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int l = 0; l < e->n_levels; ++l) {
+        a.I[l] = e->d_gray[0][l]; a.J[l] = e->d_gray[1][l]; a.dI[l] = e->d_deriv[l];
+        a.Hs[l] = e->lvH[l]; a.Ws[l] = e->lvW[l];
+    }
+    a.max_level = e->n_levels - 1; a.win = c.lk_win; a.K = e->K;
+    a.max_iter = std::min(std::max(c.lk_max_iter, 0), 100);
+    const double eps = std::min(std::max(c.lk_epsilon, 0.0), 10.0);
+    a.eps_sq = eps * eps; a.min_eig_thr = c.lk_min_eig_thr;
+    a.corners = e->d_corners; a.ncorners = e->d_ncorners; a.next_pts = e->d_next; a.status = e->d_status;
+    hipLaunchKernelGGL(lk_track_kernel, dim3(e->K, batch), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(compact_vectors_kernel, dim3(batch), dim3(128), 0, st, e->d_corners, e->d_next, e->d_status, e->d_ncorners, e->K, d_vectors, d_counts);
+    HIPCHK(hipGetLastError());
+    return EIGEN_OK;
+}
+
+int eigen_score(eigen_engine* e, int32_t structure, int32_t width, int32_t height, const float* d_vectors, const int32_t* d_counts, int32_t batch,
+                double* d_fitness, void* stream)
+{
+    if (!e || !d_vectors || !d_counts || !d_fitness) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (structure < 0 || structure > 3) return fail(EIGEN_ERR_INVALID, "unknown structure %d (the reference raises NameError, generate_illusion.py:606-607)", structure);
+    if (batch < 1) return fail(EIGEN_ERR_INVALID, "batch < 1");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    ScoreArgs a;
+    a.vectors = d_vectors; a.counts = d_counts; a.K = e->K; a.structure = structure; a.w = width > 0 ? width : e->W; a.h = height > 0 ? height : e->H; a.fitness = d_fitness;
+    hipLaunchKernelGGL(score_kernel, dim3(batch), dim3(SCORE_T), 0, (hipStream_t)stream, a);
+    HIPCHK(hipGetLastError());
+    return EIGEN_OK;
+}
+
+static int eval_images_impl(eigen_engine* e, const uint8_t* d_images, int batch, int structure, int pairing, double* h_fitness,
+                            float* h_vectors, int32_t* h_counts, hipStream_t st, bool rendered)
+{
+    const size_t HW = (size_t)e->H * e->W, img_bytes = (size_t)e->C0 * HW;
+    const int nr = e->cfg.n_repeat;
+    int n_steps, first;
+    if (pairing == EIGEN_PAIR_POPULATION) { n_steps = nr + 1; first = nr - 1; }  // prediction@n_repeat and 1st extension
+    else { n_steps = nr + 2; first = nr + 1; }                                    // 2nd extension
+    if (n_steps > nr + e->cfg.n_ext) return fail(EIGEN_ERR_INVALID, "pairing needs %d extension steps, engine has n_ext=%d", n_steps - nr, e->cfg.n_ext);
+    if (!rendered) HIPCHK(hipEventRecord(e->ev[0], st));
+    HIPCHK(hipEventRecord(e->ev[1], st));
+    int rc = eigen_prednet_rollout(e, d_images, batch, n_steps, first, e->d_frames, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->ev[2], st));
+    const int n_out = n_steps - first;
+    if (pairing == EIGEN_PAIR_POPULATION)
+        rc = eigen_flow(e, e->d_frames, (int64_t)(n_out * img_bytes), e->d_frames + img_bytes, (int64_t)(n_out * img_bytes), batch, e->d_vectors, e->d_counts, st);
+    else
+        rc = eigen_flow(e, d_images, (int64_t)img_bytes, e->d_frames, (int64_t)(n_out * img_bytes), batch, e->d_vectors, e->d_counts, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->ev[3], st));
+    rc = eigen_score(e, structure, 0, 0, e->d_vectors, e->d_counts, batch, e->d_fitness, st);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(e->ev[4], st));
+    HIPCHK(hipMemcpyAsync(h_fitness, e->d_fitness, sizeof(double) * batch, hipMemcpyDeviceToHost, st));
+    if (h_vectors) HIPCHK(hipMemcpyAsync(h_vectors, e->d_vectors, sizeof(float) * batch * e->K * 4, hipMemcpyDeviceToHost, st));
+    if (h_counts) HIPCHK(hipMemcpyAsync(h_counts, e->d_counts, sizeof(int32_t) * batch, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[0], e->ev[1])); e->ms[0] = ms;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[1], e->ev[2])); e->ms[1] = ms;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[2], e->ev[3])); e->ms[2] = ms;
+    HIPCHK(hipEventElapsedTime(&ms, e->ev[3], e->ev[4])); e->ms[3] = ms;
+    return EIGEN_OK;
+}
+
+int eigen_eval_population(eigen_engine* e, const eigen_genome_batch* g, int32_t structure, int32_t bg, int32_t gradient, int32_t pairing,
+                          double* h_fitness, void* stream)
+{
+    if (!e || !g || !h_fitness) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (g->n_genomes < 1 || g->n_genomes > e->B) return fail(EIGEN_ERR_CAPACITY, "batch %d exceeds max_batch %d", g->n_genomes, e->B);
+    if (structure < 0 || structure > 3) return fail(EIGEN_ERR_INVALID, "unknown structure %d", structure);
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipEventRecord(e->ev[0], st));
+    int rc = eigen_render_cppn(e, g, bg, gradient, e->d_images, st);
+    if (rc) return rc;
+    return eval_images_impl(e, e->d_images, g->n_genomes, structure, pairing, h_fitness, nullptr, nullptr, st, true);
+}
+
+int eigen_eval_images(eigen_engine* e, const uint8_t* d_images, int32_t batch, int32_t structure, int32_t pairing, double* h_fitness,
+                      float* h_vectors, int32_t* h_counts, void* stream)
+{
+    if (!e || !d_images || !h_fitness) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (batch < 1 || batch > e->B) return fail(EIGEN_ERR_CAPACITY, "batch %d exceeds max_batch %d", batch, e->B);
+    if (structure < 0 || structure > 3) return fail(EIGEN_ERR_INVALID, "unknown structure %d", structure);
+    HIPCHK(hipSetDevice(e->cfg.device));
+    return eval_images_impl(e, d_images, batch, structure, pairing, h_fitness, h_vectors, h_counts, (hipStream_t)stream, false);
+}
+
+int eigen_get_timings(eigen_engine* e, double* h_ms6)
+{
+    if (!e || !h_ms6) return fail(EIGEN_ERR_INVALID, "null argument");
+    double conv = 0; int launches = 0;
+    for (int l = 0; l < e->L; ++l) {
+        conv += e->layer[l].convA.ms + e->layer[l].lstm.ms + e->layer[l].convP.ms;
+        launches += e->layer[l].convA.launches + e->layer[l].lstm.launches + e->layer[l].convP.launches;
+    }
+    for (int i = 0; i < 4; ++i) h_ms6[i] = e->ms[i];
+    h_ms6[4] = conv; h_ms6[5] = launches;
+    return EIGEN_OK;
+}
+
+// Per-op profile of the roll-out convolutions.  enable=1 brackets every conv launch with HIP events on its stream
+// (serialising the stream per launch); rows of h_out (8 doubles each, up to max_ops):
+// [layer, epi, NI, TW, launches, total_ms, algorithmic FLOPs per launch per image (2*MACs), n_nblk]
+int eigen_conv_profile(eigen_engine* e, int32_t enable, int32_t reset, double* h_out, int32_t max_ops, int32_t* n_ops)
+{
+    if (!e) return fail(EIGEN_ERR_INVALID, "null argument");
+    e->profile_convs = enable != 0;
+    int n = 0;
+    for (int l = 0; l < e->L; ++l) {
+        ConvOp* ops[3] = {l > 0 ? &e->layer[l].convA : nullptr, &e->layer[l].lstm, &e->layer[l].convP};
+        for (ConvOp* op : ops) {
+            if (!op) continue;
+            if (h_out && n < max_ops) {
+                double* r = h_out + (size_t)n * 8;
+                r[0] = op->layer; r[1] = op->epi; r[2] = op->NI; r[3] = op->TW; r[4] = op->launches; r[5] = op->ms; r[6] = 2.0 * op->macs; r[7] = op->n_nblk;
+            }
+            if (reset) { op->ms = 0; op->launches = 0; }
+            ++n;
+        }
+    }
+    if (n_ops) *n_ops = n;
+    return EIGEN_OK;
+}
+
+int eigen_test_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, const int32_t* cin, const int32_t* up, const float* const* h_w,
+                    int32_t cout, int32_t H, int32_t W, int32_t batch, float* d_out, void* stream)
+{
+    if (!e || !d_src || !cin || !up || !h_w || !d_out) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (n_src < 1 || n_src > 3) return fail(EIGEN_ERR_INVALID, "n_src must be 1..3");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    ConvOp op;
+    op.epi = EPI_RAW; op.nsrc = n_src; op.H = H; op.W = W; op.Cout = cout;
+    choose_ni(cout, false, &op.NI, &op.n_nblk);
+    op.TW = choose_tw(H, W);
+    op.krows = 0;
+    const float* sw[3][4] = {{nullptr}, {nullptr}, {nullptr}};
+    for (int s = 0; s < n_src; ++s) { op.src_C[s] = cin[s]; op.src_up[s] = up[s]; op.krows += pad4(cin[s]) * 9; sw[s][0] = h_w[s]; }
+    std::vector<float> pk = pack_weights(op, sw, false);
+    HIPCHK(hipMalloc((void**)&op.d_wpk, pk.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(op.d_wpk, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int s = 0; s < n_src; ++s) a.src[s].ptr = d_src[s];
+    a.raw = d_out;
+    const bool prof = e->profile_convs;
+    e->profile_convs = false;
+    hipError_t r = launch_conv(e, op, a, batch, (hipStream_t)stream);
+    e->profile_convs = prof;
+    hipError_t r2 = hipStreamSynchronize((hipStream_t)stream);
+    (void)hipFree(op.d_wpk);
+    if (r != hipSuccess) return fail(EIGEN_ERR_HIP, "conv launch: %s", hipGetErrorString(r));
+    if (r2 != hipSuccess) return fail(EIGEN_ERR_HIP, "conv sync: %s", hipGetErrorString(r2));
+    return EIGEN_OK;
+}
+
+int eigen_test_det_math(eigen_engine* e, const float* d_x, int32_t n, float* d_exp, float* d_sig, float* d_tanh, void* stream)
+{
+    if (!e || !d_x) return fail(EIGEN_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(det_math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_x, n, d_exp, d_sig, d_tanh);
+    HIPCHK(hipGetLastError());
+    return EIGEN_OK;
+}
+
+// Stage-level access for the parity tests: corner list of the last eigen_flow call.
+int eigen_debug_corners(eigen_engine* e, int32_t batch, float* h_corners, int32_t* h_ncorners, float* h_next, uint8_t* h_status, void* stream)
+{
+    if (!e) return fail(EIGEN_ERR_INVALID, "null argument");
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (h_corners) HIPCHK(hipMemcpy(h_corners, e->d_corners, sizeof(float) * batch * e->K * 2, hipMemcpyDeviceToHost));
+    if (h_ncorners) HIPCHK(hipMemcpy(h_ncorners, e->d_ncorners, sizeof(int32_t) * batch, hipMemcpyDeviceToHost));
+    if (h_next) HIPCHK(hipMemcpy(h_next, e->d_next, sizeof(float) * batch * e->K * 2, hipMemcpyDeviceToHost));
+    if (h_status) HIPCHK(hipMemcpy(h_status, e->d_status, (size_t)batch * e->K, hipMemcpyDeviceToHost));
+    return EIGEN_OK;
+}
+
+}  // extern "C"

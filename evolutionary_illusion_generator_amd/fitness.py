@@ -1,0 +1,258 @@
+"""Host-side mirror of the reference's fitness API, running on the HIP engine.
+
+Same names, argument order and result conventions as the reference:
+
+* ``get_fitnesses_neat(structure, population, model_name, config, w, h, channels, id=0, c_dim=3, best_dir=".",
+  gradient=1)`` -- /root/reference/generate_illusion.py:478-673; the ``eval_genomes`` closure of
+  ``neat_illusion`` (:692-694) calls it once per generation and reads nothing back: the result is delivered by
+  setting ``genome.fitness`` on every genome of ``population`` (:623-624).
+* ``get_vectors(image_path, model_name, channels, w, h)`` and
+  ``calculate_fitness(structure, vectors, image_path, w, h)`` -- /root/reference/fitness_calculator.py:468-548.
+
+What changes underneath: no PNG round trips through ./temp (the uint8 quantisation points they imply are kept
+on the device), the whole population is one batched device pass, and with torch.distributed initialised the
+population is sharded over the ranks (one rank per GPU) with ONE all-gather of float64 fitness scalars
+(RCCL over xGMI when the backend is ``nccl``).
+
+``model_name`` is the chainer npz weight file of the reference (``-m`` flag).  ``"synthetic"`` /
+``"synthetic:<seed>"`` selects seeded stand-in weights (weights.synthetic_prednet_weights) because the trained
+files are external downloads; a dict of tensors is accepted too.
+"""
+import math
+import os
+
+import numpy as np
+
+from . import grids
+from .engine import PAIR_POPULATION, PAIR_SINGLE, Engine, EngineError
+from .genome import GenomeBatch
+from .grids import StructureType
+from .weights import load_chainer_npz, synthetic_prednet_weights
+
+SCALING = 10          # generate_illusion.py:501
+DEFAULT_MAX_BATCH = 256
+
+_engines = {}
+
+
+def _resolve_weights(model_name, channels, w, h):
+    if isinstance(model_name, dict):
+        return model_name, ("dict", id(model_name))
+    name = str(model_name)
+    if name.startswith("synthetic"):
+        seed = int(name.split(":")[1]) if ":" in name else 0
+        return synthetic_prednet_weights(channels, w, h, seed=seed), ("synthetic", seed)
+    return load_chainer_npz(name, channels, w, h), ("file", os.path.abspath(name), os.path.getmtime(name))
+
+
+def _local_device():
+    import torch
+    if not torch.cuda.is_available():
+        raise EngineError("no HIP device visible: the fitness path runs on MI355X only (no CPU fallback)")
+    return torch.cuda.current_device()
+
+
+def get_engine(model_name, w, h, channels, max_batch=None, **kw):
+    """Engine handles are cached per (device, size, channels, weights): workspaces and packed weights stay in HBM
+    across generations."""
+    channels = [int(c) for c in channels]
+    weights, wkey = _resolve_weights(model_name, channels, w, h)
+    dev = _local_device()
+    mb = int(max_batch or int(os.environ.get("EIGEN_MAX_BATCH", DEFAULT_MAX_BATCH)))
+    key = (dev, w, h, tuple(channels), wkey, mb, tuple(sorted(kw.items())))
+    eng = _engines.get(key)
+    if eng is None:
+        eng = Engine(w, h, channels, mb, device=dev, **kw)
+        eng.set_weights(weights)
+        eng._grid_key = None
+        _engines[key] = eng
+    return eng
+
+
+def clear_engines():
+    for e in _engines.values():
+        e.close()
+    _engines.clear()
+
+
+def _set_grid(eng, structure, w, h):
+    key = (int(structure), w, h)
+    if eng._grid_key != key:
+        g = grids.create_grid(structure, w, h, SCALING)
+        eng.set_grid([g["x_mat"], g["y_mat"]])
+        eng._grid_key = key
+
+
+# ----------------------------------------------------------------------------------------------- sharding
+def shard_bounds(n_items, world_size, rank):
+    """Contiguous slice of the population list owned by `rank` (list order matters: scores[i] and the
+    'last maximal genome wins' tie-break, generate_illusion.py:623-628)."""
+    per = int(math.ceil(n_items / float(world_size))) if n_items else 0
+    lo = min(n_items, rank * per)
+    return lo, min(n_items, lo + per), per
+
+
+def _dist():
+    try:
+        import torch.distributed as dist
+    except Exception:
+        return None
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+
+
+def sharded_map(n_items, evaluate, group=None):
+    """Evaluate items [lo, hi) of this rank with ``evaluate(lo, hi) -> float64 array`` and all-gather the
+    scalars so that every rank returns the full float64 vector.  One collective per call; no data-path exchange."""
+    dist = _dist()
+    if dist is None:
+        return np.asarray(evaluate(0, n_items), dtype=np.float64)
+    import torch
+    R, r = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi, per = shard_bounds(n_items, R, r)
+    local = np.zeros(per, dtype=np.float64)
+    if hi > lo:
+        local[:hi - lo] = evaluate(lo, hi)
+    on_gpu = dist.get_backend(group) == "nccl"
+    t = torch.from_numpy(local)
+    if on_gpu:
+        t = t.cuda()
+    out = torch.empty(per * R, dtype=torch.float64, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    full = out.cpu().numpy().reshape(R, per)
+    res = np.zeros(n_items, dtype=np.float64)
+    for k in range(R):
+        a, b, _ = shard_bounds(n_items, R, k)
+        res[a:b] = full[k, :b - a]
+    return res
+
+
+# ----------------------------------------------------------------------------------------------- the API
+def evaluate_population(structure, genomes, model_name, config, w, h, channels, c_dim=3, gradient=1, bg=1,
+                        pairing=PAIR_POPULATION, max_batch=None):
+    """Fitness (float64 array) of a list of genome objects on the local GPU, in chunks of max_batch."""
+    channels = [int(c) for c in channels]
+    if channels[0] != c_dim:
+        raise ValueError("channels[0]=%d but c_dim=%d: PredNet's input channels are the image channels" % (channels[0], c_dim))
+    eng = get_engine(model_name, w, h, channels, max_batch=max_batch)
+    _set_grid(eng, structure, w, h)
+    c_out = c_dim if gradient == 1 else 1
+    out = np.zeros(len(genomes), dtype=np.float64)
+    for i in range(0, len(genomes), eng.max_batch):
+        chunk = genomes[i:i + eng.max_batch]
+        gb = GenomeBatch(chunk, config, c_out)  # Q6: the first c_dim outputs are rendered
+        out[i:i + len(chunk)] = eng.eval_population(gb, int(structure), bg=bg, gradient=gradient, pairing=pairing)
+    return out
+
+
+def get_fitnesses_neat(structure, population, model_name, config, w, h, channels,
+                       id=0, c_dim=3, best_dir=".", gradient=1):
+    """Drop-in for generate_illusion.get_fitnesses_neat: sets ``genome.fitness`` for every (id, genome) pair."""
+    print("Calculating fitnesses of populations: ", len(population))
+    genomes = [g for _, g in population]
+
+    def evaluate(lo, hi):
+        return evaluate_population(structure, genomes[lo:hi], model_name, config, w, h, channels, c_dim=c_dim, gradient=gradient)
+
+    scores = sharded_map(len(genomes), evaluate)
+    best_score, best_illusion, best_genome = 0, 0, None
+    for i, (_, genome) in enumerate(population):
+        genome.fitness = float(scores[i])
+        if scores[i] >= best_score:  # last maximal genome wins (generate_illusion.py:625)
+            best_illusion, best_score, best_genome = i, float(scores[i]), genome
+    print("best", best_score, best_illusion)
+    dist = _dist()
+    if best_genome is not None and best_dir is not None and (dist is None or dist.get_rank() == 0):
+        try:
+            save_best_artifacts(structure, best_genome, model_name, config, w, h, channels, c_dim, best_dir, gradient)
+        except ImportError:
+            pass  # PIL missing: artefacts are cosmetic, fitness is the contract
+    return scores
+
+
+def render_images(structure, genomes, model_name, config, w, h, channels, c_dim=3, gradient=1, bg=1):
+    """uint8 [n, C, H, W] images of get_image_from_cppn (generate_illusion.py:372-460) for a list of genomes."""
+    import torch
+    eng = get_engine(model_name, w, h, channels)
+    _set_grid(eng, structure, w, h)
+    out = []
+    for i in range(0, len(genomes), eng.max_batch):
+        chunk = genomes[i:i + eng.max_batch]
+        gb = GenomeBatch(chunk, config, c_dim if gradient == 1 else 1)
+        d = torch.empty((len(chunk), c_dim, h, w), dtype=torch.uint8, device="cuda")
+        eng.render_cppn(gb, d, bg=bg, gradient=gradient)
+        torch.cuda.synchronize()
+        out.append(d.cpu().numpy())
+    return np.concatenate(out)
+
+
+def save_best_artifacts(structure, genome, model_name, config, w, h, channels, c_dim, best_dir, gradient):
+    """best.png / best_black_bg.png of generate_illusion.py:650-663 (flow overlay and the 800x800 'enhanced'
+    render are listed as next rows in DESIGN.md)."""
+    from PIL import Image
+    os.makedirs(best_dir, exist_ok=True)
+    for bg, name in ((1, "best.png"), (0, "best_black_bg.png")):
+        img = render_images(structure, [genome], model_name, config, w, h, channels, c_dim, gradient, bg)[0]
+        arr = img.transpose(1, 2, 0) if c_dim == 3 else img[0]
+        Image.fromarray(arr, "RGB" if c_dim == 3 else "L").save(os.path.join(best_dir, name), "PNG")
+
+
+def _read_image_chw(image_path, c_dim, w, h):
+    """read_image of chainer_prednet (PIL -> CHW uint8; gray via convert('L') when c_dim == 1), centre crop."""
+    from PIL import Image
+    im = Image.open(image_path)
+    im = im.convert("L") if c_dim == 1 else im.convert("RGB")
+    a = np.asarray(im)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    top, left = (a.shape[0] - h) // 2, (a.shape[1] - w) // 2
+    if top < 0 or left < 0:
+        raise ValueError("image %s is %dx%d, smaller than the requested %dx%d" % (image_path, a.shape[1], a.shape[0], w, h))
+    return np.ascontiguousarray(a[top:top + h, left:left + w].transpose(2, 0, 1))
+
+
+def get_vectors(image_path, model_name, channels, w, h):
+    """fitness_calculator.get_vectors: flow vectors original image -> 2nd extended prediction, np.ndarray (n, 4)
+    float, or ``[None]`` when Lucas-Kanade tracks nothing (fitness_calculator.py:496-502).  ``image_path`` may
+    also be a uint8 array (H,W[,C])."""
+    import torch
+    channels = [int(c) for c in channels]
+    c_dim = channels[0]
+    if isinstance(image_path, np.ndarray):
+        a = image_path if image_path.ndim == 3 else image_path[:, :, None]
+        img = np.ascontiguousarray(a.transpose(2, 0, 1).astype(np.uint8))
+    else:
+        img = _read_image_chw(image_path, c_dim, w, h)
+    eng = get_engine(model_name, w, h, channels)
+    d = torch.from_numpy(img[None]).cuda()
+    _, vecs = eng.eval_images(d, 1, int(StructureType.Free), pairing=PAIR_SINGLE)
+    return np.asarray(vecs[0], dtype=np.float64) if len(vecs[0]) else [None]
+
+
+def calculate_fitness(structure, vectors, image_path, w, h):
+    """fitness_calculator.calculate_fitness on the device scorer.  Deviation (Q15): where the reference raises
+    UnboundLocalError (too few plausible vectors) this returns 0.0, the value get_fitnesses_neat would assign."""
+    import torch
+    if int(structure) not in (0, 1, 2, 3):
+        raise NameError("name 'good_vectors' is not defined")  # what the reference does for an unknown structure
+    v = np.asarray(vectors, dtype=np.float64).reshape(-1, 4) if (len(vectors) and vectors[0] is not None) else np.zeros((0, 4))
+    eng = _score_engine(w, h, max(len(v), 1))
+    K = eng.K
+    if len(v) > K:
+        raise EngineError("%d vectors exceed the scorer capacity %d" % (len(v), K))
+    vec = np.zeros((1, K, 4), dtype=np.float32)
+    vec[0, :len(v)] = v
+    dv = torch.from_numpy(vec).cuda()
+    dc = torch.tensor([len(v)], dtype=torch.int32, device="cuda")
+    df = torch.zeros(1, dtype=torch.float64, device="cuda")
+    eng.score(int(structure), dv, dc, 1, df, width=int(w), height=int(h))
+    torch.cuda.synchronize()
+    return float(df.cpu().numpy()[0])
+
+
+def _score_engine(w, h, n):
+    key = ("score", _local_device())
+    eng = _engines.get(key)
+    if eng is None:
+        eng = Engine(32, 32, [1, 1], 1, device=_local_device(), max_corners=128)  # scorer only: tiny workspaces
+        _engines[key] = eng
+    return eng

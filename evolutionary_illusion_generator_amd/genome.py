@@ -1,0 +1,182 @@
+"""Flatten NEAT genomes into the engine's wire format (include/eigen_engine.h: eigen_genome_batch).
+
+Host-side counterpart of ``pytorch_neat.cppn.create_cppn`` as the reference calls it
+(/root/reference/generate_illusion.py:384-389, 436-441: ``leaf_names=["x","y"]``, no ``output_activation``):
+which connections are expressed, in which order their terms are summed, and what a node without inputs
+evaluates to are decided here; the HIP kernel (csrc/cppn_kernel.h) only executes the resulting program.
+
+Semantics kept (UPSTREAM-RECALL):
+  * ``required_for_output`` reachability runs over ALL connection keys (enabled or not);
+  * enabled connections are taken in ``genome.connections`` dict order; a connection is skipped when
+    neither end is required, or when its source is an output node;
+  * a node with no expressed inputs evaluates to ``torch.full(shape, bias)`` in torch's default dtype
+    float32; products ``w * x`` with such a constant are float32 too.  Here such nodes are folded on the
+    host with numpy float32 arithmetic and each of their outgoing edges becomes an edge from the constant-1
+    leaf whose weight is the float32 product, so the device never sees them.
+"""
+import numpy as np
+
+ACT_IDS = {"sigmoid": 0, "tanh": 1, "abs": 2, "gauss": 3, "identity": 4, "sin": 5, "relu": 6}
+
+
+def _required_for_output(inputs, outputs, connections):
+    required = set(outputs)
+    frontier = set(outputs)
+    while True:
+        t = {a for (a, b) in connections if b in frontier and a not in frontier}
+        if not t:
+            break
+        layer = {x for x in t if x not in inputs}
+        if not layer:
+            break
+        required |= layer
+        frontier |= t
+    return required
+
+
+def _f32_act(name, x):
+    x = np.float32(x)
+    with np.errstate(all="ignore"):
+        if name == "sigmoid":
+            return np.float32(1.0) / (np.float32(1.0) + np.exp(-(np.float32(5) * x)))
+        if name == "tanh":
+            return np.tanh(np.float32(2.5) * x)
+        if name == "abs":
+            return np.abs(x)
+        if name == "gauss":
+            return np.exp(np.float32(-5.0) * (x * x))
+        if name == "identity":
+            return x
+        if name == "sin":
+            return np.sin(x)
+        if name == "relu":
+            return np.maximum(x, np.float32(0))
+    raise ValueError(name)
+
+
+def flatten_genome(genome, config, n_leaves=2):
+    """-> dict(act, bias, resp, edge_off, edge_src, edge_w, out_node) for ONE genome (numpy arrays).
+
+    Leaves are numbered in ``config.genome_config.input_keys`` order; ``edge_src = -(i+1)`` is leaf i and
+    ``-(n_leaves+1)`` the constant 1.0."""
+    gc = config.genome_config
+    in_keys, out_keys = list(gc.input_keys), list(gc.output_keys)
+    if len(in_keys) != n_leaves:
+        raise ValueError("PyTorch-NEAT asserts len(leaf_names) == len(input_keys): %d leaf planes, %d input keys"
+                         % (n_leaves, len(in_keys)))
+    leaf_of = {k: i for i, k in enumerate(in_keys)}
+    required = _required_for_output(in_keys, out_keys, genome.connections)
+    node_inputs = {o: [] for o in out_keys}
+    for cg in genome.connections.values():
+        if not cg.enabled:
+            continue
+        i, o = cg.key
+        if o not in required and i not in required:
+            continue
+        if i in out_keys:
+            continue
+        node_inputs.setdefault(o, []).append((i, cg.weight))
+        node_inputs.setdefault(i, [])
+
+    # topological order by depth-first post-order from the outputs (feed_forward = True: acyclic)
+    order, state = [], {}
+    for root in out_keys:
+        stack = [(root, 0)]
+        while stack:
+            n, ci = stack.pop()
+            if n in leaf_of or state.get(n) == 2:
+                continue
+            conns = node_inputs[n]
+            if ci == 0:
+                if state.get(n) == 1:
+                    raise ValueError("genome %r has a cycle through node %r" % (getattr(genome, "key", None), n))
+                state[n] = 1
+            if ci < len(conns):
+                stack.append((n, ci + 1))
+                child = conns[ci][0]
+                if child not in leaf_of and state.get(child) != 2:
+                    if state.get(child) == 1:
+                        raise ValueError("genome %r has a cycle through node %r" % (getattr(genome, "key", None), child))
+                    stack.append((child, 0))
+            else:
+                state[n] = 2
+                order.append(n)
+
+    const32 = {}   # node -> np.float32 constant
+    index = {}
+    act, bias, resp, edge_off, edge_src, edge_w = [], [], [], [0], [], []
+    ONE = -(n_leaves + 1)
+    for n in order:
+        node = genome.nodes[n]
+        conns = node_inputs[n]
+        if node.aggregation != "sum" and conns:
+            raise ValueError("aggregation %r unsupported (neat_configs/*.txt:17 configure 'sum' only)" % node.aggregation)
+        if node.activation not in ACT_IDS:
+            raise ValueError("activation %r is not in PyTorch-NEAT's str_to_activation" % node.activation)
+        if not conns:
+            const32[n] = np.float32(node.bias)
+            continue
+        if all(i in const32 for i, _ in conns):  # whole sub-graph is float32 constants: fold it
+            with np.errstate(all="ignore"):
+                pre = None
+                for i, w in conns:
+                    t = np.float32(w) * const32[i]
+                    pre = t if pre is None else np.float32(pre + t)
+                z = np.float32(np.float32(node.response) * pre) + np.float32(node.bias)
+                const32[n] = np.float32(_f32_act(node.activation, np.float32(z)))
+            continue
+        index[n] = len(act)
+        act.append(ACT_IDS[node.activation]); bias.append(float(node.bias)); resp.append(float(node.response))
+        # Python's sum() adds left to right: a LEADING run of float32 constants is accumulated in float32 before the
+        # first float64 term promotes the running sum; later float32 terms are promoted one by one.
+        lead = 0
+        while lead < len(conns) and conns[lead][0] in const32:
+            lead += 1
+        if lead:
+            with np.errstate(all="ignore"):
+                pre = None
+                for i, w in conns[:lead]:
+                    t = np.float32(w) * const32[i]
+                    pre = t if pre is None else np.float32(pre + t)
+            edge_src.append(ONE); edge_w.append(float(pre))
+        for i, w in conns[lead:]:
+            if i in leaf_of:
+                edge_src.append(-(leaf_of[i] + 1)); edge_w.append(float(w))
+            elif i in const32:
+                with np.errstate(all="ignore"):
+                    edge_src.append(ONE); edge_w.append(float(np.float32(w) * const32[i]))
+            else:
+                edge_src.append(index[i]); edge_w.append(float(w))
+        edge_off.append(len(edge_src))
+    out_node = []
+    for o in out_keys:
+        if o in const32:  # constant output plane: identity(1 * (k * 1.0) + 0) == k
+            index[o] = len(act)
+            act.append(ACT_IDS["identity"]); bias.append(0.0); resp.append(1.0)
+            edge_src.append(ONE); edge_w.append(float(const32[o])); edge_off.append(len(edge_src))
+        out_node.append(index[o])
+    return dict(act=np.asarray(act, np.uint8), bias=np.asarray(bias, np.float64), resp=np.asarray(resp, np.float64),
+                edge_off=np.asarray(edge_off, np.int32), edge_src=np.asarray(edge_src, np.int32),
+                edge_w=np.asarray(edge_w, np.float64), out_node=np.asarray(out_node, np.int32))
+
+
+class GenomeBatch:
+    """Concatenation of flattened genomes = the arrays behind ``eigen_genome_batch``."""
+
+    def __init__(self, genomes, config, c_out, n_leaves=2):
+        flats = [flatten_genome(g, config, n_leaves) for g in genomes]
+        for f, g in zip(flats, genomes):
+            if len(f["out_node"]) < c_out:
+                raise ValueError("genome %r has %d outputs, %d are rendered" % (getattr(g, "key", None), len(f["out_node"]), c_out))
+        self.n_genomes, self.c_out = len(flats), c_out
+        self.node_off = np.zeros(len(flats) + 1, np.int32)
+        np.cumsum([len(f["act"]) for f in flats], out=self.node_off[1:])
+        eo, base = [np.zeros(1, np.int32)], 0
+        for f in flats:
+            eo.append(f["edge_off"][1:] + base)
+            base += int(f["edge_off"][-1])
+        self.edge_off = np.ascontiguousarray(np.concatenate(eo).astype(np.int32))
+        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([f[k] for f in flats]).astype(dt))
+        self.node_act, self.node_bias, self.node_resp = cat("act", np.uint8), cat("bias", np.float64), cat("resp", np.float64)
+        self.edge_src, self.edge_w = cat("edge_src", np.int32), cat("edge_w", np.float64)
+        self.out_node = np.ascontiguousarray(np.concatenate([f["out_node"][:c_out] for f in flats]).astype(np.int32))

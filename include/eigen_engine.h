@@ -1,0 +1,190 @@
+/*
+ * eigen_engine.h -- C ABI of the MI355X (gfx950) fitness-evaluation engine for EIGen.
+ *
+ * Drop-in boundary for ONE hot path of LanaSina/evolutionary_illusion_generator: per genome
+ *   CPPN render -> PredNet roll-out (20 repeats + self-fed frames) -> Lucas-Kanade flow -> motion score.
+ * The reference is pure Python and has no FFI; each entry point below replaces the Python-level call the
+ * reference makes at the cited file:line, and is what a ctypes binding on the reference side would bind
+ * (stub shown in INTEGRATION.md).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative eigen_status; eigen_last_error() gives the text
+ *     (thread-local);  no exception crosses the ABI.
+ *   - pointers named h_* are HOST memory, d_* are DEVICE (HIP) memory on the engine's device.  The caller
+ *     owns all of them; the engine owns only its handle and its internal device workspaces.
+ *   - all device work is enqueued on the caller-supplied hipStream_t (passed as void*; NULL = default
+ *     stream).  Functions that return host results (h_* outputs) synchronise that stream before returning.
+ *   - a handle is not thread-safe; use one handle per process/rank (one rank per GPU).
+ *   - images are PLANAR uint8 [B][C][H][W] (C = 1 gray or 3 RGB), the CHW form the reference feeds PredNet.
+ */
+#ifndef EIGEN_ENGINE_H
+#define EIGEN_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EIGEN_MAX_LAYERS 8
+#define EIGEN_ABI_VERSION 1
+
+typedef enum {
+    EIGEN_OK = 0,
+    EIGEN_ERR_INVALID = -1,   /* bad argument / unsupported configuration */
+    EIGEN_ERR_HIP = -2,       /* HIP runtime error (message has the hipError string) */
+    EIGEN_ERR_STATE = -3,     /* call order: weights / grid not set */
+    EIGEN_ERR_CAPACITY = -4   /* batch, genome or feature count exceeds what the handle was created for */
+} eigen_status;
+
+/* StructureType of the reference (generate_illusion.py:25-29, fitness_calculator.py:10-14) */
+typedef enum { EIGEN_BANDS = 0, EIGEN_CIRCLES = 1, EIGEN_FREE = 2, EIGEN_CIRCLES_FREE = 3 } eigen_structure;
+
+/* Which two frames Lucas-Kanade compares:
+ *   POPULATION: prediction after step n_repeat -> first extension frame   (generate_illusion.py:543-550)
+ *   SINGLE    : the input image -> second extension frame                 (fitness_calculator.py:493-498) */
+typedef enum { EIGEN_PAIR_POPULATION = 0, EIGEN_PAIR_SINGLE = 1 } eigen_pairing;
+
+/* CPPN activation ids (PyTorch-NEAT activations.py; neat_configs/ circles.txt:12 lists the options in use) */
+typedef enum {
+    EIGEN_ACT_SIGMOID = 0, /* 1/(1+exp(-5x)) */
+    EIGEN_ACT_TANH = 1,    /* tanh(2.5x)     */
+    EIGEN_ACT_ABS = 2,
+    EIGEN_ACT_GAUSS = 3,   /* exp(-5x^2)     */
+    EIGEN_ACT_IDENTITY = 4,
+    EIGEN_ACT_SIN = 5,
+    EIGEN_ACT_RELU = 6
+} eigen_activation;
+
+typedef struct {
+    int32_t device;                        /* HIP device ordinal */
+    int32_t width, height;                 /* image size; both divisible by 2^(n_layers-1) */
+    int32_t n_layers;
+    int32_t channels[EIGEN_MAX_LAYERS];    /* PredNet channels, channels[0] = c_dim (1 or 3) */
+    int32_t max_batch;                     /* genomes evaluated per device batch (workspace sizing) */
+    /* constants hard-coded in the reference (generate_illusion.py:482,531; fitness_calculator.py:470-471) */
+    int32_t n_repeat;                      /* 20 */
+    int32_t n_ext;                         /* 2  */
+    int32_t requant_feedback;              /* 0: extension frames feed the float prediction back (upstream) */
+    /* Optical_Flow_Analyzer / OpenCV parameters (goodFeaturesToTrack, calcOpticalFlowPyrLK) */
+    int32_t lk_max_corners;                /* 100  (<= 128) */
+    int32_t lk_block_size;                 /* 7    */
+    int32_t lk_win;                        /* 15   */
+    int32_t lk_max_level;                  /* 2    */
+    int32_t lk_max_iter;                   /* 10   */
+    int32_t reserved0;
+    double lk_quality_level;               /* 0.3  */
+    double lk_min_distance;                /* 7    */
+    double lk_epsilon;                     /* 0.03 */
+    double lk_min_eig_thr;                 /* 1e-4 */
+} eigen_config;
+
+/* A batch of CPPN genomes, flattened by the host (create_cppn semantics, generate_illusion.py:384-389):
+ * per genome g, nodes node_off[g]..node_off[g+1]-1 are in topological order; node n has incoming edges
+ * edge_off[n]..edge_off[n+1]-1 (global edge index), summed left to right in that order;
+ * value(n) = act(response * sum_k(weight_k * value(src_k)) + bias).
+ * edge_src >= 0 : index of a node of the same genome (relative to node_off[g]);
+ * edge_src <  0 : leaf plane  -1 -> plane 0 (x), -2 -> plane 1 (y), ...; -(n_planes+1) -> the constant 1.0.
+ * out_node[g*c_out + c]: node (relative index) rendered into channel c. */
+typedef struct {
+    int32_t n_genomes;
+    int32_t c_out;              /* outputs rendered per genome: c_dim, or 1 when gradient == 0 */
+    const int32_t* node_off;    /* [n_genomes + 1] */
+    const int32_t* edge_off;    /* [total_nodes + 1] */
+    const uint8_t* node_act;    /* [total_nodes] eigen_activation */
+    const double* node_bias;    /* [total_nodes] */
+    const double* node_resp;    /* [total_nodes] */
+    const int32_t* edge_src;    /* [total_edges] */
+    const double* edge_w;       /* [total_edges] */
+    const int32_t* out_node;    /* [n_genomes * c_out] */
+} eigen_genome_batch;
+
+typedef struct eigen_engine eigen_engine;
+
+int eigen_abi_version(void);
+const char* eigen_last_error(void);
+
+/* Defaults = the constants of the reference + OpenCV tutorial LK parameters; fills every field but
+ * device/width/height/n_layers/channels/max_batch. */
+void eigen_config_defaults(eigen_config* cfg);
+
+int eigen_create(const eigen_config* cfg, eigen_engine** out);
+int eigen_destroy(eigen_engine* e);
+
+/* Replaces `serializers.load_npz(initmodel, model)` inside test_prednet (generate_illusion.py:533).
+ * h_tensors: host float32 tensors in the order of evolutionary_illusion_generator_amd.weights.tensor_names()
+ * (per layer: [ConvA W,b (l>0)], ConvP W,b, per gate i,f,c,o: x0 W, [x1 W], h W, h b; peepholes c_i,c_f,c_o). */
+int eigen_set_prednet_weights(eigen_engine* e, const float* const* h_tensors, int32_t n_tensors);
+
+/* Replaces the per-generation create_grid result (generate_illusion.py:501) as consumed by
+ * get_image_from_cppn (:375-378): n_planes float64 planes of H*W values; background where plane 0 == -1. */
+int eigen_set_grid(eigen_engine* e, const double* h_planes, int32_t n_planes);
+
+/* Replaces get_image_from_cppn (generate_illusion.py:372-460) for a whole batch.
+ * d_images: uint8 [n_genomes][c_dim][H][W].  bg: 1 white / 0 black.  gradient: 1 / 0 as in the reference. */
+int eigen_render_cppn(eigen_engine* e, const eigen_genome_batch* h_genomes, int32_t bg, int32_t gradient,
+                      uint8_t* d_images, void* stream);
+
+/* Replaces test_prednet (generate_illusion.py:533-537, fitness_calculator.py:487-491) for a batch: state
+ * reset, n_repeat steps on the constant frame, then extension steps feeding the prediction back; runs
+ * n_steps <= n_repeat + n_ext steps in total.  The quantised prediction of every step t >= first_out_step
+ * is written to d_frames[b][t - first_out_step] (uint8 [B][n_steps - first_out_step][C][H][W]). */
+int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batch, int32_t n_steps,
+                          int32_t first_out_step, uint8_t* d_frames, void* stream);
+
+/* Replaces lucas_kanade (generate_illusion.py:549-550, fitness_calculator.py:498) for a batch of pairs.
+ * d_img0/d_img1: uint8 planar images, image b at d_imgX + b * strideX (bytes).
+ * d_vectors: float [batch][lk_max_corners][4] rows [x, y, dx, dy]; d_counts: int32 [batch]. */
+int eigen_flow(eigen_engine* e, const uint8_t* d_img0, int64_t stride0, const uint8_t* d_img1, int64_t stride1,
+               int32_t batch, float* d_vectors, int32_t* d_counts, void* stream);
+
+/* Replaces the scoring block of get_fitnesses_neat (generate_illusion.py:559-616; scorers
+ * fitness_calculator.py:18-215).  count == 0 -> the sentinel [[0,0,-1000,0]] -> fitness 0.
+ * width/height: the image size the scorers are given (w, h); 0 = the engine's own size. */
+int eigen_score(eigen_engine* e, int32_t structure, int32_t width, int32_t height, const float* d_vectors,
+                const int32_t* d_counts, int32_t batch, double* d_fitness, void* stream);
+
+/* The whole path for one batch of genomes: render -> roll-out -> flow -> score.  h_fitness: host double[B].
+ * This is what eval_genomes / get_fitnesses_neat (generate_illusion.py:478-673, 692-694) calls per shard. */
+int eigen_eval_population(eigen_engine* e, const eigen_genome_batch* h_genomes, int32_t structure, int32_t bg,
+                          int32_t gradient, int32_t pairing, double* h_fitness, void* stream);
+
+/* Same, for ready-made images (single-image API, fitness_calculator.py:468-548). */
+int eigen_eval_images(eigen_engine* e, const uint8_t* d_images, int32_t batch, int32_t structure,
+                      int32_t pairing, double* h_fitness, float* h_vectors, int32_t* h_counts, void* stream);
+
+/* ---- kernel-level entry points used by the parity tests and bench.py's roofline leg ---- */
+
+/* One fused 3x3 convolution chain on the MFMA kernel: out[b][o][y][x] = sum over sources/channels/taps, raw
+ * accumulators (no bias).  d_src[i]: float [batch][cin[i]][H>>up[i]][W>>up[i]]; h_w[i]: host float
+ * [cout][cin[i]][3][3].  d_out: float [batch][cout][H][W]. */
+int eigen_test_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, const int32_t* cin,
+                    const int32_t* up, const float* const* h_w, int32_t cout, int32_t H, int32_t W,
+                    int32_t batch, float* d_out, void* stream);
+
+/* Deterministic fp32 exp / sigmoid / tanh used by the gate epilogue. */
+int eigen_test_det_math(eigen_engine* e, const float* d_x, int32_t n, float* d_exp, float* d_sig, float* d_tanh,
+                        void* stream);
+
+/* Per-stage timing of the last eigen_eval_* call, milliseconds, measured with HIP events on the stream:
+ * [0] render  [1] PredNet roll-out  [2] flow  [3] score  [4] PredNet conv kernels only (sum)
+ * [5] number of conv kernel launches in the roll-out. */
+int eigen_get_timings(eigen_engine* e, double* h_ms6);
+
+/* Per-op profile of the roll-out convolutions.  enable=1 brackets every conv launch with HIP events recorded on the
+ * launch stream (and waits for each).  h_out rows (8 doubles each, at most max_ops rows):
+ * [layer, epilogue (1 LSTM, 2 ConvA, 3 ConvP), NI, TW, launches, total_ms, algorithmic FLOPs per launch per image,
+ *  n_nblk].  reset=1 clears the accumulators after reading. */
+int eigen_conv_profile(eigen_engine* e, int32_t enable, int32_t reset, double* h_out, int32_t max_ops, int32_t* n_ops);
+
+/* Stage-level read-back for the parity tests: corners / tracked points / status of the last eigen_flow call. */
+int eigen_debug_corners(eigen_engine* e, int32_t batch, float* h_corners, int32_t* h_ncorners, float* h_next,
+                        uint8_t* h_status, void* stream);
+
+/* Algorithmic FLOPs (2 x MACs of the 3x3 convolutions) of one PredNet step for one genome. */
+double eigen_prednet_flops_per_step(const eigen_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EIGEN_ENGINE_H */

@@ -1,0 +1,229 @@
+"""GPU parity tests: HIP path (through the C ABI) vs the CPU oracle, stage by stage and end to end.
+
+Bars: byte/integer/index outputs bit-exact (rendered images, PredNet frames, corner
+lists, vector counts); fp32 conv accumulators and gate math bit-exact against the oracle's canonical fma
+chain; flow vectors bit-exact (same integer window sums, same fp32 solve); fitness within 1e-9 relative
+(float64 sums in a different order), far inside north_star's 1e-4.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from evolutionary_illusion_generator_amd import genome as genome_mod
+from evolutionary_illusion_generator_amd import synth, weights
+from evolutionary_illusion_generator_amd.engine import PAIR_POPULATION, PAIR_SINGLE, Engine
+
+
+def _eng(w, h, ch, B, **kw):
+    return Engine(w, h, ch, B, **kw)
+
+
+def test_det_math_bit_exact(cuda, oracle_lib):
+    import torch
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rng.normal(0, 3, 200000), rng.uniform(-100, 100, 20000), np.linspace(-1, 1, 20001),
+                        [0.0, -0.0, 0.625, -0.625, 80, -80, 88, 1e-30, -1e-30]]).astype(np.float32)
+    e = _eng(16, 16, [1, 4], 1)
+    dx = torch.from_numpy(x).to(cuda)
+    de, ds, dt = (torch.empty_like(dx) for _ in range(3))
+    e.test_det_math(dx, x.size, de, ds, dt)
+    torch.cuda.synchronize()
+    oe, os_, ot = oracle_lib.det_math(x)
+    assert np.array_equal(de.cpu().numpy(), oe)
+    assert np.array_equal(ds.cpu().numpy(), os_)
+    assert np.array_equal(dt.cpu().numpy(), ot)
+    # and they are the functions they claim to be
+    assert np.max(np.abs(ot - np.tanh(x.astype(np.float64)))) < 3e-7
+    assert np.max(np.abs(os_ - 1 / (1 + np.exp(-x.astype(np.float64))))) < 3e-7
+
+
+CONV_CASES = [
+    # (B, H, W, cout, [(cin, up), ...])
+    (2, 16, 16, 16, [(8, 0)]),
+    (3, 32, 32, 48, [(6, 0)]),            # ConvA1-like, channel padding 6 -> 8, NI = 3
+    (2, 16, 32, 3, [(3, 0)]),             # ConvP0-like, cout 3, cin 3 -> 4
+    (2, 32, 16, 20, [(16, 0), (12, 1), (8, 0)]),  # three sources, one unpooled
+    (5, 8, 8, 64, [(32, 0)]),             # 8x8 maps: four images per block
+    (3, 20, 12, 32, [(20, 0), (8, 1)]),   # ragged map -> partial tiles (TW = 8)
+    (1, 24, 40, 36, [(40, 0)]),           # ragged map with 16x16 tiles, >1 K-block, cout padding
+    (2, 64, 64, 12, [(6, 0), (48, 1), (3, 0)]),  # LSTM0-like source mix
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_chain_bit_exact(cuda, oracle_lib, case):
+    import torch
+    B, H, W, cout, srcs = case
+    rng = np.random.default_rng(hash(case[:4]) & 0xFFFF)
+    e = _eng(16, 16, [1, 4], 1)
+    hs, hw, ds = [], [], []
+    for cin, up in srcs:
+        a = rng.normal(0, 1, (B, cin, H >> up, W >> up)).astype(np.float32)
+        a[rng.random(a.shape) < 0.3] = 0.0  # relu-like sparsity
+        hs.append(a)
+        hw.append(rng.normal(0, 0.2, (cout, cin, 3, 3)).astype(np.float32))
+        ds.append(torch.from_numpy(a).to(cuda))
+    out = torch.full((B, cout, H, W), float("nan"), device=cuda)
+    e.test_conv(ds, [c for c, _ in srcs], [u for _, u in srcs], hw, cout, H, W, B, out)
+    got = out.cpu().numpy()
+    for b in range(B):
+        ref = oracle_lib.conv_chain([s[b] for s in hs], [u for _, u in srcs], hw, H, W)
+        assert np.array_equal(got[b], ref), "image %d: max abs diff %g" % (b, np.nanmax(np.abs(got[b] - ref)))
+
+
+def _render_setup(w, h, c_dim, n, seed, structure=1):
+    from oracle import grids
+    cfg = synth.make_config(2, 3 if c_dim == 3 else 1)
+    pop = synth.make_population(n, cfg, seed=seed)
+    grid = grids.create_grid(structure, w, h, 10)
+    return cfg, pop, grid
+
+
+@pytest.mark.parametrize("c_dim,gradient,bg", [(3, 1, 1), (1, 1, 1), (3, 0, 1), (1, 0, 0), (3, 1, 0)])
+def test_cppn_render_matches_oracle(cuda, oracle_lib, c_dim, gradient, bg):
+    import torch
+    from oracle import cppn
+    w, h = 64, 48
+    cfg, pop, grid = _render_setup(w, h, c_dim, 24, seed=3)
+    # make some genomes hit the constant-node folding
+    for gid, g in pop[::4]:
+        for key, c in g.connections.items():
+            if key[1] in (5, 6):
+                c.enabled = False
+    e = _eng(w, h, [c_dim, 4, 8], len(pop))
+    e.set_grid([grid["x_mat"], grid["y_mat"]])
+    gb = genome_mod.GenomeBatch([g for _, g in pop], cfg, c_dim if gradient == 1 else 1)
+    img = torch.zeros((len(pop), c_dim, h, w), dtype=torch.uint8, device=cuda)
+    e.render_cppn(gb, img, bg=bg, gradient=gradient)
+    torch.cuda.synchronize()
+    got = img.cpu().numpy()
+    n_diff = 0
+    for i, (_, g) in enumerate(pop):
+        ref = cppn.render(grid, g, cfg, c_dim, w, h, bg=bg, gradient=gradient)
+        ref = ref.transpose(2, 0, 1) if ref.ndim == 3 else ref[None]
+        n_diff += int((ref != got[i]).sum())
+    # float64 libm vs ocml differ by <= 1-2 ulp: a byte can only flip when v*255 sits within ~1e-13 of an integer
+    assert n_diff == 0, "%d bytes differ" % n_diff
+
+
+@pytest.mark.parametrize("w,h,ch,requant", [(64, 64, [1, 16, 32, 64], False), (48, 32, [3, 8, 16, 32], False),
+                                              (80, 40, [3, 12, 20], True), (160, 120, [1, 16, 32, 64], False)])
+def test_prednet_rollout_frames_bit_exact(cuda, oracle_lib, w, h, ch, requant):
+    import torch
+    from oracle import cppn
+    c_dim = ch[0]
+    cfg, pop, grid = _render_setup(w, h, c_dim, 3, seed=11)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=4)
+    imgs = []
+    for _, g in pop:
+        r = cppn.render(grid, g, cfg, c_dim, w, h)
+        imgs.append(r.transpose(2, 0, 1) if r.ndim == 3 else r[None])
+    imgs = np.ascontiguousarray(np.stack(imgs))
+    e = _eng(w, h, ch, len(pop), requant_feedback=requant)
+    e.set_weights(wts)
+    d_img = torch.from_numpy(imgs).to(cuda)
+    T = 22
+    d_fr = torch.zeros((len(pop), T, c_dim, h, w), dtype=torch.uint8, device=cuda)
+    e.prednet_rollout(d_img, len(pop), T, 0, d_fr)
+    torch.cuda.synchronize()
+    got = d_fr.cpu().numpy()
+    for i in range(len(pop)):
+        ref = oracle_lib.prednet_rollout(wts, ch, w, h, imgs[i], requant=requant)
+        for t in range(T):
+            assert np.array_equal(got[i, t], ref[t]), "genome %d step %d: %d bytes differ" % (i, t, (got[i, t] != ref[t]).sum())
+    # the population path asks only for steps 19, 20
+    d2 = torch.zeros((len(pop), 2, c_dim, h, w), dtype=torch.uint8, device=cuda)
+    e.prednet_rollout(d_img, len(pop), 21, 19, d2)
+    torch.cuda.synchronize()
+    assert np.array_equal(d2.cpu().numpy(), got[:, 19:21])
+
+
+def _textured_pairs(rng, B, c, h, w):
+    """Smooth random textures and a sub-pixel-shifted, slightly perturbed copy (uint8 planar)."""
+    from numpy.fft import irfft2, rfft2
+    a = rng.normal(0, 1, (B, c, h, w))
+    fy, fx = np.meshgrid(np.fft.fftfreq(h), np.fft.rfftfreq(w), indexing="ij")
+    filt = np.exp(-(fy ** 2 + fx ** 2) * 60.0)
+    base = irfft2(rfft2(a) * filt, s=(h, w))
+    sh = irfft2(rfft2(a) * filt * np.exp(-2j * np.pi * (fy * 0.12 + fx * -0.17)), s=(h, w))
+    def q(v):
+        v = (v - v.min()) / (v.max() - v.min())
+        return (v * 255).astype(np.uint8)
+    return q(base), q(sh)
+
+
+@pytest.mark.parametrize("w,h,c", [(64, 64, 1), (160, 120, 3), (96, 40, 3)])
+def test_flow_vectors_bit_exact(cuda, oracle_lib, w, h, c):
+    import torch
+    rng = np.random.default_rng(5)
+    B = 6
+    i0, i1 = _textured_pairs(rng, B, c, h, w)
+    i0[-1] = 128  # a flat image: no corners
+    e = _eng(w, h, [c, 4, 8], B)
+    d0, d1 = torch.from_numpy(i0).to(cuda), torch.from_numpy(i1).to(cuda)
+    dv = torch.zeros((B, e.K, 4), dtype=torch.float32, device=cuda)
+    dc = torch.zeros(B, dtype=torch.int32, device=cuda)
+    e.flow(d0, c * h * w, d1, c * h * w, B, dv, dc)
+    torch.cuda.synchronize()
+    corners, ncorn, _, _ = e.debug_corners(B)
+    v, n = dv.cpu().numpy(), dc.cpu().numpy()
+    total = 0
+    for b in range(B):
+        g0 = oracle_lib.gray(i0[b])
+        ref_c = oracle_lib.good_features(g0)
+        assert ncorn[b] == len(ref_c)
+        assert np.array_equal(corners[b, :ncorn[b]], ref_c)
+        ref = oracle_lib.lucas_kanade(i0[b], i1[b])
+        assert n[b] == len(ref), (b, n[b], len(ref))
+        assert np.array_equal(v[b, :n[b]], ref), np.abs(v[b, :n[b]] - ref).max()
+        total += len(ref)
+    assert total > 50 and n[-1] == 0
+
+
+@pytest.mark.parametrize("structure", [0, 1, 2, 3])
+def test_scores_match_oracle(cuda, structure):
+    import torch
+    from oracle import scores
+    rng = np.random.default_rng(structure)
+    w, h, K = 160, 120, 100
+    B = 12
+    e = _eng(w, h, [1, 4, 8], B)
+    vec = np.zeros((B, K, 4), np.float32)
+    cnt = np.zeros(B, np.int32)
+    for b in range(B):
+        n = [0, 1, 2, 24, 25, 26, 40, 75, 100, 60, 30, 99][b]
+        cnt[b] = n
+        vec[b, :n, 0] = rng.integers(1, w - 1, n); vec[b, :n, 1] = rng.integers(1, h - 1, n)
+        vec[b, :n, 2:] = rng.normal(0, [0.05, 0.1, 0.12, 0.2][b % 4], (n, 2))
+    dv, dc = torch.from_numpy(vec).to(cuda), torch.from_numpy(cnt).to(cuda)
+    df = torch.zeros(B, dtype=torch.float64, device=cuda)
+    e.score(structure, dv, dc, B, df)
+    torch.cuda.synchronize()
+    got = df.cpu().numpy()
+    nz = 0
+    for b in range(B):
+        ref = scores.fitness_from_vectors(structure, vec[b, :cnt[b]].astype(np.float64), w, h)
+        assert got[b] == pytest.approx(ref, rel=1e-9, abs=1e-12), (b, got[b], ref)
+        nz += ref != 0
+    assert nz >= 3
+
+
+@pytest.mark.parametrize("w,h,ch,structure,pairing", [(64, 64, [1, 16, 32, 64], 2, PAIR_POPULATION),
+                                                       (160, 120, [1, 16, 32, 64], 1, PAIR_POPULATION),
+                                                       (96, 64, [3, 12, 24, 48], 1, PAIR_POPULATION),
+                                                       (160, 120, [1, 8, 16, 32], 3, PAIR_POPULATION),
+                                                       (64, 64, [3, 8, 16, 32], 2, PAIR_SINGLE)])
+def test_end_to_end_fitness(cuda, oracle_lib, w, h, ch, structure, pairing):
+    from oracle import pipeline
+    c_dim = ch[0]
+    cfg, pop, grid = _render_setup(w, h, c_dim, 6, seed=21, structure=structure)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=7)
+    e = _eng(w, h, ch, len(pop))
+    e.set_weights(wts)
+    e.set_grid([grid["x_mat"], grid["y_mat"]])
+    gb = genome_mod.GenomeBatch([g for _, g in pop], cfg, c_dim)
+    got = e.eval_population(gb, structure, pairing=pairing)
+    ref = np.array([pipeline.genome_fitness(g, cfg, grid, wts, ch, w, h, structure, pairing=pairing) for _, g in pop])
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-12, equal_nan=True), (got, ref)
+    assert (ref != 0).sum() >= 2, "vacuous parity: the oracle scored everything 0"
