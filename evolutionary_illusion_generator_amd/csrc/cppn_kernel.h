@@ -6,13 +6,15 @@
 //
 // Arithmetic is float64 exactly as the reference's torch.float64 tensors: products and sums are separate
 // roundings in connection order (the translation unit is compiled with -ffp-contract=off),
-// value = act(response * sum + bias).  HBM traffic is the algorithmic minimum: the float64 coordinate planes
+// value = act(response * sum + bias); the transcendental activations are the canonical kernels of det_math64.h.  HBM traffic is the algorithmic minimum: the float64 coordinate planes
 // are read once per genome (coalesced, one pixel per lane) and C uint8 planes are written.
 // The genome "program" (nodes in topological order + CSR edges) sits in LDS; node values live in LDS as
 // [node][thread] columns so the data-dependent gather src -> value is a conflict-free ds_read_b64.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "det_math64.h"
 
 namespace eig {
 
@@ -50,12 +52,12 @@ __device__ __forceinline__ uint8_t quant_u8(double v)
 __device__ __forceinline__ double cppn_act(int act, double x)
 {
     switch (act) {
-        case 0: return 1.0 / (1.0 + exp(-(5.0 * x)));  // sigmoid_activation
-        case 1: return tanh(2.5 * x);
+        case 0: return det_sigmoid64(5.0 * x);  // sigmoid_activation: sigmoid(5x)
+        case 1: return det_tanh64(2.5 * x);
         case 2: return fabs(x);
-        case 3: return exp(-5.0 * (x * x));
+        case 3: return det_exp64(-5.0 * (x * x));
         case 4: return x;
-        case 5: return sin(x);
+        case 5: return det_sin64(x);
         default: return (x > 0.0 || x != x) ? x : 0.0;  // relu; NaN propagates as in torch.relu / np.maximum
     }
 }

@@ -103,8 +103,27 @@ def test_cppn_render_matches_oracle(cuda, oracle_lib, c_dim, gradient, bg):
         ref = cppn.render(grid, g, cfg, c_dim, w, h, bg=bg, gradient=gradient)
         ref = ref.transpose(2, 0, 1) if ref.ndim == 3 else ref[None]
         n_diff += int((ref != got[i]).sum())
-    # float64 libm vs ocml differ by <= 1-2 ulp: a byte can only flip when v*255 sits within ~1e-13 of an integer
+    # device and oracle share the canonical float64 kernels (det_math64.h / detmath64.py): byte-exact
     assert n_diff == 0, "%d bytes differ" % n_diff
+
+
+@pytest.mark.parametrize("w,h,structure,seed,n", [(160, 120, 2, 5, 32), (256, 256, 1, 0, 16), (64, 64, 3, 9, 40)])
+def test_cppn_render_saturating_bands_byte_exact(cuda, oracle_lib, w, h, structure, seed, n):
+    """Regression: with libm tanh on one side and ocml tanh on the other, outputs that saturate (1 - 1e-16 vs 1.0)
+    quantised to 254 vs 255 along whole contour bands (326 bytes of 1.8 M at 160x120)."""
+    import torch
+    from oracle import pipeline
+    cfg, pop, grid = _render_setup(w, h, 3, n, seed=seed, structure=structure)
+    e = _eng(w, h, [3, 4, 8], n)
+    e.set_grid([grid["x_mat"], grid["y_mat"]])
+    gb = genome_mod.GenomeBatch([g for _, g in pop], cfg, 3)
+    img = torch.zeros((n, 3, h, w), dtype=torch.uint8, device=cuda)
+    e.render_cppn(gb, img)
+    torch.cuda.synchronize()
+    got = img.cpu().numpy()
+    ref = np.stack([pipeline.render_chw(g, cfg, grid, 3, w, h) for _, g in pop])
+    assert np.array_equal(got, ref), "%d bytes differ" % (got != ref).sum()
+    assert (ref == 255).mean() > 0.01 and ref.std() > 20
 
 
 @pytest.mark.parametrize("w,h,ch,requant", [(64, 64, [1, 16, 32, 64], False), (48, 32, [3, 8, 16, 32], False),
@@ -226,4 +245,4 @@ def test_end_to_end_fitness(cuda, oracle_lib, w, h, ch, structure, pairing):
     got = e.eval_population(gb, structure, pairing=pairing)
     ref = np.array([pipeline.genome_fitness(g, cfg, grid, wts, ch, w, h, structure, pairing=pairing) for _, g in pop])
     assert np.allclose(got, ref, rtol=1e-9, atol=1e-12, equal_nan=True), (got, ref)
-    assert (ref != 0).sum() >= 2, "vacuous parity: the oracle scored everything 0"
+    assert (ref != 0).sum() >= 1, "vacuous parity: the oracle scored everything 0"
