@@ -1,0 +1,135 @@
+"""CPU: self-consistency of the C oracle (the stages whose parity is UNPINNED -- no reference fixture exists)."""
+import numpy as np
+import pytest
+
+
+def test_conv_chain_is_the_documented_fma_chain(oracle_lib):
+    rng = np.random.default_rng(0)
+    H, W = 6, 7
+    srcs = [rng.normal(0, 1, (5, H, W)).astype(np.float32), rng.normal(0, 1, (3, H // 2 + 0, W // 2 + 0)).astype(np.float32)]
+    srcs[1] = rng.normal(0, 1, (3, 3, 4)).astype(np.float32)  # half resolution of 6x8 -> use W=8
+    H, W = 6, 8
+    srcs[0] = rng.normal(0, 1, (5, H, W)).astype(np.float32)
+    ws = [rng.normal(0, 0.3, (4, 5, 3, 3)).astype(np.float32), rng.normal(0, 0.3, (4, 3, 3, 3)).astype(np.float32)]
+    got = oracle_lib.conv_chain(srcs, [0, 1], ws, H, W)
+    ref = np.zeros((4, H, W), np.float32)
+    for o in range(4):
+        for y in range(H):
+            for x in range(W):
+                acc = np.float32(0)
+                for s, (src, w, up) in enumerate(zip(srcs, ws, [0, 1])):
+                    for c in range(src.shape[0]):
+                        for ky in range(3):
+                            for kx in range(3):
+                                yy, xx = y + ky - 1, x + kx - 1
+                                v = np.float32(0)
+                                if 0 <= yy < H and 0 <= xx < W:
+                                    v = src[c, yy >> up, xx >> up]
+                                # fused multiply-add: exact product, one rounding
+                                acc = np.float32(np.float64(v) * np.float64(w[o, c, ky, kx]) + np.float64(acc))
+                ref[o, y, x] = acc
+    assert np.array_equal(got, ref)
+
+
+def test_det_math32_accuracy(oracle_lib):
+    x = np.concatenate([np.linspace(-30, 30, 200001), [0.0, 0.625, -0.625, 80, -80, 100, -100]]).astype(np.float32)
+    e, s, t = oracle_lib.det_math(x)
+    xd = x.astype(np.float64)
+    ok = np.abs(xd) <= 80
+    assert np.max(np.abs(e[ok] - np.exp(xd[ok])) / np.exp(xd[ok])) < 3e-7
+    assert np.max(np.abs(s - 1 / (1 + np.exp(-xd)))) < 2e-7
+    assert np.max(np.abs(t - np.tanh(xd))) < 2e-7
+    assert t[np.abs(x) > 10].tolist() == np.sign(x[np.abs(x) > 10]).tolist()
+
+
+def test_det_math64_accuracy():
+    from oracle import detmath64 as d
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.normal(0, 5, 100000), rng.uniform(-300, 300, 50000), np.linspace(-1, 1, 4001)])
+    ulp = lambda a, b: np.abs(a - b) / np.spacing(np.abs(b))
+    assert ulp(d.det_exp(x), np.exp(x)).max() <= 2
+    assert ulp(d.det_tanh(x), np.tanh(x))[x != 0].max() <= 3
+    s = np.sin(x)
+    assert (np.abs(d.det_sin(x) - s) <= 4 * np.spacing(np.abs(s)) + 1e-16).all()
+    assert np.all(d.det_tanh(np.array([20.0, 40.0, 1e300, np.inf])) == 1.0) and np.all(d.det_tanh(-np.array([20.0, np.inf])) == -1.0)
+    assert np.isnan(d.det_sin(np.array([np.inf, np.nan]))).all() and np.isnan(d.det_exp(np.array([np.nan]))).all()
+
+
+@pytest.mark.parametrize("w,h,ch,requant", [(32, 24, [1, 4, 8], False), (32, 32, [3, 6, 8, 12], False), (40, 24, [3, 5, 7], True)])
+def test_prednet_c_matches_independent_torch_restatement(oracle_lib, w, h, ch, requant):
+    from evolutionary_illusion_generator_amd import weights
+    from oracle.prednet_torch import PredNetTorch
+    rng = np.random.default_rng(3)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=5)
+    img = rng.integers(0, 256, (ch[0], h, w)).astype(np.uint8)
+    img[:, : h // 2] = np.clip(np.linspace(0, 255, w)[None, None, :] + rng.normal(0, 8, (ch[0], h // 2, w)), 0, 255).astype(np.uint8)
+    fr, p0 = oracle_lib.prednet_rollout(wts, ch, w, h, img, requant=requant, return_float=True)
+    f2, p2 = PredNetTorch(wts, ch, w, h).rollout(img[None], requant=requant)
+    if not requant:
+        assert np.abs(p0 - p2[0]).max() < 5e-6
+    assert (fr != f2[0]).mean() < 2e-3          # uint8 flips only at quantisation boundaries
+    assert np.abs(fr.astype(int) - f2[0].astype(int)).max() <= (1 if not requant else 2)
+    assert fr.shape == (22, ch[0], h, w)
+    assert np.abs(fr[19].astype(int) - img.astype(int)).mean() < 40  # the synthetic net does track its input
+
+
+def test_prednet_rejects_sizes_the_pooling_cannot_halve(oracle_lib):
+    from evolutionary_illusion_generator_amd import weights
+    with pytest.raises(ValueError):
+        weights.tensor_shapes([1, 4, 8, 16], 36, 36)
+    wts = weights.synthetic_prednet_weights([1, 4, 8], 12, 12)
+    with pytest.raises(ValueError):
+        oracle_lib.prednet_rollout(wts, [1, 4, 8], 10, 10, np.zeros((1, 10, 10), np.uint8))
+
+
+def test_gray_and_pyrdown_known_values(oracle_lib):
+    img = np.zeros((3, 4, 4), np.uint8)
+    img[0], img[1], img[2] = 255, 0, 0
+    assert oracle_lib.gray(img)[0, 0] == (255 * 9798 + (1 << 14)) >> 15  # 76
+    img[:] = 200
+    assert np.all(oracle_lib.gray(img) == 200)
+    g = np.full((8, 10), 37, np.uint8)
+    assert np.all(oracle_lib.pyr_down(g) == 37) and oracle_lib.pyr_down(g).shape == (4, 5)
+    g = np.zeros((9, 9), np.uint8); g[4, 4] = 255
+    d = oracle_lib.pyr_down(g)
+    assert d.shape == (5, 5) and d[2, 2] == (255 * 36 + 128) >> 8 and d[1, 2] == (255 * 6 + 128) >> 8
+
+
+def _texture(rng, h, w, shift=(0.0, 0.0)):
+    from numpy.fft import irfft2, rfft2
+    a = rng.normal(0, 1, (h, w))
+    fy, fx = np.meshgrid(np.fft.fftfreq(h), np.fft.rfftfreq(w), indexing="ij")
+    filt = np.exp(-(fy ** 2 + fx ** 2) * 80.0)
+    ph = np.exp(-2j * np.pi * (fy * shift[1] + fx * shift[0]))
+    f = rfft2(a) * filt
+    base, sh = irfft2(f, s=(h, w)), irfft2(f * ph, s=(h, w))
+    lo, hi = base.min(), base.max()
+    q = lambda v: np.clip((v - lo) / (hi - lo) * 255, 0, 255).astype(np.uint8)
+    return q(base), q(sh)
+
+
+def test_lucas_kanade_recovers_a_known_subpixel_shift(oracle_lib):
+    rng = np.random.default_rng(4)
+    g0, g1 = _texture(rng, 96, 128, shift=(0.30, -0.20))
+    v = oracle_lib.lucas_kanade(g0[None], g1[None])
+    assert len(v) >= 20
+    assert abs(np.median(v[:, 2]) - 0.30) < 0.05 and abs(np.median(v[:, 3]) + 0.20) < 0.05
+    # corners: integer coordinates, inside the 1-pixel border, at least minDistance apart, at most maxCorners
+    pts = oracle_lib.good_features(g0)
+    assert len(pts) <= 100 and np.all(pts == np.round(pts)) and pts[:, 0].min() >= 1 and pts[:, 1].max() <= 94
+    d = np.hypot(pts[:, None, 0] - pts[None, :, 0], pts[:, None, 1] - pts[None, :, 1]) + np.eye(len(pts)) * 100
+    assert d.min() >= 7
+    eig = oracle_lib.min_eig(g0)
+    vals = eig[pts[:, 1].astype(int), pts[:, 0].astype(int)]
+    assert np.all(np.diff(vals) <= 0) and vals[-1] > 0.3 * eig.max()
+
+
+def test_lucas_kanade_edge_cases(oracle_lib):
+    flat = np.full((1, 64, 64), 90, np.uint8)
+    assert len(oracle_lib.lucas_kanade(flat, flat)) == 0            # nothing to track -> caller substitutes the sentinel
+    rng = np.random.default_rng(5)
+    g0, _ = _texture(rng, 64, 64)
+    v = oracle_lib.lucas_kanade(g0[None], g0[None])
+    assert len(v) > 0 and np.all(v[:, 2:] == 0)                      # identical frames -> zero flow
+    small = rng.integers(0, 255, (1, 20, 24)).astype(np.uint8)       # pyramid cannot go below the 15-px window
+    oracle_lib.lucas_kanade(small, small)

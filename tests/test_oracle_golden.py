@@ -1,0 +1,93 @@
+"""CPU: the oracle's restatements (and the product's host-side grid code) against golden vectors produced by
+IMPORTING the reference (tests/golden/make_golden.py; the reference itself never travels)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+GRID_CASES = [("circles_64x64", 1, 64, 64), ("circles_160x120", 1, 160, 120), ("circles_96x64", 1, 96, 64),
+              ("circlesfree_64x64", 3, 64, 64), ("circlesfree_80x60", 3, 80, 60), ("free_64x64", 2, 64, 64),
+              ("free_160x120", 2, 160, 120), ("bands_160x120", 0, 160, 120), ("bands_80x40", 0, 80, 40)]
+
+
+@pytest.mark.parametrize("name,structure,w,h", GRID_CASES)
+def test_grids_bit_exact(name, structure, w, h):
+    from evolutionary_illusion_generator_amd import grids as product_grids
+    from oracle import grids as oracle_grids
+    g = np.load(os.path.join(GOLD, "grids.npz"))
+    gx, gy = g[name + "_x"].reshape(h, w), g[name + "_y"].reshape(h, w)
+    for impl in (oracle_grids, product_grids):
+        o = impl.create_grid(structure, w, h, 10)
+        assert o["x_mat"].shape == (h, w)
+        assert np.array_equal(o["x_mat"], gx) and np.array_equal(o["y_mat"], gy), impl.__name__
+
+
+def test_enhanced_grid_bit_exact():
+    from evolutionary_illusion_generator_amd import grids
+    g = np.load(os.path.join(GOLD, "grids.npz"))
+    e = grids.enhanced_image_grid(120, 120, 1)
+    assert np.array_equal(e["x_mat"], g["enhanced_circles_120x120_x"])
+    assert np.array_equal(e["y_mat"], g["enhanced_circles_120x120_y"])
+
+
+def test_bands_generalisation_for_sizes_the_reference_rejects():
+    from evolutionary_illusion_generator_amd import grids
+    o = grids.create_grid(0, 256, 256, 10)  # reference: ValueError (256 % 10 != 0), SURVEY Q5
+    assert o["x_mat"].shape == (256, 256) and np.all(o["x_mat"][:, 250:] == 0)
+    from oracle import grids as og
+    with pytest.raises(ValueError):
+        og.create_grid(0, 256, 256, 10)
+
+
+def test_postprocess_matches_reference_bytes():
+    from oracle import cppn
+    z = np.load(os.path.join(GOLD, "postprocess.npz"))
+    meta = json.load(open(os.path.join(GOLD, "postprocess.json")))
+    w, h = meta["w"], meta["h"]
+    for ci, case in enumerate(meta["cases"]):
+        out = cppn.postprocess(list(z["case%d_planes" % ci]), z["grid_x"], case["c_dim"], w, h, bg=case["bg"], gradient=case["gradient"])
+        assert out.dtype == np.uint8 and np.array_equal(out, z["case%d_img" % ci]), case
+
+
+def test_scorers_bit_exact():
+    from oracle import scores as S
+    d = json.load(open(os.path.join(GOLD, "scores.json")))
+    w, h = d["w"], d["h"]
+    checked = 0
+    for case in d["cases"]:
+        v = np.asarray(case["vectors"])
+        for lim in (0.15, 0.3, 0.4):
+            r, good = S.plausibility_ratio(v, lim)
+            assert [r, len(good)] == case["plaus_%g" % lim]
+            if len(good):
+                for name, val in (("strength", S.strength_number(good, lim)), ("hsym", S.horizontal_symmetry_score(good, [0, h / 4 * 2])),
+                                  ("rot", S.rotation_symmetry_score(good, w, h, [0, h / 2])), ("swarm", S.swarm_score(good))):
+                    ref = case["%s_%g" % (name, lim)]
+                    assert float(val) == ref or (np.isnan(val) and np.isnan(ref)), (name, lim)
+                    checked += 1
+        for st in (0, 1, 2, 3):
+            ref = case["fitness_%d" % st]
+            got = S.fitness_from_vectors(st, v, w, h)
+            if ref == "UnboundLocalError":  # calculate_fitness crashes where get_fitnesses_neat scores 0 (Q15)
+                assert got == 0.0
+            else:
+                assert got == ref
+    assert checked > 100
+
+
+def test_orchestration_matches_get_fitnesses_neat():
+    """Fitness assigned by the reference's get_fitnesses_neat for stubbed LK vectors, and its call contract:
+    20 repeats per genome, extension_start 20, duration 2, reset_at 22, LK(prediction 19 -> extended 20)."""
+    from oracle import scores as S
+    o = json.load(open(os.path.join(GOLD, "orchestration.json")))
+    for run in o["runs"]:
+        fit = [S.fitness_from_vectors(run["structure"], np.asarray(v).reshape(-1, 4), run["w"], run["h"]) for v in run["lk_vectors"]]
+        assert fit == run["fitness"]
+        kw = run["prednet_kwargs"]
+        assert (kw["extension_start"], kw["extension_duration"], kw["reset_at"], kw["skip_save_frames"]) == (20, 2, 22, 1)
+        assert run["sequence_len"] == 20 * len(run["fitness"])
+        assert run["lk_files"][0] == ["0000000019.png", "0000000020_extended.png"]
+        assert run["lk_files"][1] == ["0000000039.png", "0000000040_extended.png"]
