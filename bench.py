@@ -133,7 +133,7 @@ def main():
         eng.conv_profile(True, reset=True)
         step_local = fitness.evaluate_population(STRUCTURE, genomes[:args.pop], wts, cfg, W, H, CHANNELS, c_dim=C_DIM, gradient=1, max_batch=args.pop)
         rows = eng.conv_profile(False, reset=True)
-        lstm = [r for r in rows if r["epi"] == "lstm" and r["TW"] == 16]
+        lstm = [r for r in rows if r["epi"] == "lstm" and r["NI"] == 4]
         fl = sum(r["flops_per_image"] * args.pop * r["launches"] for r in lstm)
         ms = sum(r["ms"] for r in lstm)
         n_l = sum(r["launches"] for r in lstm)

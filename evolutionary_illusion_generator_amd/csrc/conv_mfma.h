@@ -12,11 +12,13 @@
 // Channel counts are padded to multiples of 4 with zero weights AFTER the real channels of each source, which
 // appends exact no-op terms (fma(a, 0, acc) == acc) and leaves the chain of real terms untouched.
 //
-// Per K-block (16 channels of one source) the block stages
-//   - the input tile with its 1-pixel halo, [16][NIMG][TH+2][TW+2] fp32, through registers (zero fill at the image
-//     border, 2x nearest unpooling folded into the gather for the R_{l+1} source), and
-//   - the weight slab [144][NI*16] fp32 straight into LDS with global_load_lds (16 B per lane),
-// then runs 36 MFMA steps whose A operand is gathered from the halo tile at (pixel + tap) -- im2col never exists
+// Per K-block (KC = 8 channels of one source) the block stages
+//   - the input tile with its 1-pixel halo, [KC][NIMG][TH+2][TW+2] fp32, straight into LDS with global_load_lds 4 B
+//     per lane (each lane supplies the address of its halo pixel, or of a zero word outside the image; the 2x
+//     nearest unpooling of the R_{l+1} source is folded into that address), and
+//   - the weight slab [KC*9][NI*16] fp32 straight into LDS with global_load_lds 16 B per lane,
+// into the buffer NOT being computed on (two LDS buffers, loads in flight during the MFMAs of the previous K-block),
+// then runs KC*9/4 MFMA steps whose A operand is gathered from the halo tile at (pixel + tap) -- im2col never exists
 // in memory.  k advances by 4 per step, (channel, tap) = divmod(k, 9), so the per-lane LDS offset pattern has period
 // 9 steps (= 4 channels): nine precomputed address registers + immediates, no address VALU in the loop.
 //
@@ -26,6 +28,12 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
+
+#ifndef EIG_ABLATE
+#define EIG_ABLATE 0  // measurement-only builds (scripts/ablate_conv.py): 1 = no staging after the first K-block
+#endif
 
 namespace eig {
 
@@ -69,6 +77,8 @@ struct ConvArgs {
     int _pad2;
     // EPI_RAW
     float* raw;         // [B][Cout][H][W]
+    const float* zeros; // >= 64 zero bytes in device memory: DMA source for out-of-image / padded-channel positions
+    unsigned long long* dbg;  // EIG_TIMING builds only: per-block cycle counters
 };
 
 // ---- deterministic fp32 transcendental kernels: same operations, same order as oracle/eig_oracle.c ----
@@ -111,28 +121,45 @@ __device__ __forceinline__ float det_tanhf(float x)
 }
 __device__ __forceinline__ float relu_f(float v) { return v > 0.0f ? v : 0.0f; }
 
-template <int TW> struct TileGeom {
+// LDS geometry of the haloed input tile.
+//  VEC (every layer whose width is a multiple of 4 -- all real PredNet shapes): a row holds the ALIGNED 16-byte chunks
+//  x0-4 .. x0+TW+3 of the source row, so the whole tile is moved by 16 B/lane DMA; output column px, tap kx sits at
+//  LDS column px + kx + 3.  An unpooled (half-resolution) source is staged at ITS resolution (rows y0/2-1 ..,
+//  chunks x0/2-4 ..) and the x2 nearest unpooling happens in the gather address ((py+ky-1)>>1, (px+kx-1)>>1).
+//  !VEC (odd widths): rows of TW+2 floats at output resolution, 4 B/lane DMA, unpooling folded into the DMA source.
+template <int TW, bool VEC> struct TileGeom {
     static constexpr int TH = (TW == 16) ? 16 : 8;
     static constexpr int NIMG = 256 / (TH * TW);
-    static constexpr int S = TW + 2;
+    static constexpr int S = VEC ? TW + 8 : TW + 2;
+    static constexpr int XO = VEC ? 3 : 0;
     static constexpr int PH = TH + 2;
     static constexpr int PLANE = NIMG * PH * S;  // floats per channel in LDS
+    static constexpr int SU = TW / 2 + 8;        // unpooled source, VEC only
+    static constexpr int PHU = TH / 2 + 2;
+    static constexpr int PLANE_U = NIMG * PHU * SU;
 };
 
-constexpr int KC = 16;  // channels per K-block
+constexpr int KC = 8;  // channels per K-block
 
-template <int NI, int TW> constexpr int conv_lds_bytes() { return (KC * TileGeom<TW>::PLANE + KC * 9 * NI * 16) * 4; }
+template <int NI, int TW, bool VEC> constexpr int conv_lds_bytes() { return 2 * (KC * TileGeom<TW, VEC>::PLANE + KC * 9 * NI * 16) * 4; }
 
-template <int NI, int TW, int EPI>
-__global__ void __launch_bounds__(256, 2) conv3x3_mfma(const ConvArgs a)
+#ifndef EIG_TIMING
+#define EIG_TIMING 0  // measurement-only builds: per-wave s_memtime breakdown of the K loop into a.dbg
+#endif
+#ifndef EIG_CONV_OCC
+#define EIG_CONV_OCC 2  // blocks per CU the register allocation is capped for (__launch_bounds__ 2nd argument)
+#endif
+constexpr int CONV_THREADS = 256;  // 4 waves per block
+
+template <int NI, int TW, int EPI, bool VEC>
+__global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const ConvArgs a)
 {
-    using G = TileGeom<TW>;
-    constexpr int TH = G::TH, NIMG = G::NIMG, S = G::S, PH = G::PH, PLANE = G::PLANE;
+    using G = TileGeom<TW, VEC>;
+    constexpr int TH = G::TH, NIMG = G::NIMG, S = G::S, XO = G::XO, PH = G::PH, PLANE = G::PLANE;
+    constexpr int SU = G::SU, PHU = G::PHU, PLANE_U = G::PLANE_U;
     constexpr int NB = NI * 16;
-    constexpr int NPOS_R = (PLANE + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* const in_lds = lds;
-    float* const w_lds = lds + KC * PLANE;
+    constexpr int BUF = KC * PLANE + KC * 9 * NB;  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -149,35 +176,66 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma(const ConvArgs a)
     const int bgrp = bid / tiles;
     const int t = bid - bgrp * tiles;
     const int tyi = t / a.tilesX, txi = t - tyi * a.tilesX;
+    const int y0 = tyi * TH, x0 = txi * TW;
 
-    // ---- staging positions of this thread inside the haloed tile
-    int pos_img[NPOS_R], pos_gy[NPOS_R], pos_gx[NPOS_R];
-    bool pos_ok[NPOS_R];
+    // ---- staging slots of this thread (K-block invariant): LDS slot tid + 256 r -> pixel offset in the source plane
+    // (-1: zero fill) and image.  VEC: slots are the 16-B chunks of the whole K-block tile (the channel inside the
+    // K-block is (tid + 256 r) / slots-per-channel); !VEC: slots are the floats of ONE channel plane.
+    constexpr int RC = S / 4, RCU = SU / 4;
+    constexpr int PER_C = VEC ? NIMG * PH * RC : PLANE, PER_CU = NIMG * PHU * RCU;
+    constexpr int NR = VEC ? (KC * PER_C + 255) / 256 : (PLANE + 255) / 256;
+    constexpr int NRU = VEC ? (KC * PER_CU + 255) / 256 : 1;
+    int sl_off[NR], sl_img[NR], su_off[NRU], su_img[NRU];
 #pragma unroll
-    for (int r = 0; r < NPOS_R; ++r) {
-        const int pos = tid + r * 256;
-        const int img = pos / (PH * S);
-        const int rem = pos - img * (PH * S);
-        const int yy = rem / S, xx = rem - yy * S;
-        pos_img[r] = bgrp * NIMG + img;
-        pos_gy[r] = tyi * TH + yy - 1;
-        pos_gx[r] = txi * TW + xx - 1;
-        pos_ok[r] = (pos < PLANE) && (pos_img[r] < a.B) && pos_gy[r] >= 0 && pos_gy[r] < a.H && pos_gx[r] >= 0 && pos_gx[r] < a.W;
+    for (int r = 0; r < NR; ++r) {
+        const int p = tid + r * 256;
+        int rem = VEC ? p % PER_C : p;
+        constexpr int RW = VEC ? RC : S;
+        const int img = rem / (PH * RW);
+        rem -= img * (PH * RW);
+        const int yy = rem / RW, xx = rem - yy * RW;
+        const int gy = y0 + yy - 1, gx = VEC ? (x0 - 4 + 4 * xx) : (x0 + xx - 1);
+        const int b = bgrp * NIMG + img;
+        const bool ok = (VEC || p < PLANE) && b < a.B && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        // VEC: byte offset of the chunk inside ONE image of the source, channel part included; -1 = out of range,
+        // which the buffer bounds check turns into zeros.  !VEC: pixel offset.
+        sl_off[r] = ok ? (VEC ? ((p / PER_C) * a.H * a.W + gy * a.W + gx) * 4 : gy * a.W + gx) : -1;
+        sl_img[r] = VEC ? img : b;
+    }
+    if (VEC) {
+        const int Hs = a.H >> 1, Ws = a.W >> 1;
+#pragma unroll
+        for (int r = 0; r < NRU; ++r) {
+            const int p = tid + r * 256;
+            int rem = p % PER_CU;
+            const int img = rem / (PHU * RCU);
+            rem -= img * (PHU * RCU);
+            const int yy = rem / RCU, xx = rem - yy * RCU;
+            const int gy = (y0 >> 1) + yy - 1, gx = (x0 >> 1) - 4 + 4 * xx;
+            const int b = bgrp * NIMG + img;
+            const bool ok = b < a.B && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+            su_off[r] = ok ? ((p / PER_CU) * Hs * Ws + gy * Ws + gx) * 4 : -1;
+            su_img[r] = img;
+        }
     }
 
-    // ---- A-operand gather addresses: lane row r = lane&15 = 4*rq + rreg -> pixel (dy, dx); k-slot j = lane>>4
-    int addrA[9];
+    // ---- A-operand gather addresses: lane row r = lane&15 = 4*rq + rreg -> pixel (dy, dx); k-slot j = lane>>4.
+    // k = 4*step + j, (channel, tap) = divmod(k, 9): period 9 steps = 4 channels -> nine address registers per layout.
+    int addrA[9], addrU[9];
     {
         const int r = col;
         const int dy = (r & 3) >> 1, dx = 2 * (r >> 2) + (r & 1);
-        int base;
-        if (TW == 16) base = (wv * 4 + dy) * S + dx;  // sub-tile mi adds (mi>>1)*2*S + (mi&1)*8
-        else base = wv * PH * S + dy * S + dx;        // one image per wave; sub-tile mi adds mi*2*S
+        const int base = (TW == 16) ? (wv * 4 + dy) * S + dx + XO      // sub-tile mi adds (mi>>1)*2*S + (mi&1)*8
+                                    : wv * PH * S + dy * S + dx + XO;  // one image per wave; sub-tile mi adds mi*2*S
+        const int baseU = (TW == 16) ? (wv * 2 + 1) * SU + 4           // sub-tile mi adds (mi>>1)*SU + (mi&1)*4
+                                     : (wv * PHU + 1) * SU + 4;        // sub-tile mi adds mi*SU
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             const int k = 4 * s + q;
             const int c = k / 9, tap = k - 9 * c;
-            addrA[s] = base + c * PLANE + (tap / 3) * S + (tap % 3);
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            addrA[s] = base + c * PLANE + ky * S + kx;
+            addrU[s] = baseU + c * PLANE_U + ((dy + ky - 1) >> 1) * SU + ((dx + kx - 1) >> 1);
         }
     }
     const int boff = q * NB + col;
@@ -188,72 +246,157 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma(const ConvArgs a)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const float* wslab = a.wpk + (size_t)nblk * a.krows * NB;
-
-    for (int s = 0; s < a.nsrc; ++s) {
-        const ConvSrc src = a.src[s];
+    // ---- K loop: K-blocks of KC channels, enumerated across the sources, two LDS buffers.
+    // Both operands go global -> LDS by DMA (global_load_lds: no staging registers, no ds_write pass; every lane
+    // supplies the global address of its LDS slot, or of a zero buffer outside the image / for padded channels).
+    // The DMA instructions of K-block kb+1 are INTERLEAVED with the 18 MFMA steps of K-block kb (one every other
+    // step): a DMA issued while the wave would anyway be waiting for the matrix pipe costs nothing, whereas a burst
+    // of them ahead of the MFMAs measured ~0.7 % of the K-block time per instruction.  ONE barrier per K-block.
+    constexpr int NWR = (KC * 9 * (NB / 4) + 255) / 256;          // weight DMA rounds per K-block
+    constexpr int NIN = VEC ? (NR > NRU ? NR : NRU) : KC * NR;    // input DMA ops per K-block
+    constexpr int NOPS = NWR + NIN;
+    constexpr int NSTEP = KC * 9 / 4;                             // 18
+    struct KB { int s, c0, kc, up; };
+    auto kb_first = [&]() { KB k; k.s = 0; k.c0 = 0; k.kc = min(KC, a.src[0].Cpad); k.up = VEC ? a.src[0].up : 0; return k; };
+    auto kb_next = [&](KB k) {
+        k.c0 += KC;
+        if (k.c0 >= a.src[k.s].Cpad) { k.c0 = 0; ++k.s; }
+        if (k.s < a.nsrc) { k.kc = min(KC, a.src[k.s].Cpad - k.c0); k.up = VEC ? a.src[k.s].up : 0; }
+        else { k.kc = 0; k.up = 0; }
+        return k;
+    };
+    // Buffer descriptors (VEC path): one per source covering the NIMG images of this block, one for this N-block's
+    // weight slab.  A DMA then needs no per-lane address arithmetic at all: voffset is a K-block-invariant register,
+    // the channel / K-block part is a scalar offset, and out-of-image or padded-channel slots are simply out of
+    // range of the descriptor, which the hardware turns into zeros.
+    const int b0 = bgrp * NIMG;
+    const int nimg_here = min(NIMG, a.B - b0);
+    auto make_rsrc = [&](int si) {
+        const ConvSrc src = a.src[si < a.nsrc ? si : 0];
+        const size_t per_img = (size_t)src.C * ((a.H >> src.up) * (a.W >> src.up));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(src.ptr + (size_t)b0 * per_img), 0, (int)(per_img * nimg_here * 4), 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(0), rs1 = make_rsrc(1), rs2 = make_rsrc(2);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * a.krows * NB), 0, a.krows * NB * 4, 0x00020000);
+    auto buf_dma16 = [&](int si, float* lds_dst, int voff, int soff) {
+        auto l = (__attribute__((address_space(3))) void*)lds_dst;
+        if (si == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, l, 16, voff, soff, 0, 0);
+        else if (si == 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, l, 16, voff, soff, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs2, l, 16, voff, soff, 0, 0);
+    };
+    // one DMA instruction (op j of K-block k) into buffer `buf`; wrow = first weight row of that K-block
+    auto dma_op = [&](int j, const KB& k, int wrow, float* buf) {
+        const ConvSrc src = a.src[k.s];
+        if (j < NWR) {
+            const int n16 = k.kc * 9 * (NB / 4);
+            const int base = j * 256 + wv * 64, ch = base + lane;
+            if (ch < n16)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(buf + KC * PLANE + (size_t)base * 4), 16,
+                                                         tid * 16, (wrow * NB + j * 1024) * 4, 0, 0);
+            return;
+        }
         const int Hs = a.H >> src.up, Ws = a.W >> src.up;
         const int chs = Hs * Ws;
-        const float* sp[NPOS_R];
-#pragma unroll
-        for (int r = 0; r < NPOS_R; ++r)
-            sp[r] = src.ptr + (size_t)pos_img[r] * src.C * chs + (pos_ok[r] ? ((pos_gy[r] >> src.up) * Ws + (pos_gx[r] >> src.up)) : 0);
-
-        for (int c0 = 0; c0 < src.Cpad; c0 += KC) {
-            const int kc = min(KC, src.Cpad - c0);
-            __syncthreads();  // everyone is done reading the previous K-block
-            // weight slab -> LDS, direct (lane-linear image)
-            {
-                const int n16 = kc * 9 * (NB / 4);
-                for (int base = wv * 64; base < n16; base += 256) {
-                    const int ch = base + lane;
-                    if (ch < n16)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wslab + (size_t)ch * 4),
-                                                         (__attribute__((address_space(3))) void*)(w_lds + (size_t)base * 4), 16, 0, 0);
+        if (VEC) {
+            const int r = j - NWR;
+            const int p = tid + r * 256;
+            const int soff = k.c0 * chs * 4;
+            const bool tail = k.c0 + KC > src.C;  // padded channels present: mask them explicitly (rare, tiny layers)
+            if (!k.up) {
+                if (r < NR) {
+                    int vo = sl_off[r < NR ? r : 0];
+                    if (NIMG > 1) vo = vo < 0 ? vo : vo + sl_img[r < NR ? r : 0] * src.C * chs * 4;
+                    if (tail && k.c0 + p / PER_C >= src.C) vo = -1;
+                    if (p < k.kc * PER_C) buf_dma16(k.s, buf + (r * 256 + wv * 64) * 4, vo, soff);
+                }
+            } else {
+                if (r < NRU) {
+                    int vo = su_off[r < NRU ? r : 0];
+                    if (NIMG > 1) vo = vo < 0 ? vo : vo + su_img[r < NRU ? r : 0] * src.C * chs * 4;
+                    if (tail && k.c0 + p / PER_CU >= src.C) vo = -1;
+                    if (p < k.kc * PER_CU) buf_dma16(k.s, buf + (r * 256 + wv * 64) * 4, vo, soff);
                 }
             }
-            // input tile with halo -> registers -> LDS
-            {
-                float v[KC][NPOS_R];
-#pragma unroll
-                for (int c = 0; c < KC; ++c)
-#pragma unroll
-                    for (int r = 0; r < NPOS_R; ++r) {
-                        const bool ok = pos_ok[r] && (c < kc) && (c0 + c < src.C);
-                        v[c][r] = ok ? sp[r][(size_t)(c0 + c) * chs] : 0.0f;
-                    }
-#pragma unroll
-                for (int c = 0; c < KC; ++c)
-#pragma unroll
-                    for (int r = 0; r < NPOS_R; ++r)
-                        if (c < kc && (r == 0 || tid + r * 256 < PLANE)) in_lds[c * PLANE + tid + r * 256] = v[c][r];
-            }
-            wslab += (size_t)kc * 9 * NB;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-
-            const int nper = kc >> 2;
-            for (int per = 0; per < nper; ++per) {
-                const float* ap = in_lds + per * 4 * PLANE;
-                const float* bp = w_lds + per * 36 * NB + boff;
-#pragma unroll
-                for (int st = 0; st < 9; ++st) {
-                    float av[4], bv[NI];
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
-                        const int moff = (TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S);
-                        av[mi] = ap[addrA[st] + moff];
-                    }
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) bv[ni] = bp[st * 4 * NB + ni * 16];
-#pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                        for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
-                }
+        } else {
+            const int c = (j - NWR) / NR, r = (j - NWR) % NR;
+            if (c < k.kc) {
+                const bool pok = sl_off[r] >= 0;
+                const int gy = pok ? sl_off[r] / a.W : 0, gx = pok ? sl_off[r] - gy * a.W : 0;
+                const float* g = (pok && (k.c0 + c < src.C))
+                                     ? src.ptr + ((size_t)sl_img[r] * src.C + k.c0 + c) * chs + (gy >> src.up) * Ws + (gx >> src.up) : a.zeros;
+                if (tid + r * 256 < PLANE)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                     (__attribute__((address_space(3))) void*)(buf + c * PLANE + r * 256 + wv * 64), 4, 0, 0);
             }
         }
+    };
+
+    int nkb = 0;
+    for (int s = 0; s < a.nsrc; ++s) nkb += (a.src[s].Cpad + KC - 1) / KC;
+    KB cur_kb = kb_first();
+    int wrow = 0;  // first packed weight row of the current K-block
+#pragma unroll
+    for (int j = 0; j < NOPS; ++j) dma_op(j, cur_kb, wrow, lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    unsigned long long t_mfma = 0, t_wait = 0, t_bar = 0, t_all0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const unsigned long long tk0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
+        float* const cur = lds + (kb & 1) * BUF;
+        float* const nxt = lds + ((kb & 1) ^ 1) * BUF;
+        const KB nxt_kb = kb_next(cur_kb);
+        const int wrow_nxt = wrow + cur_kb.kc * 9;
+        const bool more_kb = (kb + 1 < nkb) && EIG_ABLATE != 1;
+
+        // The two tile layouts (full resolution / unpooled source) differ only in the nine gather addresses, the four
+        // sub-tile offsets and the channel stride, all wave-uniform per K-block: ONE loop body.
+        const bool up = cur_kb.up;
+        int ad[9], mo[4];
+#pragma unroll
+        for (int st = 0; st < 9; ++st) ad[st] = up ? addrU[st] : addrA[st];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const int m_full = (TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S);
+            const int m_up = (TW == 16) ? ((mi >> 1) * SU + (mi & 1) * 4) : (mi * SU);
+            mo[mi] = up ? m_up : m_full;
+        }
+        const int pl4 = 4 * (up ? PLANE_U : PLANE);
+        const float* const in_lds = cur;
+        const float* const w_lds = cur + KC * PLANE + boff;
+#pragma unroll
+        for (int st = 0; st < NSTEP; ++st) {
+            if (st < 9 || cur_kb.kc > 4) {  // second period only for a full K-block (wave-uniform)
+                const int per = st / 9, s9 = st % 9;
+                float av[4], bv[NI];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) av[mi] = in_lds[per * pl4 + ad[s9] + mo[mi]];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) bv[ni] = w_lds[st * 4 * NB + ni * 16];
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+            }
+            if (more_kb) {
+#pragma unroll
+                for (int j = 0; j < NOPS; ++j)
+                    if (j * NSTEP / NOPS == st) dma_op(j, nxt_kb, wrow_nxt, nxt);
+            }
+        }
+        wrow = wrow_nxt;
+        cur_kb = nxt_kb;
+        const unsigned long long tk1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA for K-block kb+1 has landed
+        const unsigned long long tk2 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
+        __syncthreads();
+        if (EIG_TIMING) { const unsigned long long tk3 = __builtin_readcyclecounter(); t_mfma += tk1 - tk0; t_wait += tk2 - tk1; t_bar += tk3 - tk2; }
+    }
+    if (EIG_TIMING && a.dbg && lane == 0) {
+        const unsigned long long t_all = __builtin_readcyclecounter() - t_all0;
+        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wv) * 4;
+        d[0] = t_mfma; d[1] = t_wait; d[2] = t_bar; d[3] = t_all;
     }
 
     // ---------------------------------------------------------------- epilogue
@@ -300,6 +443,36 @@ __global__ void __launch_bounds__(256, 2) conv3x3_mfma(const ConvArgs a)
                 float zf = acc[mi][1][reg] + bf; zf = fmaf(a.peep[pstride + pbase + pix], cold, zf);
                 const float zc = acc[mi][2][reg] + bc;
                 float zo = acc[mi][3][reg] + bo; zo = fmaf(a.peep[2 * pstride + pbase + pix], cold, zo);
+                const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
+                const float gi = gg * ii;
+                const float cnew = fmaf(ff, cold, gi);
+                a.c_state[cbase + pix] = cnew;
+                a.h_out[cbase + pix] = oo * det_tanhf(cnew);
+            }
+        } else if (EPI == EPI_LSTM_PACKED) {
+            // C <= 4 (layer 0): ONE 16-column tile holds the 4 gates x 4 channel slots, column = gate*4 + channel.
+            // Lanes of gate 0 fetch the other three gates of their channel from lanes col+4, +8, +12.
+            const int ch = col & 3;
+            const bool active = (col < 4) && (ch < a.Cout);
+            const int cc = active ? ch : 0;
+            const float bi = a.bias[cc], bf = a.bias[a.Cout + cc], bc = a.bias[2 * a.Cout + cc], bo = a.bias[3 * a.Cout + cc];
+            const size_t cbase = ((size_t)b * a.Cout + cc) * HW;
+            const size_t pbase = (size_t)cc * HW;
+            const size_t pstride = (size_t)a.Cout * HW;
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float ai = acc[mi][0][reg];
+                const float af = __shfl(ai, lane + 4, 64);
+                const float ac = __shfl(ai, lane + 8, 64);
+                const float ao = __shfl(ai, lane + 12, 64);
+                const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);
+                if (!active || gy >= a.H || gx >= a.W) continue;
+                const int pix = gy * a.W + gx;
+                const float cold = a.c_state[cbase + pix];
+                float zi = ai + bi; zi = fmaf(a.peep[pbase + pix], cold, zi);
+                float zf = af + bf; zf = fmaf(a.peep[pstride + pbase + pix], cold, zf);
+                const float zc = ac + bc;
+                float zo = ao + bo; zo = fmaf(a.peep[2 * pstride + pbase + pix], cold, zo);
                 const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
                 const float gi = gg * ii;
                 const float cnew = fmaf(ff, cold, gi);

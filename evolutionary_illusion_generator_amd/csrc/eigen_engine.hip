@@ -99,6 +99,7 @@ struct eigen_engine {
     uint8_t* d_status = nullptr;
     int *d_ncorners = nullptr, *d_counts = nullptr;
     double* d_fitness = nullptr;
+    float* d_zeros = nullptr;  // DMA source for zero fill (conv_mfma.h)
     // timing
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pev0 = nullptr, pev1 = nullptr;
@@ -134,7 +135,9 @@ static int choose_tw(int H, int W)
 
 // Pack OIHW weights of one fused conv into [n_nblk][krows][NB]; row = (source, channel (padded to 4), tap).
 // srcw[s][g] points at [Cout][Cin_s][3][3]; g = 0 for plain convs, 0..3 (i,f,c,o) for the LSTM.
-static std::vector<float> pack_weights(const ConvOp& op, const float* const srcw[3][4], bool lstm)
+// lstm: 0 plain conv, 1 gates as four 16-channel tiles (column = gate*16 + channel), 2 packed for C <= 4
+// (ONE 16-column tile, column = gate*4 + channel).
+static std::vector<float> pack_weights(const ConvOp& op, const float* const srcw[3][4], int lstm)
 {
     const int NB = op.NI * 16;
     std::vector<float> out((size_t)op.n_nblk * op.krows * NB, 0.0f);
@@ -148,7 +151,8 @@ static std::vector<float> pack_weights(const ConvOp& op, const float* const srcw
                     float* dst = &out[((size_t)nb * op.krows + row) * NB];
                     for (int n = 0; n < NB; ++n) {
                         int g = 0, o;
-                        if (lstm) { g = n / 16; o = nb * 16 + (n % 16); }
+                        if (lstm == 1) { g = n / 16; o = nb * 16 + (n % 16); }
+                        else if (lstm == 2) { g = n / 4; o = n % 4; }
                         else o = nb * NB + n;
                         if (o >= op.Cout) continue;
                         dst[n] = srcw[s][g][((size_t)o * Cin + c) * 9 + tap];
@@ -159,33 +163,38 @@ static std::vector<float> pack_weights(const ConvOp& op, const float* const srcw
     return out;
 }
 
-template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st)
+template <int NI, int TW, int EPI, bool VEC> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
-    constexpr int lds = conv_lds_bytes<NI, TW>();
+    constexpr int lds = conv_lds_bytes<NI, TW, VEC>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI>), dim3(grid), dim3(256), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
     return hipGetLastError();
 }
 
-template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& a, int grid, hipStream_t st)
+template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec)
+{
+    return vec ? launch_inst2<NI, TW, EPI, true>(a, grid, st) : launch_inst2<NI, TW, EPI, false>(a, grid, st);
+}
+
+template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& a, int grid, hipStream_t st, bool vec)
 {
     if (TW == 16) {
         switch (NI) {
-            case 1: return launch_inst<1, 16, EPI>(a, grid, st);
-            case 2: return launch_inst<2, 16, EPI>(a, grid, st);
-            case 3: return launch_inst<3, 16, EPI>(a, grid, st);
-            default: return launch_inst<4, 16, EPI>(a, grid, st);
+            case 1: return launch_inst<1, 16, EPI>(a, grid, st, vec);
+            case 2: return launch_inst<2, 16, EPI>(a, grid, st, vec);
+            case 3: return launch_inst<3, 16, EPI>(a, grid, st, vec);
+            default: return launch_inst<4, 16, EPI>(a, grid, st, vec);
         }
     }
     switch (NI) {
-        case 1: return launch_inst<1, 8, EPI>(a, grid, st);
-        case 2: return launch_inst<2, 8, EPI>(a, grid, st);
-        case 3: return launch_inst<3, 8, EPI>(a, grid, st);
-        default: return launch_inst<4, 8, EPI>(a, grid, st);
+        case 1: return launch_inst<1, 8, EPI>(a, grid, st, vec);
+        case 2: return launch_inst<2, 8, EPI>(a, grid, st, vec);
+        case 3: return launch_inst<3, 8, EPI>(a, grid, st, vec);
+        default: return launch_inst<4, 8, EPI>(a, grid, st, vec);
     }
 }
 
@@ -196,17 +205,21 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     a.H = op.H; a.W = op.W; a.B = batch;
     a.tilesX = (op.W + op.TW - 1) / op.TW;
     a.tilesY = (op.H + TH - 1) / TH;
-    a.n_nblk = op.n_nblk; a.krows = op.krows; a.wpk = op.d_wpk; a.Cout = op.Cout;
+    a.n_nblk = op.n_nblk; a.krows = op.krows; a.wpk = op.d_wpk; a.Cout = op.Cout; a.zeros = e->d_zeros;
     a.nsrc = op.nsrc;
     for (int s = 0; s < op.nsrc; ++s) { a.src[s].C = op.src_C[s]; a.src[s].Cpad = pad4(op.src_C[s]); a.src[s].up = op.src_up[s]; }
     const int grid = op.n_nblk * ((batch + NIMG - 1) / NIMG) * a.tilesX * a.tilesY;
+    // 16-byte DMA staging needs chunk-aligned rows: W % 4 == 0, and W % 8 == 0 when a half-resolution source is read
+    bool vec = (op.W % 4) == 0;
+    for (int s = 0; s < op.nsrc; ++s) if (op.src_up[s] && ((op.W % 8) != 0 || (op.H % 2) != 0)) vec = false;
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
     switch (op.epi) {
-        case EPI_LSTM: r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st) : launch_inst<4, 8, EPI_LSTM>(a, grid, st); break;
-        case EPI_CONVA: r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st); break;
-        case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st); break;
-        default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st); break;
+        case EPI_LSTM: r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec); break;
+        case EPI_LSTM_PACKED: r = (op.TW == 16) ? launch_inst<1, 16, EPI_LSTM_PACKED>(a, grid, st, vec) : launch_inst<1, 8, EPI_LSTM_PACKED>(a, grid, st, vec); break;
+        case EPI_CONVA: r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st, vec); break;
+        case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st, vec); break;
+        default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec); break;
     }
     if (e->profile_convs && r == hipSuccess) {
         (void)hipEventRecord(e->pev1, st);
@@ -245,7 +258,7 @@ int eigen_destroy(eigen_engine* e)
     e->g_node_off.release(); e->g_edge_off.release(); e->g_edge_src.release(); e->g_out_node.release();
     e->g_node_act.release(); e->g_node_bias.release(); e->g_node_resp.release(); e->g_edge_w.release();
     void* misc[] = {e->d_images, e->d_frames, e->d_eig, e->d_cand, e->d_corners, e->d_next, e->d_vectors, e->d_status,
-                    e->d_ncorners, e->d_counts, e->d_fitness};
+                    e->d_ncorners, e->d_counts, e->d_fitness, e->d_zeros};
     for (void* p : misc) if (p) (void)hipFree(p);
     for (int i = 0; i < 2; ++i)
         for (int l = 0; l < FLOW_MAX_LEVELS; ++l) if (e->d_gray[i][l]) (void)hipFree(e->d_gray[i][l]);
@@ -319,6 +332,8 @@ int eigen_create(const eigen_config* cfg, eigen_engine** out)
     ALLOC(e->d_ncorners, B * sizeof(int));
     ALLOC(e->d_counts, B * sizeof(int));
     ALLOC(e->d_fitness, B * sizeof(double));
+    ALLOC(e->d_zeros, 256);
+    (void)hipMemset(e->d_zeros, 0, 256);
 #undef ALLOC
     for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipEventCreate(&e->pev0));
@@ -370,7 +385,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             op.krows = pad4(op.src_C[0]) * 9;
             op.macs = (double)op.H * op.W * C * op.src_C[0] * 9;
             const float* sw[3][4] = {{convA_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
-            std::vector<float> pk = pack_weights(op, sw, false);
+            std::vector<float> pk = pack_weights(op, sw, 0);
             if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.biasA, convA_b, C)) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d)", l);
         }
         // ---- ConvLSTM_l: sources E_l, unpooled R_{l+1}, h_l ; 4 gates fused on N
@@ -383,6 +398,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             if (l < L - 1) { op.src_C[op.nsrc] = e->layer[l + 1].C; op.src_up[op.nsrc] = 1; op.nsrc++; }
             op.src_C[op.nsrc] = C; op.src_up[op.nsrc] = 0; op.nsrc++;
             choose_ni(C, true, &op.NI, &op.n_nblk);
+            if (C <= 4) { op.epi = EPI_LSTM_PACKED; op.NI = 1; op.n_nblk = 1; }  // 4 gates x <=4 channels in one MFMA tile
             op.TW = choose_tw(op.H, op.W);
             op.krows = 0; op.macs = 0;
             for (int s = 0; s < op.nsrc; ++s) { op.krows += pad4(op.src_C[s]) * 9; op.macs += (double)y.H * y.W * 4 * C * op.src_C[s] * 9; }
@@ -392,7 +408,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             s++;
             if (l < L - 1) { for (int g = 0; g < 4; ++g) sw[s][g] = wx1[g]; s++; }
             for (int g = 0; g < 4; ++g) sw[s][g] = wh[g];
-            std::vector<float> pk = pack_weights(op, sw, true);
+            std::vector<float> pk = pack_weights(op, sw, op.epi == EPI_LSTM_PACKED ? 2 : 1);
             std::vector<float> bias(4 * (size_t)C);
             for (int g = 0; g < 4; ++g) memcpy(&bias[(size_t)g * C], bh[g], sizeof(float) * C);
             const size_t chw = (size_t)C * y.H * y.W;
@@ -412,7 +428,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             op.krows = pad4(C) * 9;
             op.macs = (double)y.H * y.W * C * C * 9;
             const float* sw[3][4] = {{convP_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
-            std::vector<float> pk = pack_weights(op, sw, false);
+            std::vector<float> pk = pack_weights(op, sw, 0);
             if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.biasP, convP_b, C)) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvP%d)", l);
         }
     }
@@ -721,8 +737,8 @@ int eigen_conv_profile(eigen_engine* e, int32_t enable, int32_t reset, double* h
     return EIGEN_OK;
 }
 
-int eigen_test_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, const int32_t* cin, const int32_t* up, const float* const* h_w,
-                    int32_t cout, int32_t H, int32_t W, int32_t batch, float* d_out, void* stream)
+static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_src, const int32_t* cin, const int32_t* up, const float* const* h_w,
+                          int32_t cout, int32_t H, int32_t W, int32_t batch, float* d_out, void* stream, int iters, double* h_ms)
 {
     if (!e || !d_src || !cin || !up || !h_w || !d_out) return fail(EIGEN_ERR_INVALID, "null argument");
     if (n_src < 1 || n_src > 3) return fail(EIGEN_ERR_INVALID, "n_src must be 1..3");
@@ -734,7 +750,7 @@ int eigen_test_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, c
     op.krows = 0;
     const float* sw[3][4] = {{nullptr}, {nullptr}, {nullptr}};
     for (int s = 0; s < n_src; ++s) { op.src_C[s] = cin[s]; op.src_up[s] = up[s]; op.krows += pad4(cin[s]) * 9; sw[s][0] = h_w[s]; }
-    std::vector<float> pk = pack_weights(op, sw, false);
+    std::vector<float> pk = pack_weights(op, sw, 0);
     HIPCHK(hipMalloc((void**)&op.d_wpk, pk.size() * sizeof(float)));
     HIPCHK(hipMemcpy(op.d_wpk, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
     ConvArgs a;
@@ -743,13 +759,56 @@ int eigen_test_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, c
     a.raw = d_out;
     const bool prof = e->profile_convs;
     e->profile_convs = false;
-    hipError_t r = launch_conv(e, op, a, batch, (hipStream_t)stream);
+    hipError_t r = launch_conv(e, op, a, batch, (hipStream_t)stream);  // also the warm-up of a timed run
+#if EIG_TIMING
+    {
+        const int TH_ = (op.TW == 16) ? 16 : 8, NIMG_ = 256 / (TH_ * op.TW);
+        const int grid_ = op.n_nblk * ((batch + NIMG_ - 1) / NIMG_) * ((W + op.TW - 1) / op.TW) * ((H + TH_ - 1) / TH_);
+        unsigned long long* dbg = nullptr;
+        (void)hipMalloc((void**)&dbg, (size_t)grid_ * 16 * 8);
+        (void)hipMemset(dbg, 0, (size_t)grid_ * 16 * 8);
+        a.dbg = dbg;
+        (void)launch_conv(e, op, a, batch, (hipStream_t)stream);
+        (void)hipStreamSynchronize((hipStream_t)stream);
+        std::vector<unsigned long long> h((size_t)grid_ * 16);
+        (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        double s4[4] = {0, 0, 0, 0};
+        for (size_t i = 0; i < h.size(); ++i) s4[i & 3] += (double)h[i];
+        const double n = (double)grid_ * 4;
+        fprintf(stderr, "[EIG_TIMING] blocks=%d per-wave cycles: mfma+dma-issue %.0f  vmcnt-wait %.0f  barrier %.0f  loop-total %.0f\n", grid_, s4[0] / n, s4[1] / n, s4[2] / n, s4[3] / n);
+        a.dbg = nullptr;
+        (void)hipFree(dbg);
+    }
+#endif
+    if (iters > 0 && r == hipSuccess) {
+        (void)hipEventRecord(e->pev0, (hipStream_t)stream);
+        for (int i = 0; i < iters && r == hipSuccess; ++i) r = launch_conv(e, op, a, batch, (hipStream_t)stream);
+        (void)hipEventRecord(e->pev1, (hipStream_t)stream);
+        (void)hipEventSynchronize(e->pev1);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, e->pev0, e->pev1);
+        if (h_ms) *h_ms = ms / iters;
+    }
     e->profile_convs = prof;
     hipError_t r2 = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(op.d_wpk);
     if (r != hipSuccess) return fail(EIGEN_ERR_HIP, "conv launch: %s", hipGetErrorString(r));
     if (r2 != hipSuccess) return fail(EIGEN_ERR_HIP, "conv sync: %s", hipGetErrorString(r2));
     return EIGEN_OK;
+}
+
+int eigen_test_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, const int32_t* cin, const int32_t* up, const float* const* h_w,
+                    int32_t cout, int32_t H, int32_t W, int32_t batch, float* d_out, void* stream)
+{
+    return test_conv_impl(e, n_src, d_src, cin, up, h_w, cout, H, W, batch, d_out, stream, 0, nullptr);
+}
+
+// Same launch repeated `iters` times between two HIP events on the launch stream: average kernel time in ms.
+int eigen_time_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, const int32_t* cin, const int32_t* up, const float* const* h_w,
+                    int32_t cout, int32_t H, int32_t W, int32_t batch, float* d_out, int32_t iters, double* h_ms, void* stream)
+{
+    if (iters < 1 || !h_ms) return fail(EIGEN_ERR_INVALID, "iters >= 1 and h_ms required");
+    return test_conv_impl(e, n_src, d_src, cin, up, h_w, cout, H, W, batch, d_out, stream, iters, h_ms);
 }
 
 int eigen_test_det_math(eigen_engine* e, const float* d_x, int32_t n, float* d_exp, float* d_sig, float* d_tanh, void* stream)

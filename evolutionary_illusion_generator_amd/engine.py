@@ -17,7 +17,7 @@ PAIR_POPULATION, PAIR_SINGLE = 0, 1
 
 EXPORTS = ["eigen_abi_version", "eigen_last_error", "eigen_config_defaults", "eigen_create", "eigen_destroy",
            "eigen_set_prednet_weights", "eigen_set_grid", "eigen_render_cppn", "eigen_prednet_rollout", "eigen_flow",
-           "eigen_score", "eigen_eval_population", "eigen_eval_images", "eigen_test_conv", "eigen_test_det_math",
+           "eigen_score", "eigen_eval_population", "eigen_eval_images", "eigen_test_conv", "eigen_time_conv", "eigen_test_det_math",
            "eigen_get_timings", "eigen_conv_profile", "eigen_debug_corners", "eigen_prednet_flops_per_step"]
 
 
@@ -188,6 +188,19 @@ class Engine:
         _check(self.lib.eigen_test_conv(self._h, ctypes.c_int32(n), st, ci, up, wt, ctypes.c_int32(cout), ctypes.c_int32(H),
                                         ctypes.c_int32(W), ctypes.c_int32(batch), _ptr(d_out), _stream_arg(stream)))
 
+    def time_conv(self, d_srcs, cins, ups, h_weights, cout, H, W, batch, d_out, iters=5, stream=None):
+        n = len(d_srcs)
+        st = (ctypes.c_void_p * n)(*[int(s.data_ptr()) for s in d_srcs])
+        ws = [np.ascontiguousarray(w, dtype=np.float32) for w in h_weights]
+        wt = (ctypes.c_void_p * n)(*[w.ctypes.data for w in ws])
+        ci = (ctypes.c_int32 * n)(*cins)
+        up = (ctypes.c_int32 * n)(*ups)
+        ms = ctypes.c_double(0)
+        _check(self.lib.eigen_time_conv(self._h, ctypes.c_int32(n), st, ci, up, wt, ctypes.c_int32(cout), ctypes.c_int32(H),
+                                        ctypes.c_int32(W), ctypes.c_int32(batch), _ptr(d_out), ctypes.c_int32(iters), ctypes.byref(ms),
+                                        _stream_arg(stream)))
+        return ms.value
+
     def test_det_math(self, d_x, n, d_exp, d_sig, d_tanh, stream=None):
         _check(self.lib.eigen_test_det_math(self._h, _ptr(d_x), ctypes.c_int32(n), _ptr(d_exp), _ptr(d_sig), _ptr(d_tanh), _stream_arg(stream)))
 
@@ -203,7 +216,7 @@ class Engine:
                                            ctypes.c_int32(out.shape[0]), ctypes.byref(n)))
         rows = []
         for r in out[:n.value]:
-            rows.append(dict(layer=int(r[0]), epi={1: "lstm", 2: "convA", 3: "convP"}.get(int(r[1]), "raw"), NI=int(r[2]), TW=int(r[3]),
+            rows.append(dict(layer=int(r[0]), epi={1: "lstm", 2: "convA", 3: "convP", 4: "lstm"}.get(int(r[1]), "raw"), NI=int(r[2]), TW=int(r[3]),
                              launches=int(r[4]), ms=float(r[5]), flops_per_image=float(r[6]), n_nblk=int(r[7])))
         return rows
 

@@ -162,6 +162,12 @@ int eigen_test_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, c
                     const int32_t* up, const float* const* h_w, int32_t cout, int32_t H, int32_t W,
                     int32_t batch, float* d_out, void* stream);
 
+/* eigen_test_conv's launch repeated `iters` times between two HIP events on the launch stream; *h_ms = average
+ * kernel duration in milliseconds (measurement hook of scripts/ and bench.py). */
+int eigen_time_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, const int32_t* cin, const int32_t* up,
+                    const float* const* h_w, int32_t cout, int32_t H, int32_t W, int32_t batch, float* d_out,
+                    int32_t iters, double* h_ms, void* stream);
+
 /* Deterministic fp32 exp / sigmoid / tanh used by the gate epilogue. */
 int eigen_test_det_math(eigen_engine* e, const float* d_x, int32_t n, float* d_exp, float* d_sig, float* d_tanh,
                         void* stream);
