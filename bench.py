@@ -140,9 +140,20 @@ def main():
         all_fl = sum(r["flops_per_image"] * args.pop * r["launches"] for r in rows)
         all_ms = sum(r["ms"] for r in rows)
         ach = fl / (ms * 1e-3) / 1e12
+        # HBM traffic per launch of the same kernel: from the committed rocprofv3 --pmc passes (separate runs of this
+        # command, scripts/pmc_passes.sh + scripts/summarize_pmc.py; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+        # for 16 B/lane reads).  PMC cannot be collected from inside this process, hence read from profiles/.
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")))
+            for kname, kv in pm["kernels"].items():
+                if "conv3x3_mfma<4, 16, 1" in kname and pm.get("pop") == args.pop:
+                    traffic = kv.get("hbm_read_bytes_per_launch", 0.0) + kv.get("hbm_write_bytes_per_launch", 0.0)
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "mfma", "kernel": "conv3x3_mfma<4,16,EPI_LSTM> (fused ConvLSTM gates, v_mfma_f32_16x16x4_f32)",
                            "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
-                           "traffic": None, "launches": n_l, "avg_launch_ms": ms / max(n_l, 1),
+                           "traffic": traffic, "traffic_source": "profiles/pmc_summary_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None, "launches": n_l, "avg_launch_ms": ms / max(n_l, 1),
                            "algorithmic_flops_per_launch": fl / max(n_l, 1),
                            "all_conv_kernels": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "frac": all_fl / (all_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                                 "total_ms": all_ms, "launches": sum(r["launches"] for r in rows)},

@@ -167,14 +167,19 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     const int q = lane >> 4;
     const int col = lane & 15;
 
-    // ---- block -> (N-block, image group, tile); tile index fastest so that co-resident blocks share a weight slab
+    // ---- block -> (N-block, image group, tile), XCD-aware: workgroup b runs on XCD b % 8 (observed dispatch order;
+    // speed only, never correctness).  Within one XCD consecutive workgroups walk the N-blocks of ONE tile, so the
+    // n_nblk blocks that read the same input tile share it through that XCD's L2 instead of re-reading it from HBM
+    // n_nblk times; the weight slabs they stream are K-block-sized and stay L2-resident as well.
     const int tiles = a.tilesX * a.tilesY;
     const int ngroups = (a.B + NIMG - 1) / NIMG;
-    int bid = blockIdx.x;
-    const int nblk = bid / (ngroups * tiles);
-    bid -= nblk * ngroups * tiles;
-    const int bgrp = bid / tiles;
-    const int t = bid - bgrp * tiles;
+    const int ntile = ngroups * tiles;
+    const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
+    const int nblk = xi % a.n_nblk;
+    const int tlin = (xi / a.n_nblk) * 8 + xcd;
+    if (tlin >= ntile) return;  // grid is padded to a multiple of 8 tiles
+    const int bgrp = tlin / tiles;
+    const int t = tlin - bgrp * tiles;
     const int tyi = t / a.tilesX, txi = t - tyi * a.tilesX;
     const int y0 = tyi * TH, x0 = txi * TW;
 

@@ -208,7 +208,8 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     a.n_nblk = op.n_nblk; a.krows = op.krows; a.wpk = op.d_wpk; a.Cout = op.Cout; a.zeros = e->d_zeros;
     a.nsrc = op.nsrc;
     for (int s = 0; s < op.nsrc; ++s) { a.src[s].C = op.src_C[s]; a.src[s].Cpad = pad4(op.src_C[s]); a.src[s].up = op.src_up[s]; }
-    const int grid = op.n_nblk * ((batch + NIMG - 1) / NIMG) * a.tilesX * a.tilesY;
+    const int ntile = ((batch + NIMG - 1) / NIMG) * a.tilesX * a.tilesY;
+    const int grid = op.n_nblk * ((ntile + 7) / 8) * 8;  // XCD-aware tile map (conv_mfma.h): tiles padded to a multiple of 8
     // 16-byte DMA staging needs chunk-aligned rows: W % 4 == 0, and W % 8 == 0 when a half-resolution source is read
     bool vec = (op.W % 4) == 0;
     for (int s = 0; s < op.nsrc; ++s) if (op.src_up[s] && ((op.W % 8) != 0 || (op.H % 2) != 0)) vec = false;
@@ -763,7 +764,7 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
 #if EIG_TIMING
     {
         const int TH_ = (op.TW == 16) ? 16 : 8, NIMG_ = 256 / (TH_ * op.TW);
-        const int grid_ = op.n_nblk * ((batch + NIMG_ - 1) / NIMG_) * ((W + op.TW - 1) / op.TW) * ((H + TH_ - 1) / TH_);
+        const int grid_ = op.n_nblk * (((((batch + NIMG_ - 1) / NIMG_) * ((W + op.TW - 1) / op.TW) * ((H + TH_ - 1) / TH_)) + 7) / 8) * 8;
         unsigned long long* dbg = nullptr;
         (void)hipMalloc((void**)&dbg, (size_t)grid_ * 16 * 8);
         (void)hipMemset(dbg, 0, (size_t)grid_ * 16 * 8);
