@@ -1,0 +1,125 @@
+"""GPU: the drop-in Python API (fitness.py) end to end against the CPU oracle, including chunking and sharding."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from evolutionary_illusion_generator_amd import fitness, grids, synth, weights
+
+
+def _oracle_fitness(pop, cfg, wts, ch, w, h, structure, pairing=0):
+    from oracle import pipeline
+    grid = grids.create_grid(structure, w, h, 10)
+    return np.array([pipeline.genome_fitness(g, cfg, grid, wts, ch, w, h, structure, pairing=pairing) for _, g in pop])
+
+
+@pytest.mark.parametrize("structure,w,h,ch", [(2, 64, 64, [1, 16, 32, 64]), (0, 160, 120, [1, 8, 16, 32]), (1, 96, 64, [3, 12, 24, 48])])
+def test_get_fitnesses_neat_drop_in(cuda, oracle_lib, tmp_path, structure, w, h, ch):
+    c_dim = ch[0]
+    cfg = synth.make_config(2, 3 if c_dim == 3 else 1)
+    pop = synth.make_population(9, cfg, seed=31)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=2)
+    ret = fitness.get_fitnesses_neat(structure, pop, wts, cfg, w, h, ch, c_dim=c_dim, best_dir=str(tmp_path), gradient=1)
+    ref = _oracle_fitness(pop, cfg, wts, ch, w, h, structure)
+    got = np.array([g.fitness for _, g in pop])
+    assert all(isinstance(g.fitness, float) for _, g in pop)
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-12, equal_nan=True), (got, ref)
+    assert np.array_equal(got, ret)
+    assert (ref != 0).any()
+    # best artefacts: the LAST maximal genome, white and black background renders
+    from PIL import Image
+    from oracle import pipeline
+    best = max(range(len(pop)), key=lambda i: (got[i], i))
+    grid = grids.create_grid(structure, w, h, 10)
+    for name, bg in (("best.png", 1), ("best_black_bg.png", 0)):
+        img = np.asarray(Image.open(tmp_path / name))
+        exp = pipeline.render_chw(pop[best][1], cfg, grid, c_dim, w, h, bg=bg)
+        exp = exp.transpose(1, 2, 0) if c_dim == 3 else exp[0]
+        assert np.array_equal(img, exp), name
+
+
+def test_population_larger_than_device_batch_is_chunked(cuda, oracle_lib):
+    w, h, ch = 64, 64, [1, 8, 16]
+    cfg = synth.make_config(2, 1)
+    pop = synth.make_population(11, cfg, seed=5)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=3)
+    genomes = [g for _, g in pop]
+    one = fitness.evaluate_population(2, genomes, wts, cfg, w, h, ch, c_dim=1, max_batch=16)
+    chunked = fitness.evaluate_population(2, genomes, wts, cfg, w, h, ch, c_dim=1, max_batch=4)
+    assert np.array_equal(one, chunked)
+    assert np.allclose(one, _oracle_fitness(pop, cfg, wts, ch, w, h, 2), rtol=1e-9, atol=1e-12)
+
+
+def test_get_vectors_and_calculate_fitness_single_image_api(cuda, oracle_lib, tmp_path):
+    from PIL import Image
+    from oracle import pipeline, scores
+    w, h, ch, structure = 160, 120, [3, 8, 16, 32], 2
+    cfg = synth.make_config(2, 3)
+    pop = synth.make_population(3, cfg, seed=8)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=4)
+    grid = grids.create_grid(structure, w, h, 10)
+    for i, (_, g) in enumerate(pop):
+        img = pipeline.render_chw(g, cfg, grid, 3, w, h)
+        path = str(tmp_path / ("img%d.png" % i))
+        Image.fromarray(img.transpose(1, 2, 0), "RGB").save(path, "PNG")
+        v = fitness.get_vectors(path, wts, ch, w, h)
+        ref_v = pipeline.image_vectors(img, wts, ch, w, h, pairing=pipeline.PAIR_SINGLE)  # original -> 2nd extension
+        if len(ref_v) == 0:
+            assert v == [None]
+            continue
+        assert isinstance(v, np.ndarray) and v.shape == ref_v.shape
+        assert np.array_equal(v.astype(np.float32), ref_v)
+        for st in (0, 1, 2, 3):
+            got = fitness.calculate_fitness(st, v, path, w, h)
+            assert got == pytest.approx(scores.fitness_from_vectors(st, ref_v.astype(np.float64), w, h), rel=1e-9, abs=1e-12)
+    assert fitness.calculate_fitness(1, [None], "x.png", w, h) == 0.0
+    with pytest.raises(NameError):
+        fitness.calculate_fitness(7, np.zeros((3, 4)), "x.png", w, h)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _rank_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)  # the test box has ONE GPU: both ranks share it, gloo carries the all-gather
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from evolutionary_illusion_generator_amd import fitness as F, synth as S, weights as W
+    w, h, ch = 64, 64, [1, 8, 16]
+    cfg = S.make_config(2, 1)
+    pop = S.make_population(7, cfg, seed=12)
+    wts = W.synthetic_prednet_weights(ch, w, h, seed=6)
+    F.get_fitnesses_neat(2, pop, wts, cfg, w, h, ch, c_dim=1, best_dir=None)
+    q.put((rank, [g.fitness for _, g in pop]))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_shard_the_population(cuda, oracle_lib):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    w, h, ch = 64, 64, [1, 8, 16]
+    cfg = synth.make_config(2, 1)
+    pop = synth.make_population(7, cfg, seed=12)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=6)
+    ref = _oracle_fitness(pop, cfg, wts, ch, w, h, 2)
+    assert res[0] == res[1]
+    assert np.allclose(res[0], ref, rtol=1e-9, atol=1e-12)
