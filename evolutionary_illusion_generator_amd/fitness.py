@@ -75,11 +75,23 @@ def clear_engines():
     _engines.clear()
 
 
-def _set_grid(eng, structure, w, h):
-    key = (int(structure), w, h)
+def leaf_planes(structure, w, h, n_inputs=2):
+    """CPPN input planes.  The reference feeds x_mat and y_mat only (generate_illusion.py:374-378); for configs with
+    num_inputs = 4 (neat_configs/default.txt:49), where PyTorch-NEAT would assert, the build-defined extra leaves are
+    r = sqrt(x^2 + y^2) and a constant 1 (BASELINE.json north_star: "(x, y, r, bias)")."""
+    g = grids.create_grid(structure, w, h, SCALING)
+    x, y = g["x_mat"], g["y_mat"]
+    if n_inputs == 2:
+        return [x, y]
+    if n_inputs == 4:
+        return [x, y, np.sqrt(x * x + y * y), np.ones_like(x)]
+    raise ValueError("CPPNs with %d inputs are not defined (2: x, y; 4: x, y, r, bias)" % n_inputs)
+
+
+def _set_grid(eng, structure, w, h, n_inputs=2):
+    key = (int(structure), w, h, n_inputs)
     if eng._grid_key != key:
-        g = grids.create_grid(structure, w, h, SCALING)
-        eng.set_grid([g["x_mat"], g["y_mat"]])
+        eng.set_grid(leaf_planes(structure, w, h, n_inputs))
         eng._grid_key = key
 
 
@@ -134,12 +146,13 @@ def evaluate_population(structure, genomes, model_name, config, w, h, channels, 
     if channels[0] != c_dim:
         raise ValueError("channels[0]=%d but c_dim=%d: PredNet's input channels are the image channels" % (channels[0], c_dim))
     eng = get_engine(model_name, w, h, channels, max_batch=max_batch)
-    _set_grid(eng, structure, w, h)
+    n_in = len(config.genome_config.input_keys)
+    _set_grid(eng, structure, w, h, n_in)
     c_out = c_dim if gradient == 1 else 1
     out = np.zeros(len(genomes), dtype=np.float64)
     for i in range(0, len(genomes), eng.max_batch):
         chunk = genomes[i:i + eng.max_batch]
-        gb = GenomeBatch(chunk, config, c_out)  # Q6: the first c_dim outputs are rendered
+        gb = GenomeBatch(chunk, config, c_out, n_leaves=n_in)  # Q6: the first c_dim outputs are rendered
         out[i:i + len(chunk)] = eng.eval_population(gb, int(structure), bg=bg, gradient=gradient, pairing=pairing)
     return out
 
@@ -173,11 +186,12 @@ def render_images(structure, genomes, model_name, config, w, h, channels, c_dim=
     """uint8 [n, C, H, W] images of get_image_from_cppn (generate_illusion.py:372-460) for a list of genomes."""
     import torch
     eng = get_engine(model_name, w, h, channels)
-    _set_grid(eng, structure, w, h)
+    n_in = len(config.genome_config.input_keys)
+    _set_grid(eng, structure, w, h, n_in)
     out = []
     for i in range(0, len(genomes), eng.max_batch):
         chunk = genomes[i:i + eng.max_batch]
-        gb = GenomeBatch(chunk, config, c_dim if gradient == 1 else 1)
+        gb = GenomeBatch(chunk, config, c_dim if gradient == 1 else 1, n_leaves=n_in)
         d = torch.empty((len(chunk), c_dim, h, w), dtype=torch.uint8, device="cuda")
         eng.render_cppn(gb, d, bg=bg, gradient=gradient)
         torch.cuda.synchronize()

@@ -246,3 +246,88 @@ def test_end_to_end_fitness(cuda, oracle_lib, w, h, ch, structure, pairing):
     ref = np.array([pipeline.genome_fitness(g, cfg, grid, wts, ch, w, h, structure, pairing=pairing) for _, g in pop])
     assert np.allclose(got, ref, rtol=1e-9, atol=1e-12, equal_nan=True), (got, ref)
     assert (ref != 0).sum() >= 1, "vacuous parity: the oracle scored everything 0"
+
+
+# ------------------------------------------------------------------------------------------ full-size checks
+def test_full_size_256_colour_properties_and_oracle_spot_check(cuda, oracle_lib):
+    """BASELINE.json's headline shape (256x256, channels 3,48,96,192).  The CPU oracle needs ~10 s per genome here, so
+    ONE genome is compared end to end; the rest are size-independent properties: batch-position invariance
+    (duplicates in one batch agree bit for bit), batch-size invariance (a genome alone == inside a batch) and
+    run-to-run determinism."""
+    import torch
+    from oracle import pipeline
+    w, h, ch, structure = 256, 256, [3, 48, 96, 192], 1
+    cfg, pop, grid = _render_setup(w, h, 3, 5, seed=0, structure=structure)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=0)
+    genomes = [g for _, g in pop]
+    batch = [genomes[0], genomes[1], genomes[0], genomes[2], genomes[3], genomes[1], genomes[4]]
+    e = _eng(w, h, ch, len(batch))
+    e.set_weights(wts)
+    e.set_grid([grid["x_mat"], grid["y_mat"]])
+    gb = genome_mod.GenomeBatch(batch, cfg, 3)
+    f1 = e.eval_population(gb, structure)
+    f2 = e.eval_population(gb, structure)
+    assert np.array_equal(f1, f2)                                 # deterministic
+    assert f1[0] == f1[2] and f1[1] == f1[5]                      # position in the batch does not matter
+    alone = e.eval_population(genome_mod.GenomeBatch([genomes[3]], cfg, 3), structure)
+    assert alone[0] == f1[4]                                      # nor does the batch size
+    # frames of duplicates are byte-identical
+    d_img = torch.zeros((len(batch), 3, h, w), dtype=torch.uint8, device=cuda)
+    e.render_cppn(gb, d_img)
+    d_fr = torch.zeros((len(batch), 2, 3, h, w), dtype=torch.uint8, device=cuda)
+    e.prednet_rollout(d_img, len(batch), 21, 19, d_fr)
+    torch.cuda.synchronize()
+    fr = d_fr.cpu().numpy()
+    assert np.array_equal(fr[0], fr[2]) and np.array_equal(fr[1], fr[5]) and not np.array_equal(fr[0], fr[1])
+    # one genome against the bit-exact CPU oracle at full size: frames and fitness
+    img = pipeline.render_chw(genomes[0], cfg, grid, 3, w, h)
+    assert np.array_equal(img, d_img[0].cpu().numpy())
+    ref_fr = oracle_lib.prednet_rollout(wts, ch, w, h, img, n_repeat=20, n_ext=1)
+    assert np.array_equal(ref_fr[19], fr[0, 0]) and np.array_equal(ref_fr[20], fr[0, 1])
+    ref = pipeline.image_fitness(img, wts, ch, w, h, structure)
+    assert f1[0] == pytest.approx(ref, rel=1e-9, abs=1e-12) and ref != 0
+
+
+def test_largest_config_512_colour_one_step_window(cuda, oracle_lib):
+    """BASELINE.json configs[4] shape (512x512 colour): a short roll-out (3 repeats + 1 extension) against the oracle
+    keeps the CPU side to a few seconds while still covering every layer shape of that configuration."""
+    import torch
+    from oracle import pipeline
+    w, h, ch = 512, 512, [3, 48, 96, 192]
+    cfg, pop, grid = _render_setup(w, h, 3, 2, seed=4, structure=2)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=1)
+    imgs = np.stack([pipeline.render_chw(g, cfg, grid, 3, w, h) for _, g in pop])
+    e = _eng(w, h, ch, 2, n_repeat=3, n_ext=1)
+    e.set_weights(wts)
+    d_img = torch.from_numpy(imgs).to(cuda)
+    d_fr = torch.zeros((2, 4, 3, h, w), dtype=torch.uint8, device=cuda)
+    e.prednet_rollout(d_img, 2, 4, 0, d_fr)
+    torch.cuda.synchronize()
+    got = d_fr.cpu().numpy()
+    ref = oracle_lib.prednet_rollout(wts, ch, w, h, imgs[0], n_repeat=3, n_ext=1)
+    assert np.array_equal(got[0], ref)
+    v = oracle_lib.lucas_kanade(ref[2], ref[3])
+    dv = torch.zeros((2, e.K, 4), device=cuda); dc = torch.zeros(2, dtype=torch.int32, device=cuda)
+    e.flow(d_fr[:, 2].contiguous(), 3 * h * w, d_fr[:, 3].contiguous(), 3 * h * w, 2, dv, dc)
+    torch.cuda.synchronize()
+    assert int(dc[0]) == len(v) and np.array_equal(dv[0, :len(v)].cpu().numpy(), v)
+
+
+def test_default_config_four_inputs_six_outputs(cuda, oracle_lib):
+    """neat_configs/default.txt (num_inputs = 4, num_outputs = 6; BASELINE.json configs[0], 64x64 gray): the reference
+    asserts here; build-defined: leaves x, y, r = sqrt(x^2 + y^2), bias = 1 and the first c_dim outputs."""
+    from oracle import cppn, pipeline, scores
+    import oracle
+    w, h, ch, structure = 64, 64, [1, 16, 32, 64], 2
+    cfg = synth.make_config(4, 6)
+    pop = synth.make_population(10, cfg, seed=2, num_hidden=8)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=0)
+    from evolutionary_illusion_generator_amd import fitness, grids
+    fitness.get_fitnesses_neat(structure, pop, wts, cfg, w, h, ch, c_dim=1, best_dir=None)
+    grid = grids.create_grid(structure, w, h, 10)
+    x, y = grid["x_mat"].reshape(-1), grid["y_mat"].reshape(-1)
+    extra = [np.sqrt(x * x + y * y), np.ones_like(x)]
+    for _, g in pop:
+        img = cppn.render(grid, g, cfg, 1, w, h, extra_leaves=extra)[None]
+        ref = pipeline.image_fitness(np.ascontiguousarray(img), wts, ch, w, h, structure)
+        assert g.fitness == pytest.approx(ref, rel=1e-9, abs=1e-12)
