@@ -199,15 +199,49 @@ def render_images(structure, genomes, model_name, config, w, h, channels, c_dim=
     return np.concatenate(out)
 
 
-def save_best_artifacts(structure, genome, model_name, config, w, h, channels, c_dim, best_dir, gradient):
-    """best.png / best_black_bg.png of generate_illusion.py:650-663 (flow overlay and the 800x800 'enhanced'
-    render are listed as next rows in DESIGN.md)."""
-    from PIL import Image
+def save_best_artifacts(structure, genome, model_name, config, w, h, channels, c_dim, best_dir, gradient,
+                        enhanced_size=800, flow_scale=20.0):
+    """best.png, best_black_bg.png, best_flow.png and the 800x800 enhanced.png of generate_illusion.py:650-673.
+    The renders run on the device (the reference's pure-Python enhanced_image_grid + per-pixel loops take ~12 s);
+    best_flow.png is a plain overlay of the flow vectors (the upstream drawing style is not pinned anywhere)."""
+    import torch
+    from PIL import Image, ImageDraw
     os.makedirs(best_dir, exist_ok=True)
-    for bg, name in ((1, "best.png"), (0, "best_black_bg.png")):
-        img = render_images(structure, [genome], model_name, config, w, h, channels, c_dim, gradient, bg)[0]
-        arr = img.transpose(1, 2, 0) if c_dim == 3 else img[0]
-        Image.fromarray(arr, "RGB" if c_dim == 3 else "L").save(os.path.join(best_dir, name), "PNG")
+    mode = "RGB" if c_dim == 3 else "L"
+    to_pil = lambda img: Image.fromarray(img.transpose(1, 2, 0) if c_dim == 3 else img[0], mode)
+    white = render_images(structure, [genome], model_name, config, w, h, channels, c_dim, gradient, 1)[0]
+    to_pil(white).save(os.path.join(best_dir, "best.png"), "PNG")
+    black = render_images(structure, [genome], model_name, config, w, h, channels, c_dim, gradient, 0)[0]
+    to_pil(black).save(os.path.join(best_dir, "best_black_bg.png"), "PNG")
+    # flow overlay: population pairing (prediction@20 -> first extension), as the fitness used
+    eng = get_engine(model_name, w, h, channels)
+    d = torch.from_numpy(white[None]).cuda()
+    _, vecs = eng.eval_images(d, 1, int(structure), pairing=PAIR_POPULATION)
+    flow = to_pil(white).convert("RGB")
+    draw = ImageDraw.Draw(flow)
+    for x, y, dx, dy in vecs[0]:
+        draw.line([(x, y), (x + flow_scale * dx, y + flow_scale * dy)], fill=(255, 0, 0), width=1)
+        draw.ellipse([x - 1, y - 1, x + 1, y + 1], fill=(255, 255, 0))
+    flow.save(os.path.join(best_dir, "best_flow.png"), "PNG")
+    # enhanced image: 3x3 + 2x2 circles on a render-only engine (one PredNet layer keeps its workspaces tiny)
+    if enhanced_size and int(structure) in (int(StructureType.Circles), int(StructureType.CirclesFree)):
+        e = enhanced_size
+        key = ("render", _local_device(), e, c_dim)
+        reng = _engines.get(key)
+        if reng is None:
+            reng = Engine(e, e, [c_dim], 1, device=_local_device())
+            reng._grid_key = None
+            _engines[key] = reng
+        gk = ("enhanced", int(structure), e)
+        if reng._grid_key != gk:
+            g = grids.enhanced_image_grid(e, e, structure)
+            reng.set_grid([g["x_mat"], g["y_mat"]])
+            reng._grid_key = gk
+        gb = GenomeBatch([genome], config, c_dim if gradient == 1 else 1, n_leaves=len(config.genome_config.input_keys))
+        dimg = torch.empty((1, c_dim, e, e), dtype=torch.uint8, device="cuda")
+        reng.render_cppn(gb, dimg, bg=1, gradient=gradient)
+        torch.cuda.synchronize()
+        to_pil(dimg.cpu().numpy()[0]).save(os.path.join(best_dir, "enhanced.png"), "PNG")
 
 
 def _read_image_chw(image_path, c_dim, w, h):

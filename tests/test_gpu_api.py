@@ -42,6 +42,12 @@ def test_get_fitnesses_neat_drop_in(cuda, oracle_lib, tmp_path, structure, w, h,
         exp = pipeline.render_chw(pop[best][1], cfg, grid, c_dim, w, h, bg=bg)
         exp = exp.transpose(1, 2, 0) if c_dim == 3 else exp[0]
         assert np.array_equal(img, exp), name
+    assert Image.open(tmp_path / "best_flow.png").size == (w, h)
+    if structure == 1:  # enhanced.png: the 800x800 3x3 + 2x2 circle grid (generate_illusion.py:665-671), byte-exact
+        from oracle import cppn
+        eg = grids.enhanced_image_grid(800, 800, structure)
+        exp = cppn.render(eg, pop[best][1], cfg, c_dim, 800, 800)
+        assert np.array_equal(np.asarray(Image.open(tmp_path / "enhanced.png")), exp)
 
 
 def test_population_larger_than_device_batch_is_chunked(cuda, oracle_lib):
