@@ -356,40 +356,42 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
 
         // The two tile layouts (full resolution / unpooled source) differ only in the nine gather addresses, the four
         // sub-tile offsets and the channel stride, all wave-uniform per K-block: ONE loop body.
-        const bool up = cur_kb.up;
-        int ad[9], mo[4];
-#pragma unroll
-        for (int st = 0; st < 9; ++st) ad[st] = up ? addrU[st] : addrA[st];
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int m_full = (TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S);
-            const int m_up = (TW == 16) ? ((mi >> 1) * SU + (mi & 1) * 4) : (mi * SU);
-            mo[mi] = up ? m_up : m_full;
-        }
-        const int pl4 = 4 * (up ? PLANE_U : PLANE);
+        // Two instantiations of the 18-step body (full-resolution tile / unpooled source) so that every LDS offset of
+        // the operand gather is an immediate: the four A reads of a step pair up into two ds_read2_b32, no address VALU.
         const float* const in_lds = cur;
         const float* const w_lds = cur + KC * PLANE + boff;
+        auto body = [&](auto up_tag) {
+            constexpr bool UP = decltype(up_tag)::value;
+            constexpr int PL = UP ? PLANE_U : PLANE;
+            const int* const ad = UP ? addrU : addrA;
 #pragma unroll
-        for (int st = 0; st < NSTEP; ++st) {
-            if (st < 9 || cur_kb.kc > 4) {  // second period only for a full K-block (wave-uniform)
-                const int per = st / 9, s9 = st % 9;
-                float av[4], bv[NI];
+            for (int st = 0; st < NSTEP; ++st) {
+                if (st < 9 || cur_kb.kc > 4) {  // second period only for a full K-block (wave-uniform)
+                    const int per = st / 9, s9 = st % 9;
+                    float av[4], bv[NI];
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) av[mi] = in_lds[per * pl4 + ad[s9] + mo[mi]];
+                    for (int mi = 0; mi < 4; ++mi) {
+                        const int moff = UP ? ((TW == 16) ? ((mi >> 1) * SU + (mi & 1) * 4) : (mi * SU))
+                                            : ((TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S));
+                        av[mi] = in_lds[ad[s9] + per * 4 * PL + moff];
+                    }
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) bv[ni] = w_lds[st * 4 * NB + ni * 16];
+                    for (int ni = 0; ni < NI; ++ni) bv[ni] = w_lds[st * 4 * NB + ni * 16];
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+                    for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni)
-                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                        for (int ni = 0; ni < NI; ++ni)
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                }
+                if (more_kb) {
+#pragma unroll
+                    for (int j = 0; j < NOPS; ++j)
+                        if (j * NSTEP / NOPS == st) dma_op(j, nxt_kb, wrow_nxt, nxt);
+                }
             }
-            if (more_kb) {
-#pragma unroll
-                for (int j = 0; j < NOPS; ++j)
-                    if (j * NSTEP / NOPS == st) dma_op(j, nxt_kb, wrow_nxt, nxt);
-            }
-        }
+        };
+        if (VEC && cur_kb.up) body(std::true_type{});
+        else body(std::false_type{});
         wrow = wrow_nxt;
         cur_kb = nxt_kb;
         const unsigned long long tk1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
