@@ -16,7 +16,7 @@
 //   - the input tile with its 1-pixel halo, [KC][NIMG][TH+2][TW+2] fp32, straight into LDS with global_load_lds 4 B
 //     per lane (each lane supplies the address of its halo pixel, or of a zero word outside the image; the 2x
 //     nearest unpooling of the R_{l+1} source is folded into that address), and
-//   - the weight slab [KC*9][NI*16] fp32 straight into LDS with global_load_lds 16 B per lane,
+//   - the weight slab [KC*9][16 channels][NI tiles] fp32 straight into LDS, 16 B per lane,
 // into the buffer NOT being computed on (two LDS buffers, loads in flight during the MFMAs of the previous K-block),
 // then runs KC*9/4 MFMA steps whose A operand is gathered from the halo tile at (pixel + tap) -- im2col never exists
 // in memory.  k advances by 4 per step, (channel, tap) = divmod(k, 9), so the per-lane LDS offset pattern has period
@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
             addrU[s] = baseU + c * PLANE_U + ((dy + ky - 1) >> 1) * SU + ((dx + kx - 1) >> 1);
         }
     }
-    const int boff = q * NB + col;
+    const int boff = q * NB + col * NI;  // weight slab row k = [16 channels][NI tiles]: a lane's NI values are contiguous
 
     f32x4 acc[4][NI];
 #pragma unroll
@@ -375,8 +375,14 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
                                             : ((TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S));
                         av[mi] = in_lds[ad[s9] + per * 4 * PL + moff];
                     }
+                    if (NI == 4) {  // one ds_read_b128
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(w_lds + st * 4 * NB);
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) bv[ni] = w_lds[st * 4 * NB + ni * 16];
+                        for (int ni = 0; ni < NI; ++ni) bv[ni] = b4[ni];
+                    } else {
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni) bv[ni] = w_lds[st * 4 * NB + ni];
+                    }
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll

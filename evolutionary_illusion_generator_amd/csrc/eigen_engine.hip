@@ -155,7 +155,9 @@ static std::vector<float> pack_weights(const ConvOp& op, const float* const srcw
                         else if (lstm == 2) { g = n / 4; o = n % 4; }
                         else o = nb * NB + n;
                         if (o >= op.Cout) continue;
-                        dst[n] = srcw[s][g][((size_t)o * Cin + c) * 9 + tap];
+                        // LDS/slab column order: [16 lanes (n % 16)][NI tiles (n / 16)] so that a lane reads its NI values
+                        // of a row with one ds_read_b128 (conv_mfma.h: boff)
+                        dst[(n % 16) * op.NI + (n / 16)] = srcw[s][g][((size_t)o * Cin + c) * 9 + tap];
                     }
                 }
         }
