@@ -50,6 +50,12 @@ def load_library(path=None):
     global _lib
     if _lib is None or path is not None:
         p = path or LIB_PATH
+        # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime of the process (device tensors and
+        # streams come from torch), so make sure it is loaded before this library's dependency is resolved.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         if not os.path.exists(p):
             raise EngineError("HIP engine library %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % p)
