@@ -48,6 +48,9 @@ CONV_CASES = [
     (3, 20, 12, 32, [(20, 0), (8, 1)]),   # ragged map -> partial tiles (TW = 8)
     (1, 24, 40, 36, [(40, 0)]),           # ragged map with 16x16 tiles, >1 K-block, cout padding
     (2, 64, 64, 12, [(6, 0), (48, 1), (3, 0)]),  # LSTM0-like source mix
+    (2, 12, 10, 16, [(8, 0)]),            # W % 4 != 0: 4-byte DMA path (VEC = false)
+    (3, 6, 6, 8, [(5, 0), (4, 1)]),       # tiny odd map with an unpooled 3x3 source
+    (1, 48, 80, 64, [(16, 0), (16, 1)]),  # W % 8 == 0: unpooled source staged at its own resolution
 ]
 
 
@@ -127,7 +130,8 @@ def test_cppn_render_saturating_bands_byte_exact(cuda, oracle_lib, w, h, structu
 
 
 @pytest.mark.parametrize("w,h,ch,requant", [(64, 64, [1, 16, 32, 64], False), (48, 32, [3, 8, 16, 32], False),
-                                              (80, 40, [3, 12, 20], True), (160, 120, [1, 16, 32, 64], False)])
+                                              (80, 40, [3, 12, 20], True), (160, 120, [1, 16, 32, 64], False),
+                                              (20, 12, [1, 4, 8], False)])  # widths 20 / 10 / 5: mixed VEC and 4-byte DMA layers
 def test_prednet_rollout_frames_bit_exact(cuda, oracle_lib, w, h, ch, requant):
     import torch
     from oracle import cppn
