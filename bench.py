@@ -65,9 +65,18 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pop", type=int, default=POP_PER_GPU, help="genomes per GPU")
+    ap.add_argument("--shape", default="headline", choices=["headline", "ref160"],
+                    help="headline: 256x256 colour pop 256 (BASELINE.json metric); ref160: the reference's own default "
+                         "160x120 colour, pop 50 (the only published datum: 0.80 evals/s on a Colab GPU, BASELINE.md)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
+    global W, H
+    if args.shape == "ref160":
+        W, H = 160, 120
+        if args.pop == POP_PER_GPU:
+            args.pop = 50
+        args.no_cpu_baseline = True  # supplementary number: no CPU leg, no PMC traffic
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -114,14 +123,14 @@ def main():
     stage = eng.timings()
 
     out = {
-        "metric": "genome fitness evals/sec at 256x256, pop=256 per GPU",
+        "metric": "genome fitness evals/sec at %dx%d, pop=%d per GPU" % (W, H, args.pop),
         "value": global_pop * args.steps / dt,
         "unit": "genome evals/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1000.0 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "neat_configs/circles.txt colour pop=%d/GPU, 256x256, PredNet 3,48,96,192, 21 steps, LK + rotation-symmetry score" % args.pop,
+        "config": {"workload": "neat_configs/circles.txt colour pop=%d/GPU, %dx%d, PredNet 3,48,96,192, 21 steps, LK + rotation-symmetry score" % (args.pop, W, H),
                    "global_pop": global_pop, "image": [W, H], "channels": CHANNELS, "structure": "Circles",
                    "parallelism": "pop-shard x%d + all-gather(fitness f64)" % world},
         "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items() if k.endswith("_ms") and k != "conv_ms"},
