@@ -9,6 +9,10 @@ SHAPES = {  # name: (B, H, W, cout, [(cin, up)...])   EPI_RAW with cout = 4*C mi
     "L2-lstm-like": (64, 64, 64, 384, [(192, 0), (192, 1), (96, 0)]),
     "L1-lstm-like": (64, 128, 128, 192, [(96, 0), (96, 1), (48, 0)]),
     "L3-lstm-like": (64, 32, 32, 768, [(384, 0), (192, 0)]),
+    "L0-lstm-like": (64, 256, 256, 16, [(6, 0), (48, 1), (3, 0)]),
+    "convA1-like": (64, 256, 256, 48, [(6, 0)]),
+    "convA2-like": (64, 128, 128, 96, [(96, 0)]),
+    "convP1-like": (64, 128, 128, 48, [(48, 0)]),
 }
 libs = sys.argv[1:] or [engine.LIB_PATH]
 for lib in libs:

@@ -133,3 +133,26 @@ def test_lucas_kanade_edge_cases(oracle_lib):
     assert len(v) > 0 and np.all(v[:, 2:] == 0)                      # identical frames -> zero flow
     small = rng.integers(0, 255, (1, 20, 24)).astype(np.uint8)       # pyramid cannot go below the 15-px window
     oracle_lib.lucas_kanade(small, small)
+
+
+def test_flow_building_blocks_against_independent_scipy_math(oracle_lib):
+    """pyrDown, the Shi-Tomasi response and the Scharr-based LK normal equations re-derived with scipy / float64."""
+    from scipy import ndimage
+    rng = np.random.default_rng(7)
+    g0, _ = _texture(rng, 40, 56)
+    # pyrDown = 5x5 binomial blur (BORDER_REFLECT_101 == scipy 'mirror'), every second pixel, round half up
+    k = np.array([1, 4, 6, 4, 1], dtype=np.int64)
+    blur = ndimage.correlate1d(ndimage.correlate1d(g0.astype(np.int64), k, axis=0, mode="mirror"), k, axis=1, mode="mirror")
+    assert np.array_equal(oracle_lib.pyr_down(g0), ((blur[::2, ::2] + 128) >> 8).astype(np.uint8))
+    # cornerMinEigenVal: smaller eigenvalue of the 7x7 box-summed Sobel structure tensor, scaled by (1/(4*7*255))^2
+    f = g0.astype(np.float64)
+    dx = ndimage.correlate1d(ndimage.correlate1d(f, [-1, 0, 1], axis=1, mode="mirror"), [1, 2, 1], axis=0, mode="mirror")
+    dy = ndimage.correlate1d(ndimage.correlate1d(f, [-1, 0, 1], axis=0, mode="mirror"), [1, 2, 1], axis=1, mode="mirror")
+    box = lambda a: ndimage.uniform_filter(a, 7, mode="mirror") * 49.0
+    sc = (1.0 / (4 * 7 * 255.0)) ** 2
+    a, b, c = box(dx * dx) * sc, box(dx * dy) * sc, box(dy * dy) * sc
+    lam = 0.5 * (a + c) - np.sqrt((0.5 * (a - c)) ** 2 + b * b)
+    got = oracle_lib.min_eig(g0).astype(np.float64)
+    assert np.max(np.abs(got - lam)) <= 2e-6 * max(1.0, lam.max())
+    # the box-filter border of the tensor is the tensor AT the mirrored pixel (not the tensor of a mirrored image):
+    # uniform_filter(mode='mirror') on the product images is exactly that, so the agreement above covers the border.
