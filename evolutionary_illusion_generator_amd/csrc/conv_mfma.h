@@ -12,15 +12,18 @@
 // Channel counts are padded to multiples of 4 with zero weights AFTER the real channels of each source, which
 // appends exact no-op terms (fma(a, 0, acc) == acc) and leaves the chain of real terms untouched.
 //
-// Per K-block (KC = 8 channels of one source) the block stages
-//   - the input tile with its 1-pixel halo, [KC][NIMG][TH+2][TW+2] fp32, straight into LDS with global_load_lds 4 B
-//     per lane (each lane supplies the address of its halo pixel, or of a zero word outside the image; the 2x
-//     nearest unpooling of the R_{l+1} source is folded into that address), and
-//   - the weight slab [KC*9][16 channels][NI tiles] fp32 straight into LDS, 16 B per lane,
-// into the buffer NOT being computed on (two LDS buffers, loads in flight during the MFMAs of the previous K-block),
-// then runs KC*9/4 MFMA steps whose A operand is gathered from the halo tile at (pixel + tap) -- im2col never exists
-// in memory.  k advances by 4 per step, (channel, tap) = divmod(k, 9), so the per-lane LDS offset pattern has period
-// 9 steps (= 4 channels): nine precomputed address registers + immediates, no address VALU in the loop.
+// Per K-block (KC = 8 channels of one source) both operands travel global -> LDS by LDS-DMA (buffer_load ... lds,
+// 16 B per lane; no staging registers, no ds_write pass) into the buffer NOT being computed on:
+//   - the input tile with its halo as ALIGNED 16-byte chunks of the source rows, [KC][NIMG][TH+2][TW+8] fp32 (an
+//     unpooled R_{l+1} source is staged at its own resolution, the x2 nearest unpooling happens in the gather
+//     address); buffer descriptors make the DMA free of per-lane address arithmetic and turn out-of-image /
+//     padded-channel slots into hardware zero fill;
+//   - the weight slab [KC*9][16 channels][NI tiles] fp32 (a lane's NI values of a row are one ds_read_b128).
+// The DMA instructions of K-block k+1 are interleaved with the KC*9/4 = 18 MFMA steps of K-block k; one barrier per
+// K-block.  The A operand is gathered from the halo tile at (pixel + tap) -- im2col never exists in memory.  k advances
+// by 4 per step, (channel, tap) = divmod(k, 9), so the per-lane LDS offset pattern has period 9 steps (= 4 channels):
+// nine precomputed address registers + immediates, no address VALU in the loop.
+// (Layers whose width is not a multiple of 4 use 4-byte flat-address DMA into [KC][NIMG][TH+2][TW+2]: VEC = false.)
 //
 // Row <-> pixel map of a 16-row MFMA sub-tile: 2 image rows x 8 columns; row r = 4q + reg covers
 // (dy, dx) = (reg >> 1, 2q + (reg & 1)), so the four accumulator registers of a lane are one 2x2 pooling window
@@ -224,33 +227,6 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
         }
     }
 
-    // ---- A-operand gather addresses: lane row r = lane&15 = 4*rq + rreg -> pixel (dy, dx); k-slot j = lane>>4.
-    // k = 4*step + j, (channel, tap) = divmod(k, 9): period 9 steps = 4 channels -> nine address registers per layout.
-    int addrA[9], addrU[9];
-    {
-        const int r = col;
-        const int dy = (r & 3) >> 1, dx = 2 * (r >> 2) + (r & 1);
-        const int base = (TW == 16) ? (wv * 4 + dy) * S + dx + XO      // sub-tile mi adds (mi>>1)*2*S + (mi&1)*8
-                                    : wv * PH * S + dy * S + dx + XO;  // one image per wave; sub-tile mi adds mi*2*S
-        const int baseU = (TW == 16) ? (wv * 2 + 1) * SU + 4           // sub-tile mi adds (mi>>1)*SU + (mi&1)*4
-                                     : (wv * PHU + 1) * SU + 4;        // sub-tile mi adds mi*SU
-#pragma unroll
-        for (int s = 0; s < 9; ++s) {
-            const int k = 4 * s + q;
-            const int c = k / 9, tap = k - 9 * c;
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            addrA[s] = base + c * PLANE + ky * S + kx;
-            addrU[s] = baseU + c * PLANE_U + ((dy + ky - 1) >> 1) * SU + ((dx + kx - 1) >> 1);
-        }
-    }
-    const int boff = q * NB + col * NI;  // weight slab row k = [16 channels][NI tiles]: a lane's NI values are contiguous
-
-    f32x4 acc[4][NI];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     // ---- K loop: K-blocks of KC channels, enumerated across the sources, two LDS buffers.
     // Both operands go global -> LDS by DMA (global_load_lds: no staging registers, no ds_write pass; every lane
     // supplies the global address of its LDS slot, or of a zero buffer outside the image / for padded channels).
@@ -342,6 +318,35 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     int wrow = 0;  // first packed weight row of the current K-block
 #pragma unroll
     for (int j = 0; j < NOPS; ++j) dma_op(j, cur_kb, wrow, lds);
+    // (the first K-block is in flight: everything below up to the wait overlaps its latency)
+
+    // ---- A-operand gather addresses: lane row r = lane&15 = 4*rq + rreg -> pixel (dy, dx); k-slot j = lane>>4.
+    // k = 4*step + j, (channel, tap) = divmod(k, 9): period 9 steps = 4 channels -> nine address registers per layout.
+    int addrA[9], addrU[9];
+    {
+        const int r = col;
+        const int dy = (r & 3) >> 1, dx = 2 * (r >> 2) + (r & 1);
+        const int base = (TW == 16) ? (wv * 4 + dy) * S + dx + XO      // sub-tile mi adds (mi>>1)*2*S + (mi&1)*8
+                                    : wv * PH * S + dy * S + dx + XO;  // one image per wave; sub-tile mi adds mi*2*S
+        const int baseU = (TW == 16) ? (wv * 2 + 1) * SU + 4           // sub-tile mi adds (mi>>1)*SU + (mi&1)*4
+                                     : (wv * PHU + 1) * SU + 4;        // sub-tile mi adds mi*SU
+#pragma unroll
+        for (int s = 0; s < 9; ++s) {
+            const int k = 4 * s + q;
+            const int c = k / 9, tap = k - 9 * c;
+            const int ky = tap / 3, kx = tap - 3 * ky;
+            addrA[s] = base + c * PLANE + ky * S + kx;
+            addrU[s] = baseU + c * PLANE_U + ((dy + ky - 1) >> 1) * SU + ((dx + kx - 1) >> 1);
+        }
+    }
+    const int boff = q * NB + col * NI;  // weight slab row k = [16 channels][NI tiles]: a lane's NI values are contiguous
+
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
