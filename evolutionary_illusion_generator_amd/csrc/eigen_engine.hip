@@ -489,8 +489,22 @@ int eigen_render_cppn(eigen_engine* e, const eigen_genome_batch* g, int32_t bg, 
         if (nn < 1) return fail(EIGEN_ERR_INVALID, "genome %d has no nodes", i);
         max_nodes = std::max(max_nodes, nn); max_edges = std::max(max_edges, ne);
     }
-    for (int i = 0; i < total_edges; ++i)
-        if (g->edge_src[i] < -(e->n_planes + 1)) return fail(EIGEN_ERR_INVALID, "edge %d references leaf %d but only %d planes are set", i, -g->edge_src[i] - 1, e->n_planes);
+    // every edge must point at a leaf, the constant-1 leaf, or an EARLIER node of the same genome (topological order)
+    for (int gi = 0; gi < G; ++gi) {
+        const int n0 = g->node_off[gi], n1 = g->node_off[gi + 1];
+        for (int n = n0; n < n1; ++n)
+            for (int k = g->edge_off[n]; k < g->edge_off[n + 1]; ++k) {
+                const int src = g->edge_src[k];
+                if (src < -(e->n_planes + 1))
+                    return fail(EIGEN_ERR_INVALID, "genome %d: edge %d references leaf %d but only %d planes are set", gi, k, -src - 1, e->n_planes);
+                if (src >= n - n0)
+                    return fail(EIGEN_ERR_INVALID, "genome %d: edge %d of node %d reads node %d (not topologically earlier)", gi, k, n - n0, src);
+            }
+        for (int c = 0; c < g->c_out; ++c) {
+            const int o = g->out_node[gi * g->c_out + c];
+            if (o < 0 || o >= n1 - n0) return fail(EIGEN_ERR_INVALID, "genome %d: output %d names node %d of %d", gi, c, o, n1 - n0);
+        }
+    }
     const size_t lds = (size_t)max_nodes * CPPN_THREADS * 8 + (size_t)max_nodes * 16 + (size_t)max_edges * 8 + (size_t)(max_nodes + 1) * 4 + (size_t)max_edges * 4 + max_nodes + 64;
     if (lds > 160 * 1024) return fail(EIGEN_ERR_CAPACITY, "genome with %d nodes / %d edges needs %zu B of LDS (> 160 KiB)", max_nodes, max_edges, lds);
     if (e->g_node_off.ensure(G + 1) || e->g_edge_off.ensure(total_nodes + 1) || e->g_node_act.ensure(total_nodes) ||
