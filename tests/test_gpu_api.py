@@ -129,3 +129,36 @@ def test_two_ranks_shard_the_population(cuda, oracle_lib):
     ref = _oracle_fitness(pop, cfg, wts, ch, w, h, 2)
     assert res[0] == res[1]
     assert np.allclose(res[0], ref, rtol=1e-9, atol=1e-12)
+
+
+def test_abi_error_conventions(cuda):
+    """Negative status + eigen_last_error text; nothing is computed on bad input."""
+    import torch
+    from evolutionary_illusion_generator_amd import genome as gm
+    from evolutionary_illusion_generator_amd.engine import Engine, EngineError
+    with pytest.raises(EngineError, match="divisible"):
+        Engine(66, 64, [1, 4, 8], 2)                       # 2x2 pooling per layer needs W % 4 == 0 here
+    with pytest.raises(EngineError, match="c_dim"):
+        Engine(64, 64, [2, 4], 2)
+    e = Engine(32, 32, [1, 4, 8], 2)
+    img = torch.zeros((2, 1, 32, 32), dtype=torch.uint8, device=cuda)
+    fr = torch.zeros((2, 2, 1, 32, 32), dtype=torch.uint8, device=cuda)
+    with pytest.raises(EngineError, match="eigen_set_prednet_weights"):
+        e.prednet_rollout(img, 2, 21, 19, fr)
+    cfg = synth.make_config(2, 1)
+    gb = gm.GenomeBatch([g for _, g in synth.make_population(2, cfg)], cfg, 1)
+    with pytest.raises(EngineError, match="eigen_set_grid"):
+        e.render_cppn(gb, img)
+    e.set_weights(weights.synthetic_prednet_weights([1, 4, 8], 32, 32))
+    with pytest.raises(EngineError, match="max_batch"):
+        e.prednet_rollout(img, 3, 21, 19, fr)
+    with pytest.raises(EngineError, match="n_steps"):
+        e.prednet_rollout(img, 2, 23, 19, fr)
+    g = grids.create_grid(2, 32, 32, 10)
+    e.set_grid([g["x_mat"], g["y_mat"]])
+    gb.edge_src[0] = 10 ** 6                                # corrupt program: must be rejected on the host
+    with pytest.raises(EngineError, match="topologically"):
+        e.render_cppn(gb, img)
+    d = torch.zeros(2, dtype=torch.float64, device=cuda)
+    with pytest.raises(EngineError, match="structure"):
+        e.score(9, torch.zeros((2, e.K, 4), device=cuda), torch.zeros(2, dtype=torch.int32, device=cuda), 2, d)
