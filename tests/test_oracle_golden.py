@@ -91,3 +91,46 @@ def test_orchestration_matches_get_fitnesses_neat():
         assert run["sequence_len"] == 20 * len(run["fitness"])
         assert run["lk_files"][0] == ["0000000019.png", "0000000020_extended.png"]
         assert run["lk_files"][1] == ["0000000039.png", "0000000040_extended.png"]
+
+
+def test_corner_detector_against_the_references_published_flow_overlays(oracle_lib):
+    """EVIDENCE, not exact parity: the reference's screenshots illusions_rating/EIGEN-images/*/vectors.png show the tracked
+    goodFeaturesToTrack corners as yellow radius-2 dots.  They were computed on the PredNet prediction of the stimulus, the
+    fixture holds the stimulus, so only part of the corners can coincide -- but those that do, coincide to the pixel, and
+    a sweep over 36 parameter combinations singles out blockSize 7 and qualityLevel 0.3 (the recalled OpenCV-tutorial values);
+    minDistance 7 and 10 explain the overlays equally well."""
+    import itertools
+    import oracle
+    z = np.load(os.path.join(GOLD, "flow_overlays.npz"))
+    names = sorted(k[:-4] for k in z.files if k.endswith("_img"))
+    disk = [(dy, dx) for dy in range(-2, 3) for dx in range(-2, 3) if dy * dy + dx * dx <= 4]
+    data = []
+    for n in names:
+        img = z[n + "_img"]
+        yellow = np.unpackbits(z[n + "_yellow"])[:120 * 160].reshape(120, 160).astype(bool)
+        data.append((oracle.gray(img), yellow))
+
+    def hits(params):
+        full = total = 0
+        for g, yellow in data:
+            pts = oracle.good_features(g, params).astype(int)
+            total += len(pts)
+            for x, y in pts:
+                full += all(0 <= y + dy < 120 and 0 <= x + dx < 160 and yellow[y + dy, x + dx] for dy, dx in disk)
+        return full, total
+
+    n_dots = sum(int(y.sum()) for _, y in data) / 13.0            # a radius-2 disk has 13 pixels (merged dots undercount)
+    full, total = hits(oracle.LKParams())
+    assert 250 <= total <= 330 and full / total > 0.40           # 133 of 289 corners are exact dot centres
+
+    def f1(f, t):
+        p, r = f / max(t, 1), f / n_dots
+        return 2 * p * r / max(p + r, 1e-9)
+
+    score = {}
+    for q, md, bs in itertools.product([0.1, 0.3, 0.5], [5, 7, 10], [3, 5, 7, 9]):
+        score[(q, md, bs)] = f1(*hits(oracle.LKParams(quality_level=q, min_distance=md, block_size=bs)))
+    ranked = sorted(score, key=score.get, reverse=True)
+    assert all(k[2] == 7 for k in ranked[:5]), ranked[:5]        # blockSize 7 is unambiguous
+    assert ranked[0][0] == 0.3                                   # so is qualityLevel 0.3
+    assert score[(0.3, 7, 7)] >= 0.95 * score[ranked[0]]         # minDistance 7 vs 10 cannot be told apart from overlays
