@@ -65,9 +65,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pop", type=int, default=POP_PER_GPU, help="genomes per GPU")
-    ap.add_argument("--shape", default="headline", choices=["headline", "ref160"],
+    ap.add_argument("--shape", default="headline", choices=["headline", "ref160", "c5"],
                     help="headline: 256x256 colour pop 256 (BASELINE.json metric); ref160: the reference's own default "
-                         "160x120 colour, pop 50 (the only published datum: 0.80 evals/s on a Colab GPU, BASELINE.md)")
+                         "160x120 colour, pop 50 (the only published datum: 0.80 evals/s on a Colab GPU, BASELINE.md); "
+                         "c5: BASELINE.json configs[4] per-GPU share, 512x512 colour Free structure, pop 128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -77,6 +78,12 @@ def main():
         if args.pop == POP_PER_GPU:
             args.pop = 50
         args.no_cpu_baseline = True  # supplementary number: no CPU leg, no PMC traffic
+    global STRUCTURE
+    if args.shape == "c5":
+        W, H, STRUCTURE = 512, 512, 2
+        if args.pop == POP_PER_GPU:
+            args.pop = 128
+        args.no_cpu_baseline = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
