@@ -335,3 +335,45 @@ def test_default_config_four_inputs_six_outputs(cuda, oracle_lib):
         img = cppn.render(grid, g, cfg, 1, w, h, extra_leaves=extra)[None]
         ref = pipeline.image_fitness(np.ascontiguousarray(img), wts, ch, w, h, structure)
         assert g.fitness == pytest.approx(ref, rel=1e-9, abs=1e-12)
+
+
+def test_flow_rare_branches_bit_exact(cuda, oracle_lib):
+    """Lucas-Kanade paths that smooth sub-pixel pairs never take: multi-pixel motion (iteration cap, lost tracks),
+    noise (oscillation damping branch), corners hugging the border (window reads through the REFLECT_101 / zero
+    borders), a level that the pyramid refuses to build (small image)."""
+    import torch
+    rng = np.random.default_rng(77)
+    lost_total = 0
+    for (w, h, c, B) in [(96, 72, 1, 24), (40, 36, 3, 8), (160, 120, 3, 8)]:
+        i0 = np.zeros((B, c, h, w), np.uint8)
+        i1 = np.zeros((B, c, h, w), np.uint8)
+        for b in range(B):
+            base = rng.integers(0, 256, (c, h // 4 + 12, w // 4 + 12)).astype(np.float64)
+            big = np.kron(base, np.ones((1, 4, 4)))[:, :h + 40, :w + 40]                    # blocky texture: strong corners
+            big = (big + np.roll(big, 1, 1) + np.roll(big, 1, 2)) / 3.0
+            sy, sx = rng.integers(0, 6, 2) if b % 4 else rng.integers(0, 3, 2) * 13                # 0..5 px, sometimes 13/26 px
+            a = big[:, 30:30 + h, 30:30 + w]
+            bimg = big[:, 30 - sy:30 - sy + h, 30 - sx:30 - sx + w]
+            noise = rng.normal(0, [0, 3, 12][b % 3], a.shape)
+            i0[b] = np.clip(a, 0, 255)
+            i1[b] = np.clip(bimg + noise, 0, 255)
+        e = _eng(w if w % 2 == 0 else w + 1, h if h % 2 == 0 else h + 1, [c, 4], B)
+        d0, d1 = torch.from_numpy(i0).to(cuda), torch.from_numpy(i1).to(cuda)
+        dv = torch.zeros((B, e.K, 4), dtype=torch.float32, device=cuda)
+        dc = torch.zeros(B, dtype=torch.int32, device=cuda)
+        e.flow(d0, c * h * w, d1, c * h * w, B, dv, dc)
+        torch.cuda.synchronize()
+        corners, ncorn, nxt, st = e.debug_corners(B)
+        lost = 0
+        for b in range(B):
+            g0, g1 = oracle_lib.gray(i0[b]), oracle_lib.gray(i1[b])
+            pts = oracle_lib.good_features(g0)
+            assert ncorn[b] == len(pts) and np.array_equal(corners[b, :len(pts)], pts)
+            rn, rs = oracle_lib.pyr_lk(g0, g1, pts)
+            assert np.array_equal(st[b, :len(pts)], rs)
+            assert np.array_equal(nxt[b, :len(pts)][rs == 1], rn[rs == 1])
+            lost += int((rs == 0).sum())
+            ref = oracle_lib.lucas_kanade(i0[b], i1[b])
+            assert int(dc[b]) == len(ref) and np.array_equal(dv[b, :len(ref)].cpu().numpy(), ref)
+        lost_total += lost
+    assert lost_total > 0, "no track was ever lost: the status==0 paths were not exercised"
