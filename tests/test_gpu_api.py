@@ -162,3 +162,19 @@ def test_abi_error_conventions(cuda):
     d = torch.zeros(2, dtype=torch.float64, device=cuda)
     with pytest.raises(EngineError, match="structure"):
         e.score(9, torch.zeros((2, e.K, 4), device=cuda), torch.zeros(2, dtype=torch.int32, device=cuda), 2, d)
+
+
+def test_fast_path_reproduces_the_fitness_assigned_by_the_references_glue(cuda):
+    """The fixture was produced by /root/reference's unmodified get_fitnesses_neat (PNG files, frame index arithmetic,
+    scoring) with its absent dependencies backed by the CPU oracle (tests/golden/make_golden.py --e2e).  The HIP path
+    -- one batched device pass, no files -- must assign the same fitness to the same genomes."""
+    import json
+    from test_oracle_golden import GOLD, _genomes_from_fixture
+    runs = json.load(open(os.path.join(GOLD, "e2e_reference_glue.json")))["runs"]
+    for run in runs:
+        cfg, pop = _genomes_from_fixture(run)
+        w, h, ch, st = run["w"], run["h"], run["channels"], run["structure"]
+        wts = weights.synthetic_prednet_weights(ch, w, h, seed=run["weights_seed"])
+        fitness.get_fitnesses_neat(st, pop, wts, cfg, w, h, ch, c_dim=run["c_dim"], best_dir=None, gradient=1)
+        got = np.array([g.fitness for _, g in pop])
+        assert np.allclose(got, run["fitness"], rtol=1e-9, atol=1e-12), (st, got, run["fitness"])
