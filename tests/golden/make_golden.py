@@ -48,7 +48,7 @@ def install_stubs(state):
         state.setdefault("lk_calls", []).append((f0, f1, save_name))
         i = len(state["lk_calls"]) - 1
         if save_name:  # the reference later copies this file (generate_illusion.py:655-657)
-            os.makedirs(os.path.dirname(save_name), exist_ok=True)
+            os.makedirs(os.path.dirname(save_name) or ".", exist_ok=True)
             open(save_name, "wb").close()
         v = state["lk_vectors"][i]
         return {"vectors": [list(map(float, r)) for r in v]}
@@ -267,7 +267,7 @@ def make_e2e():
         c = holder["c_dim"]
         v = oracle.lucas_kanade(read_chw(f0, c), read_chw(f1, c))
         if save_name:
-            os.makedirs(os.path.dirname(save_name), exist_ok=True)
+            os.makedirs(os.path.dirname(save_name) or ".", exist_ok=True)
             open(save_name, "wb").close()
         return {"vectors": [[float(x) for x in row] for row in v]}
 
@@ -298,8 +298,35 @@ def make_e2e():
                                   "connections": [[list(c.key), c.weight, c.enabled] for c in g.connections.values()]} for _, g in pop],
                      "fitness": [float(g.fitness) for _, g in pop]})
         print("e2e", structure, [round(g.fitness, 6) for _, g in pop])
+    # single-image API: fitness_calculator.get_vectors (original -> 2nd extended frame) + calculate_fitness, unmodified
+    import fitness_calculator as fcm
+    fcm.test_prednet = test_prednet
+    fcm.lucas_kanade = lucas_kanade
+    single = []
+    for structure, c_dim, w, h, channels, seed in [(2, 3, 96, 64, [3, 6, 8], 5), (1, 1, 160, 120, [1, 4, 8], 6)]:
+        cfg = synth.make_config(2, 3 if c_dim == 3 else 1)
+        g = synth.make_population(1, cfg, seed=seed)[0][1]
+        from oracle import grids as ogrids
+        grid = ogrids.create_grid(structure, w, h, 10)
+        img = ocppn.render(grid, g, cfg, c_dim, w, h)
+        holder["weights"] = weights.synthetic_prednet_weights(channels, w, h, seed=seed)
+        holder["c_dim"] = c_dim
+        with _tempfile.TemporaryDirectory() as td:
+            os.chdir(td)
+            try:
+                Image.fromarray(img).save("stim.png")
+                v = fcm.get_vectors("stim.png", "model.npz", channels, w, h)
+                try:
+                    fit = float(fcm.calculate_fitness(fcm.StructureType(structure), v, "stim.png", w, h))
+                except UnboundLocalError:
+                    fit = "UnboundLocalError"
+            finally:
+                os.chdir(cwd)
+        single.append({"structure": structure, "c_dim": c_dim, "w": w, "h": h, "channels": channels, "weights_seed": seed,
+                       "image": img.tolist(), "vectors": np.asarray(v, dtype=np.float64).tolist() if v[0] is not None else None, "fitness": fit})
+        print("single", structure, len(v), fit)
     with open(os.path.join(OUT, "e2e_reference_glue.json"), "w") as f:
-        _json.dump({"runs": runs}, f)
+        _json.dump({"runs": runs, "single": single}, f)
 
 
 if __name__ == "__main__" and "--e2e" in sys.argv:

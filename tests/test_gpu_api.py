@@ -178,3 +178,19 @@ def test_fast_path_reproduces_the_fitness_assigned_by_the_references_glue(cuda):
         fitness.get_fitnesses_neat(st, pop, wts, cfg, w, h, ch, c_dim=run["c_dim"], best_dir=None, gradient=1)
         got = np.array([g.fitness for _, g in pop])
         assert np.allclose(got, run["fitness"], rtol=1e-9, atol=1e-12), (st, got, run["fitness"])
+
+
+def test_single_image_api_reproduces_the_references_glue(cuda):
+    """fitness_calculator.get_vectors + calculate_fitness of the reference, run unmodified over oracle-backed
+    dependencies (fixture 'single'), against the drop-in single-image API on the device."""
+    import json
+    from test_oracle_golden import GOLD
+    for case in json.load(open(os.path.join(GOLD, "e2e_reference_glue.json")))["single"]:
+        img = np.asarray(case["image"], dtype=np.uint8)
+        w, h, ch = case["w"], case["h"], case["channels"]
+        wts = weights.synthetic_prednet_weights(ch, w, h, seed=case["weights_seed"])
+        v = fitness.get_vectors(img, wts, ch, w, h)
+        assert np.array_equal(np.asarray(v, dtype=np.float64), np.asarray(case["vectors"]))
+        if case["fitness"] != "UnboundLocalError":
+            got = fitness.calculate_fitness(case["structure"], v, None, w, h)
+            assert abs(got - case["fitness"]) <= 1e-9 * abs(case["fitness"])

@@ -169,3 +169,18 @@ def test_end_to_end_fitness_assigned_by_the_references_own_glue_code(oracle_lib)
         assert got == run["fitness"], (st, got, run["fitness"])
         nonzero += sum(f != 0 for f in got)
     assert nonzero >= 4
+
+
+def test_single_image_api_of_the_reference_glue(oracle_lib):
+    """fitness_calculator.get_vectors / calculate_fitness run unmodified (oracle-backed dependencies): Lucas-Kanade
+    compares the ORIGINAL image with the SECOND extended frame (file '%010d_extended.png' % 21, fitness_calculator.py:493)."""
+    from evolutionary_illusion_generator_amd import weights
+    from oracle import pipeline, scores
+    for case in json.load(open(os.path.join(GOLD, "e2e_reference_glue.json")))["single"]:
+        img = np.asarray(case["image"], dtype=np.uint8)
+        chw = np.ascontiguousarray(img.transpose(2, 0, 1) if img.ndim == 3 else img[None])
+        wts = weights.synthetic_prednet_weights(case["channels"], case["w"], case["h"], seed=case["weights_seed"])
+        v = pipeline.image_vectors(chw, wts, case["channels"], case["w"], case["h"], pairing=pipeline.PAIR_SINGLE)
+        assert np.array_equal(v.astype(np.float64), np.asarray(case["vectors"]))
+        if case["fitness"] != "UnboundLocalError":
+            assert scores.fitness_from_vectors(case["structure"], v.astype(np.float64), case["w"], case["h"]) == case["fitness"]
