@@ -35,9 +35,11 @@ struct CppnArgs {
     int c_out;                // outputs evaluated per genome
     int c_dim;                // channels written per genome
     int bg;                   // 0 / 1
-    int mode;                 // 0: gradient colour/gray; 1: gray rounded (gradient==0, c_dim==1); 2: 5-colour palette
+    int mode;                 // 0: gradient colour/gray; 1: gray rounded (gradient==0, c_dim==1); 2: 5-colour palette;
+                              // 3: raw float64 node values to out_f64 (the create_cppn node call itself)
     int max_nodes;            // LDS column count
     uint8_t* out;             // [G][c_dim][N]
+    double* out_f64;          // mode 3: [G][c_out][N]
 };
 
 // np.array(float64, dtype=np.uint8) on x86-64: truncate toward zero to int32, keep the low byte;
@@ -116,6 +118,11 @@ __global__ void __launch_bounds__(CPPN_THREADS) cppn_render_kernel(const CppnArg
         vals[(size_t)n * CPPN_THREADS + tid] = cppn_act(s_act[n], pre + s_bias[n]);
     }
 
+    if (a.mode == 3) {  // node_func(x=inp_x, y=inp_y) of generate_illusion.py:395,406,443: the float64 plane itself
+        for (int c = 0; c < a.c_out; ++c)
+            a.out_f64[((size_t)g * a.c_out + c) * a.N + p] = vals[(size_t)a.out_node[g * a.c_out + c] * CPPN_THREADS + tid];
+        return;
+    }
     uint8_t* out = a.out + (size_t)g * a.c_dim * a.N + p;
     if (a.mode == 2) {  // colour, gradient == 0: palette from node 0 (generate_illusion.py:405-431)
         const double v = vals[(size_t)a.out_node[g * a.c_out] * CPPN_THREADS + tid];

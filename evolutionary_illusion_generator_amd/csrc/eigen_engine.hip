@@ -469,15 +469,13 @@ int eigen_set_grid(eigen_engine* e, const double* h_planes, int32_t n_planes)
     return EIGEN_OK;
 }
 
-int eigen_render_cppn(eigen_engine* e, const eigen_genome_batch* g, int32_t bg, int32_t gradient, uint8_t* d_images, void* stream)
+static int render_cppn_impl(eigen_engine* e, const eigen_genome_batch* g, int32_t bg, int mode, uint8_t* d_images, double* d_nodes, void* stream)
 {
-    if (!e || !g || !d_images) return fail(EIGEN_ERR_INVALID, "null argument");
     if (!e->have_grid) return fail(EIGEN_ERR_STATE, "eigen_set_grid has not been called");
     HIPCHK(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     const int G = g->n_genomes;
     if (G < 1) return fail(EIGEN_ERR_INVALID, "n_genomes < 1");
-    const int mode = (gradient == 1) ? 0 : (e->C0 == 1 ? 1 : 2);
     const int need_out = (mode == 0) ? e->C0 : 1;
     if (g->c_out < need_out) return fail(EIGEN_ERR_INVALID, "genome batch provides %d outputs per genome, %d needed", g->c_out, need_out);
     const int total_nodes = g->node_off[G];
@@ -525,11 +523,23 @@ int eigen_render_cppn(eigen_engine* e, const eigen_genome_batch* g, int32_t bg, 
     a.node_off = e->g_node_off.p; a.edge_off = e->g_edge_off.p; a.node_act = e->g_node_act.p;
     a.node_bias = e->g_node_bias.p; a.node_resp = e->g_node_resp.p; a.edge_src = e->g_edge_src.p; a.edge_w = e->g_edge_w.p;
     a.out_node = e->g_out_node.p; a.planes = e->d_planes; a.n_planes = e->n_planes; a.N = e->H * e->W;
-    a.c_out = g->c_out; a.c_dim = e->C0; a.bg = bg; a.mode = mode; a.max_nodes = max_nodes; a.out = d_images;
+    a.c_out = g->c_out; a.c_dim = e->C0; a.bg = bg; a.mode = mode; a.max_nodes = max_nodes; a.out = d_images; a.out_f64 = d_nodes;
     (void)hipFuncSetAttribute((const void*)cppn_render_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(cppn_render_kernel, dim3((a.N + CPPN_THREADS - 1) / CPPN_THREADS, G), dim3(CPPN_THREADS), lds, st, a);
     HIPCHK(hipGetLastError());
     return EIGEN_OK;
+}
+
+int eigen_render_cppn(eigen_engine* e, const eigen_genome_batch* g, int32_t bg, int32_t gradient, uint8_t* d_images, void* stream)
+{
+    if (!e || !g || !d_images) return fail(EIGEN_ERR_INVALID, "null argument");
+    return render_cppn_impl(e, g, bg, (gradient == 1) ? 0 : (e->C0 == 1 ? 1 : 2), d_images, nullptr, stream);
+}
+
+int eigen_eval_cppn_nodes(eigen_engine* e, const eigen_genome_batch* g, double* d_nodes, void* stream)
+{
+    if (!e || !g || !d_nodes) return fail(EIGEN_ERR_INVALID, "null argument");
+    return render_cppn_impl(e, g, 1, 3, nullptr, d_nodes, stream);
 }
 
 int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batch, int32_t n_steps, int32_t first_out_step,
@@ -578,7 +588,8 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
                 a.bias = y.bias_lstm; a.c_state = y.c; a.h_out = y.h[cur ^ 1]; a.peep = y.peep;
                 HIPCHK(launch_conv(e, y.lstm, a, batch, st));
             }
-            {
+            // P_l (l > 0) is only read by ConvA_l of the NEXT step: nothing reads it after the last one
+            if (l == 0 || t + 1 < n_steps) {
                 ConvArgs a;
                 memset(&a, 0, sizeof(a));
                 a.src[0].ptr = y.h[cur ^ 1];

@@ -16,7 +16,7 @@ MAX_LAYERS = 8
 PAIR_POPULATION, PAIR_SINGLE = 0, 1
 
 EXPORTS = ["eigen_abi_version", "eigen_last_error", "eigen_config_defaults", "eigen_create", "eigen_destroy",
-           "eigen_set_prednet_weights", "eigen_set_grid", "eigen_render_cppn", "eigen_prednet_rollout", "eigen_flow",
+           "eigen_set_prednet_weights", "eigen_set_grid", "eigen_render_cppn", "eigen_eval_cppn_nodes", "eigen_prednet_rollout", "eigen_flow",
            "eigen_score", "eigen_eval_population", "eigen_eval_images", "eigen_test_conv", "eigen_time_conv", "eigen_test_det_math",
            "eigen_get_timings", "eigen_conv_profile", "eigen_debug_corners", "eigen_prednet_flops_per_step"]
 
@@ -155,6 +155,11 @@ class Engine:
     def render_cppn(self, gb, d_images, bg=1, gradient=1, stream=None):
         s = self._genome_struct(gb)
         _check(self.lib.eigen_render_cppn(self._h, ctypes.byref(s), ctypes.c_int32(bg), ctypes.c_int32(gradient), _ptr(d_images), _stream_arg(stream)))
+
+    def eval_cppn_nodes(self, gb, d_nodes, stream=None):
+        """float64 [n, c_out, H*W] raw output-node values (create_cppn node calls, generate_illusion.py:395)."""
+        s = self._genome_struct(gb)
+        _check(self.lib.eigen_eval_cppn_nodes(self._h, ctypes.byref(s), _ptr(d_nodes), _stream_arg(stream)))
 
     def prednet_rollout(self, d_images, batch, n_steps, first_out_step, d_frames, stream=None):
         _check(self.lib.eigen_prednet_rollout(self._h, _ptr(d_images), ctypes.c_int32(batch), ctypes.c_int32(n_steps),

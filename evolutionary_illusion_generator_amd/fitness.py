@@ -304,3 +304,68 @@ def _score_engine(w, h, n):
         eng = Engine(32, 32, [1, 1], 1, device=_local_device(), max_corners=128)  # scorer only: tiny workspaces
         _engines[key] = eng
     return eng
+
+
+# ------------------------------------------------------------------- stage-level entry points (import shims)
+def _aux_engine(kind, w, h, c_dim):
+    """Render-/flow-only engine: one PredNet layer keeps the workspaces tiny; no weights are ever set."""
+    key = (kind, _local_device(), w, h, c_dim)
+    eng = _engines.get(key)
+    if eng is None:
+        eng = Engine(w, h, [c_dim], 1, device=_local_device())
+        eng._grid_key = None
+        _engines[key] = eng
+    return eng
+
+
+def cppn_node_planes(genome, config, planes, n_outputs=None):
+    """Raw float64 output-node values of one genome over arbitrary input planes: what the node objects returned by
+    PyTorch-NEAT's create_cppn compute when called as ``node(x=inp_x, y=inp_y)`` (generate_illusion.py:395,406,443).
+    planes: list of equal-length float64 arrays (x, y[, r, bias]).  Returns float64 [n_outputs, N]."""
+    import torch
+    planes = [np.ascontiguousarray(np.asarray(p, dtype=np.float64).reshape(-1)) for p in planes]
+    n = planes[0].size
+    n_out = int(n_outputs or len(config.genome_config.output_keys))
+    eng = _aux_engine("nodes", n, 1, 1)
+    eng.set_grid(planes)
+    gb = GenomeBatch([genome], config, n_out, n_leaves=len(planes))
+    d = torch.empty((1, n_out, n), dtype=torch.float64, device="cuda")
+    eng.eval_cppn_nodes(gb, d)
+    torch.cuda.synchronize()
+    return d.cpu().numpy()[0]
+
+
+def prednet_predictions(images, model_name, channels, w, h, n_repeat=20, n_ext=2):
+    """Quantised prediction frames of test_prednet for a batch of constant-image sequences: uint8
+    [n, n_repeat + n_ext, C, H, W] (frame t = prediction after t+1 steps; the last n_ext are the self-fed ones)."""
+    import torch
+    channels = [int(c) for c in channels]
+    images = np.ascontiguousarray(images, dtype=np.uint8)
+    n_steps = n_repeat + n_ext
+    eng = get_engine(model_name, w, h, channels, n_repeat=n_repeat, n_ext=n_ext)
+    out = np.empty((len(images), n_steps) + images.shape[1:], dtype=np.uint8)
+    for i in range(0, len(images), eng.max_batch):
+        chunk = images[i:i + eng.max_batch]
+        d = torch.from_numpy(chunk).cuda()
+        fr = torch.empty((len(chunk), n_steps) + chunk.shape[1:], dtype=torch.uint8, device="cuda")
+        eng.prednet_rollout(d, len(chunk), n_steps, 0, fr)
+        torch.cuda.synchronize()
+        out[i:i + len(chunk)] = fr.cpu().numpy()
+    return out
+
+
+def flow_vectors(img0, img1):
+    """Lucas-Kanade vectors [x, y, dx, dy] (float32 [n, 4]) between two uint8 CHW images of equal size
+    (Optical_Flow_Analyzer lucas_kanade; generate_illusion.py:549-550, fitness_calculator.py:498)."""
+    import torch
+    a, b = np.ascontiguousarray(img0, dtype=np.uint8), np.ascontiguousarray(img1, dtype=np.uint8)
+    if a.shape != b.shape or a.ndim != 3:
+        raise ValueError("flow_vectors needs two CHW uint8 images of the same shape, got %s and %s" % (a.shape, b.shape))
+    c, h, w = a.shape
+    eng = _aux_engine("flow", w, h, c)
+    d0, d1 = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    vec = torch.zeros((1, eng.K, 4), dtype=torch.float32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    eng.flow(d0, a.size, d1, b.size, 1, vec, cnt)
+    torch.cuda.synchronize()
+    return vec.cpu().numpy()[0, :int(cnt.cpu().numpy()[0])]

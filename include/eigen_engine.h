@@ -125,6 +125,12 @@ int eigen_set_grid(eigen_engine* e, const double* h_planes, int32_t n_planes);
 int eigen_render_cppn(eigen_engine* e, const eigen_genome_batch* h_genomes, int32_t bg, int32_t gradient,
                       uint8_t* d_images, void* stream);
 
+/* Replaces the node calls `node_func(x=inp_x, y=inp_y)` on the objects create_cppn returns (PyTorch-NEAT
+ * Node.__call__; generate_illusion.py:395, 406, 443) for a batch: the raw float64 value of every output node
+ * at every pixel of the planes given to eigen_set_grid, no background fill and no quantisation.
+ * d_nodes: float64 [n_genomes][c_out][H*W].  Used by the import shim pytorch_neat.pytorch_neat.cppn. */
+int eigen_eval_cppn_nodes(eigen_engine* e, const eigen_genome_batch* h_genomes, double* d_nodes, void* stream);
+
 /* Replaces test_prednet (generate_illusion.py:533-537, fitness_calculator.py:487-491) for a batch: state
  * reset, n_repeat steps on the constant frame, then extension steps feeding the prediction back; runs
  * n_steps <= n_repeat + n_ext steps in total.  The quantised prediction of every step t >= first_out_step
