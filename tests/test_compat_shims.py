@@ -194,3 +194,75 @@ def test_test_prednet_shim_rejects_what_it_cannot_honour(cuda, shims, tmp_path):
     test_prednet(sequence_list=[[a, a, b, b]], reset_at=3, **kw)
     assert sorted(os.listdir(tmp_path / "o")) == ["0000000000.png", "0000000001.png", "0000000002.png", "0000000002_extended.png",
                                                   "0000000003.png", "0000000004_extended.png"]
+
+
+# ------------------------------------------------------------ the unedited reference driver on the shims (CPU, build container)
+def _oracle_stage_doubles(monkeypatch, wts_holder):
+    """TEST-ONLY: the three stage-level device calls the shims funnel into, answered by the CPU oracle, so that the
+    reference's unedited Python (and the shims' file handling) can be executed where there is no GPU."""
+    import oracle
+    from evolutionary_illusion_generator_amd import fitness
+    from oracle import cppn as ocppn
+
+    def cppn_node_planes(genome, config, planes, n_outputs=None):
+        out = ocppn.render_planes(genome, config, [np.asarray(p, dtype=np.float64).reshape(-1) for p in planes])
+        return np.stack([np.asarray(o, dtype=np.float64) for o in out])
+
+    def prednet_predictions(images, model_name, channels, w, h, n_repeat=20, n_ext=2):
+        wts = wts_holder["weights"]
+        return np.stack([oracle.prednet_rollout(wts, channels, w, h, im, n_repeat=n_repeat, n_ext=n_ext) for im in images])
+
+    monkeypatch.setattr(fitness, "cppn_node_planes", cppn_node_planes)
+    monkeypatch.setattr(fitness, "prednet_predictions", prednet_predictions)
+    monkeypatch.setattr(fitness, "flow_vectors", lambda a, b: oracle.lucas_kanade(a, b))
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "generate_illusion.py")), reason="reference checkout only exists in the build container")
+def test_unedited_reference_get_fitnesses_neat_on_the_shims_assigns_the_fixture_fitness(shims, oracle_lib, monkeypatch, tmp_path):
+    """generate_illusion.get_fitnesses_neat, unedited, importing the shims as its submodules.  With the device calls
+    answered by the oracle (no GPU here) the shims' file handling + the reference's glue must assign the same fitness
+    as the fixture (made with throw-away fakes instead of the shims) -- and as the HIP fast path does on the GPU
+    (tests/test_gpu_api.py)."""
+    sys.path.append(REF)
+    import generate_illusion as gi
+    holder = {}
+    _oracle_stage_doubles(monkeypatch, holder)
+    run, cfg, pop = _fixture_run(0)
+    w, h, ch = run["w"], run["h"], run["channels"]
+    holder["weights"] = weights.synthetic_prednet_weights(ch, w, h, seed=run["weights_seed"])
+    monkeypatch.chdir(tmp_path)
+    os.makedirs(tmp_path / "best")  # neat_illusion creates best_dir before the first generation (generate_illusion.py:683-685)
+    gi.get_fitnesses_neat(gi.StructureType(run["structure"]), pop, "model.npz", cfg, w, h, ch, c_dim=run["c_dim"],
+                          best_dir=str(tmp_path / "best"), gradient=1)
+    assert [g.fitness for _, g in pop] == run["fitness"]
+    for name in ("best.png", "best_flow.png", "best_black_bg.png"):
+        assert (tmp_path / "best" / name).exists()
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "generate_illusion.py")), reason="reference checkout only exists in the build container")
+def test_unedited_neat_illusion_driver_evolves_on_the_shims(shims, oracle_lib, monkeypatch, tmp_path):
+    """The whole unedited driver: neat.Config on the reference's own neat_configs/circles_bw.txt, neat.Population,
+    reporters, checkpointer (`neat` = neat_lite stand-in), eval_genomes -> get_fitnesses_neat for two generations."""
+    sys.path.append(REF)
+    import generate_illusion as gi
+    holder = {"weights": weights.synthetic_prednet_weights([1, 4, 8], 64, 48, seed=3)}
+    _oracle_stage_doubles(monkeypatch, holder)
+    calls = []
+    inner = gi.get_fitnesses_neat
+
+    class _Stop(Exception):
+        pass
+
+    def counted(structure, genomes, *a, **kw):
+        inner(structure, genomes, *a, **kw)
+        calls.append([g.fitness for _, g in genomes])
+        if len(calls) == 2:
+            raise _Stop()
+
+    monkeypatch.setattr(gi, "get_fitnesses_neat", counted)
+    monkeypatch.chdir(tmp_path)
+    with pytest.raises(_Stop):
+        gi.neat_illusion(str(tmp_path / "out"), "model.npz", os.path.join(REF, "neat_configs", "circles_bw.txt"),
+                         gi.StructureType.Free, 64, 48, [1, 4, 8], c_dim=1, gradient=1)
+    assert len(calls) == 2 and all(len(c) >= 5 and all(isinstance(f, float) for f in c) for c in calls)  # generation 1 is refilled to min_species_size
+    assert (tmp_path / "out" / "enhanced.png").exists()
