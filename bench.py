@@ -65,10 +65,12 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--pop", type=int, default=POP_PER_GPU, help="genomes per GPU")
-    ap.add_argument("--shape", default="headline", choices=["headline", "ref160", "c5"],
-                    help="headline: 256x256 colour pop 256 (BASELINE.json metric); ref160: the reference's own default "
+    ap.add_argument("--shape", default="headline", choices=["headline", "ref160", "c2", "c4", "c5"],
+                    help="headline: 256x256 colour pop 256 (BASELINE.json metric, configs[2]); ref160: the reference's own default "
                          "160x120 colour, pop 50 (the only published datum: 0.80 evals/s on a Colab GPU, BASELINE.md); "
-                         "c5: BASELINE.json configs[4] per-GPU share, 512x512 colour Free structure, pop 128")
+                         "c2: configs[1] circles_bw 160x120 gray (channels 1,16,32,64) pop 50; c4: configs[3] per-GPU share, "
+                         "bands.txt (8 hidden, 6 outputs) 256x256 colour Bands pop 64; "
+                         "c5: configs[4] per-GPU share, 512x512 colour Free structure, pop 128")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -78,7 +80,18 @@ def main():
         if args.pop == POP_PER_GPU:
             args.pop = 50
         args.no_cpu_baseline = True  # supplementary number: no CPU leg, no PMC traffic
-    global STRUCTURE
+    global STRUCTURE, CHANNELS, C_DIM
+    n_hidden, n_outputs = 20, 3
+    if args.shape == "c2":
+        W, H, CHANNELS, C_DIM, n_outputs = 160, 120, [1, 16, 32, 64], 1, 1
+        if args.pop == POP_PER_GPU:
+            args.pop = 50
+        args.no_cpu_baseline = True
+    if args.shape == "c4":
+        STRUCTURE, n_hidden, n_outputs = 0, 8, 6
+        if args.pop == POP_PER_GPU:
+            args.pop = 64
+        args.no_cpu_baseline = True
     if args.shape == "c5":
         W, H, STRUCTURE = 512, 512, 2
         if args.pop == POP_PER_GPU:
@@ -97,9 +110,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from evolutionary_illusion_generator_amd import fitness, grids, synth, weights
-    cfg = synth.make_config(2, 3)
+    cfg = synth.make_config(2, n_outputs)
     global_pop = args.pop * world
-    population = synth.make_population(global_pop, cfg, seed=0)  # identical on every rank (seeded)
+    population = synth.make_population(global_pop, cfg, seed=0, num_hidden=n_hidden)  # identical on every rank (seeded)
     genomes = [g for _, g in population]
     wts = weights.synthetic_prednet_weights(CHANNELS, W, H, seed=0)
     eng = fitness.get_engine(wts, W, H, CHANNELS, max_batch=args.pop)
@@ -137,8 +150,11 @@ def main():
         "ms_per_step": 1000.0 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "neat_configs/circles.txt colour pop=%d/GPU, %dx%d, PredNet 3,48,96,192, 21 steps, LK + rotation-symmetry score" % (args.pop, W, H),
-                   "global_pop": global_pop, "image": [W, H], "channels": CHANNELS, "structure": "Circles",
+        "config": {"workload": "%s pop=%d/GPU, %dx%d, PredNet %s, 21 steps, LK + %s score" % (
+                       {"headline": "neat_configs/circles.txt colour", "ref160": "neat_configs/circles.txt colour", "c2": "neat_configs/circles_bw.txt gray",
+                        "c4": "neat_configs/bands.txt colour (first 3 of 6 outputs)", "c5": "neat_configs/free.txt colour"}[args.shape], args.pop, W, H,
+                       ",".join(map(str, CHANNELS)), ["horizontal-symmetry", "rotation-symmetry", "swarm", "rotation-symmetry"][STRUCTURE]),
+                   "global_pop": global_pop, "image": [W, H], "channels": CHANNELS, "structure": ["Bands", "Circles", "Free", "CirclesFree"][STRUCTURE],
                    "parallelism": "pop-shard x%d + all-gather(fitness f64)" % world},
         "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items() if k.endswith("_ms") and k != "conv_ms"},
         "nonzero_fitness": int((fit != 0).sum()),
