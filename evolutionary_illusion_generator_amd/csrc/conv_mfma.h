@@ -161,6 +161,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     constexpr int TH = G::TH, NIMG = G::NIMG, S = G::S, XO = G::XO, PH = G::PH, PLANE = G::PLANE;
     constexpr int SU = G::SU, PHU = G::PHU, PLANE_U = G::PLANE_U;
     constexpr int NB = NI * 16;
+    const unsigned long long t_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BUF = KC * PLANE + KC * 9 * NB;  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
 
@@ -411,14 +412,20 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
         __syncthreads();
         if (EIG_TIMING) { const unsigned long long tk3 = __builtin_readcyclecounter(); t_mfma += tk1 - tk0; t_wait += tk2 - tk1; t_bar += tk3 - tk2; }
     }
-    if (EIG_TIMING && a.dbg && lane == 0) {
-        const unsigned long long t_all = __builtin_readcyclecounter() - t_all0;
-        unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wv) * 4;
-        d[0] = t_mfma; d[1] = t_wait; d[2] = t_bar; d[3] = t_all;
-    }
+    const unsigned long long t_loop1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
 
     // ---------------------------------------------------------------- epilogue
     const int HW = a.H * a.W;
+    auto timeline_record = [&](unsigned long long t_mid) {  // measurement builds only (EIG_TIMING): per-wave timeline
+        if (EIG_TIMING && a.dbg && lane == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wv) * 8;
+            d[0] = t_entry; d[1] = t_all0; d[2] = t_loop1; d[3] = __builtin_readcyclecounter();
+            d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32); d[5] = t_mfma; d[6] = t_mid; d[7] = t_bar;
+        }
+    };
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         int img, py0, px0;
@@ -499,6 +506,12 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
             }
         } else if (EPI == EPI_CONVA) {
             const int Ho = a.H >> 1, Wo = a.W >> 1;
+            float pv[NI];
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {  // all P loads of this sub-tile before the first E store (E and P might alias for the compiler)
+                const int ch = nblk * NB + ni * 16 + col;
+                pv[ni] = (ch < a.Cout) ? a.P[(((size_t)b * a.Cout + ch) * Ho + (gy0 >> 1)) * Wo + (gx0 >> 1)] : 0.0f;
+            }
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const int ch = nblk * NB + ni * 16 + col;
@@ -507,8 +520,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
                 const float v0 = relu_f(acc[mi][ni][0] + bb), v1 = relu_f(acc[mi][ni][1] + bb);
                 const float v2 = relu_f(acc[mi][ni][2] + bb), v3 = relu_f(acc[mi][ni][3] + bb);
                 const float A = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-                const size_t o = (((size_t)b * a.Cout + ch) * Ho + (gy0 >> 1)) * Wo + (gx0 >> 1);
-                const float p = a.P[o];
+                const float p = pv[ni];
                 const size_t e = (((size_t)b * 2 * a.Cout + ch) * Ho + (gy0 >> 1)) * Wo + (gx0 >> 1);
                 a.E[e] = relu_f(A - p);
                 a.E[e + (size_t)a.Cout * Ho * Wo] = relu_f(p - A);
@@ -542,6 +554,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
             }
         }
     }
+    timeline_record(0);
 }
 
 // E_0 for the first step: P_0 = 0  ->  E = [relu(x), relu(-x)] = [x, 0]

@@ -39,6 +39,7 @@ static int fail(int code, const char* fmt, ...)
 namespace {
 
 struct ConvOp {
+    int tl_seen = 0;  // EIG_TIMING builds: launches seen (timeline dump)
     int epi = 0, NI = 4, TW = 16, layer = 0;
     int nsrc = 0;
     int src_C[3] = {0, 0, 0}, src_up[3] = {0, 0, 0};
@@ -215,6 +216,14 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     // 16-byte DMA staging needs chunk-aligned rows: W % 4 == 0, and W % 8 == 0 when a half-resolution source is read
     bool vec = (op.W % 4) == 0;
     for (int s = 0; s < op.nsrc; ++s) if (op.src_up[s] && ((op.W % 8) != 0 || (op.H % 2) != 0)) vec = false;
+#if EIG_TIMING
+    unsigned long long* tl_dbg = nullptr;
+    if (getenv("EIGEN_TIMELINE") && op.epi == EPI_LSTM && ++op.tl_seen == 6) {  // a steady-state launch of every ConvLSTM op
+        (void)hipMalloc((void**)&tl_dbg, (size_t)grid * 32 * 8);
+        (void)hipMemset(tl_dbg, 0, (size_t)grid * 32 * 8);
+        a.dbg = tl_dbg;
+    }
+#endif
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
     switch (op.epi) {
@@ -224,6 +233,18 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st, vec); break;
         default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec); break;
     }
+#if EIG_TIMING
+    if (tl_dbg) {
+        (void)hipStreamSynchronize(st);
+        std::vector<unsigned long long> h((size_t)grid * 32);
+        (void)hipMemcpy(h.data(), tl_dbg, h.size() * 8, hipMemcpyDeviceToHost);
+        char name[256];
+        snprintf(name, sizeof(name), "%s/timeline_H%d_C%d.bin", getenv("EIGEN_TIMELINE"), op.H, op.Cout);
+        if (FILE* f = fopen(name, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+        (void)hipFree(tl_dbg);
+        a.dbg = nullptr;
+    }
+#endif
     if (e->profile_convs && r == hipSuccess) {
         (void)hipEventRecord(e->pev1, st);
         (void)hipEventSynchronize(e->pev1);
@@ -793,15 +814,15 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
         const int TH_ = (op.TW == 16) ? 16 : 8, NIMG_ = 256 / (TH_ * op.TW);
         const int grid_ = op.n_nblk * (((((batch + NIMG_ - 1) / NIMG_) * ((W + op.TW - 1) / op.TW) * ((H + TH_ - 1) / TH_)) + 7) / 8) * 8;
         unsigned long long* dbg = nullptr;
-        (void)hipMalloc((void**)&dbg, (size_t)grid_ * 16 * 8);
-        (void)hipMemset(dbg, 0, (size_t)grid_ * 16 * 8);
+        (void)hipMalloc((void**)&dbg, (size_t)grid_ * 32 * 8);
+        (void)hipMemset(dbg, 0, (size_t)grid_ * 32 * 8);
         a.dbg = dbg;
         (void)launch_conv(e, op, a, batch, (hipStream_t)stream);
         (void)hipStreamSynchronize((hipStream_t)stream);
-        std::vector<unsigned long long> h((size_t)grid_ * 16);
+        std::vector<unsigned long long> h((size_t)grid_ * 32);
         (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
         double s4[4] = {0, 0, 0, 0};
-        for (size_t i = 0; i < h.size(); ++i) s4[i & 3] += (double)h[i];
+        for (size_t i = 0; i < h.size(); i += 8) { s4[0] += (double)h[i + 5]; s4[1] += (double)h[i + 6]; s4[2] += (double)h[i + 7]; s4[3] += (double)(h[i + 2] - h[i + 1]); }
         const double n = (double)grid_ * 4;
         fprintf(stderr, "[EIG_TIMING] blocks=%d per-wave cycles: mfma+dma-issue %.0f  vmcnt-wait %.0f  barrier %.0f  loop-total %.0f\n", grid_, s4[0] / n, s4[1] / n, s4[2] / n, s4[3] / n);
         a.dbg = nullptr;
