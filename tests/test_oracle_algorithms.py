@@ -156,3 +156,28 @@ def test_flow_building_blocks_against_independent_scipy_math(oracle_lib):
     assert np.max(np.abs(got - lam)) <= 2e-6 * max(1.0, lam.max())
     # the box-filter border of the tensor is the tensor AT the mirrored pixel (not the tensor of a mirrored image):
     # uniform_filter(mode='mirror') on the product images is exactly that, so the agreement above covers the border.
+
+
+def test_fitness_is_insensitive_to_the_fp32_summation_order_within_the_north_star_tolerance(oracle_lib):
+    """BASELINE.json north_star: fitness within 1e-4 relative of the reference CPU path.  The reference's chainer convolutions
+    sum in an unspecified order; the canonical order of the oracle / HIP kernels is one choice.  An
+    independently ordered fp32 implementation (torch-CPU / oneDNN, oracle/prednet_torch.py) flips a few prediction bytes per
+    100 000 at quantisation boundaries; the fitness it leads to must stay within 1e-4 of the canonical one."""
+    from evolutionary_illusion_generator_amd import grids, synth, weights
+    from oracle import pipeline, scores
+    from oracle.prednet_torch import PredNetTorch
+    nonzero = 0
+    for st, c_dim, w, h, ch, n, seed in [(1, 3, 160, 120, [3, 12, 24, 48], 6, 1), (2, 1, 128, 96, [1, 8, 16, 32], 6, 2)]:
+        cfg = synth.make_config(2, 3 if c_dim == 3 else 1)
+        pop = synth.make_population(10, cfg, seed=seed)[10 - n:]
+        wts = weights.synthetic_prednet_weights(ch, w, h, seed=seed)
+        grid = grids.create_grid(st, w, h, 10)
+        net = PredNetTorch(wts, ch, w, h)
+        for _, g in pop:
+            img = pipeline.render_chw(g, cfg, grid, c_dim, w, h)
+            canonical = pipeline.image_fitness(img, wts, ch, w, h, st)
+            fr, _ = net.rollout(img[None], n_repeat=20, n_ext=1)
+            other = scores.fitness_from_vectors(st, oracle_lib.lucas_kanade(fr[0, 19], fr[0, 20]).astype(np.float64), w, h)
+            assert abs(canonical - other) <= 1e-4 * max(abs(canonical), abs(other)), (st, canonical, other)
+            nonzero += canonical != 0
+    assert nonzero >= 6
