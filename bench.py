@@ -208,6 +208,7 @@ def main():
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
+        dist.barrier()  # rank 0 is still in its (untimed) roofline pass: leave together
         dist.destroy_process_group()
 
 
