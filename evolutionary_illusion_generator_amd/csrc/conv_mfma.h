@@ -142,7 +142,10 @@ template <int TW, bool VEC> struct TileGeom {
     static constexpr int PLANE_U = NIMG * PHU * SU;
 };
 
-constexpr int KC = 8;  // channels per K-block
+#ifndef EIG_KC
+#define EIG_KC 8
+#endif
+constexpr int KC = EIG_KC;  // channels per K-block
 
 template <int NI, int TW, bool VEC> constexpr int conv_lds_bytes() { return 2 * (KC * TileGeom<TW, VEC>::PLANE + KC * 9 * NI * 16) * 4; }
 
