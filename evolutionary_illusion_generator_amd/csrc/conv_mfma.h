@@ -77,7 +77,7 @@ struct ConvArgs {
     uint8_t* frame;     // layer 0 only: quantised prediction out, or nullptr
     long long frame_bstride;
     int requant;
-    int _pad2;
+    int tile_map;       // block -> tile order, see the kernel
     // EPI_RAW
     float* raw;         // [B][Cout][H][W]
     const float* zeros; // >= 64 zero bytes in device memory: DMA source for out-of-image / padded-channel positions
@@ -183,7 +183,9 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     const int ntile = ngroups * tiles;
     const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
     const int nblk = xi % a.n_nblk;
-    const int tlin = (xi / a.n_nblk) * 8 + xcd;
+    // tile_map 1: every XCD owns a CONTIGUOUS range of tiles, so the tiles in flight on one XCD are spatial neighbours and
+    // their overlapping halos (1.7x the tile in the 16-byte-chunk layout) are L2 hits; 0: tiles interleaved over the XCDs.
+    const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + xi / a.n_nblk : (xi / a.n_nblk) * 8 + xcd;
     if (tlin >= ntile) return;  // grid is padded to a multiple of 8 tiles
     const int bgrp = tlin / tiles;
     const int t = tlin - bgrp * tiles;

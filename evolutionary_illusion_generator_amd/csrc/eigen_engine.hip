@@ -224,6 +224,10 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         a.dbg = tl_dbg;
     }
 #endif
+    {
+        static const int tile_map = getenv("EIGEN_TILE_MAP") ? atoi(getenv("EIGEN_TILE_MAP")) : 1;  // 0 only for A/B measurements
+        a.tile_map = tile_map;
+    }
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
     switch (op.epi) {
