@@ -147,7 +147,20 @@ template <int TW, bool VEC> struct TileGeom {
 #endif
 constexpr int KC = EIG_KC;  // channels per K-block
 
-template <int NI, int TW, bool VEC> constexpr int conv_lds_bytes() { return 2 * (KC * TileGeom<TW, VEC>::PLANE + KC * 9 * NI * 16) * 4; }
+// Branch-free staging (the wide instantiations, VEC && TW == 16 && NI == 4): every lane of every DMA instruction is live --
+// lanes without a slot read out of range (zeros) into padding -- so the input area is rounded up to whole 256-chunk rounds.
+template <int NI, int TW, bool VEC> constexpr bool conv_fast_dma() { return VEC && TW == 16 && KC == 8 && NI >= 3; }  // narrow tiles: the padding would cost a block per CU
+// weight area: NI == 4 keeps its exact 4.5 rounds (the half round is issued by all four waves, two of them repeating the
+// other two); narrower slabs are rounded up to whole rounds, the extra lanes fetch the following rows into the padding
+template <int NI, int TW, bool VEC> constexpr int conv_w_floats()
+{
+    return (conv_fast_dma<NI, TW, VEC>() && NI != 4) ? ((KC * 9 * NI * 4 + 255) / 256) * 1024 : KC * 9 * NI * 16;
+}
+template <int NI, int TW, bool VEC> constexpr int conv_in_floats()
+{
+    return conv_fast_dma<NI, TW, VEC>() ? ((KC * TileGeom<TW, VEC>::PLANE / 4 + 255) / 256) * 1024 : KC * TileGeom<TW, VEC>::PLANE;
+}
+template <int NI, int TW, bool VEC> constexpr int conv_lds_bytes() { return 2 * (conv_in_floats<NI, TW, VEC>() + conv_w_floats<NI, TW, VEC>()) * 4; }
 
 #ifndef EIG_TIMING
 #define EIG_TIMING 0  // measurement-only builds: per-wave s_memtime breakdown of the K loop into a.dbg
@@ -166,7 +179,9 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     constexpr int NB = NI * 16;
     const unsigned long long t_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int BUF = KC * PLANE + KC * 9 * NB;  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
+    constexpr bool FAST = conv_fast_dma<NI, TW, VEC>();
+    constexpr int INF = conv_in_floats<NI, TW, VEC>();  // floats of the input area (KC * PLANE, padded for FAST)
+    constexpr int BUF = INF + conv_w_floats<NI, TW, VEC>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -210,7 +225,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
         const int yy = rem / RW, xx = rem - yy * RW;
         const int gy = y0 + yy - 1, gx = VEC ? (x0 - 4 + 4 * xx) : (x0 + xx - 1);
         const int b = bgrp * NIMG + img;
-        const bool ok = (VEC || p < PLANE) && b < a.B && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const bool ok = (VEC ? p < KC * PER_C : p < PLANE) && b < a.B && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         // VEC: byte offset of the chunk inside ONE image of the source, channel part included; -1 = out of range,
         // which the buffer bounds check turns into zeros.  !VEC: pixel offset.
         sl_off[r] = ok ? (VEC ? ((p / PER_C) * a.H * a.W + gy * a.W + gx) * 4 : gy * a.W + gx) : -1;
@@ -227,7 +242,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
             const int yy = rem / RCU, xx = rem - yy * RCU;
             const int gy = (y0 >> 1) + yy - 1, gx = (x0 >> 1) - 4 + 4 * xx;
             const int b = bgrp * NIMG + img;
-            const bool ok = b < a.B && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
+            const bool ok = p < KC * PER_CU && b < a.B && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
             su_off[r] = ok ? ((p / PER_CU) * Hs * Ws + gy * Ws + gx) * 4 : -1;
             su_img[r] = img;
         }
@@ -244,11 +259,17 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     constexpr int NOPS = NWR + NIN;
     constexpr int NSTEP = KC * 9 / 4;                             // 18
     struct KB { int s, c0, kc, up; };
-    auto kb_first = [&]() { KB k; k.s = 0; k.c0 = 0; k.kc = min(KC, a.src[0].Cpad); k.up = VEC ? a.src[0].up : 0; return k; };
-    auto kb_next = [&](KB k) {
+    // per-source scalars picked with selects (indexing a.src[] with a run-time index would put the argument struct in scratch
+    // and turn everything derived from it -- descriptors, LDS-DMA bases -- into per-lane values)
+    const int cpad0 = a.src[0].Cpad, cpad1 = a.src[1].Cpad, cpad2 = a.src[2].Cpad;
+    const int up0 = VEC ? a.src[0].up : 0, up1 = VEC ? a.src[1].up : 0, up2 = VEC ? a.src[2].up : 0;
+    auto cpad_of = [&](int si) __attribute__((always_inline)) { return si == 0 ? cpad0 : (si == 1 ? cpad1 : cpad2); };
+    auto up_of = [&](int si) __attribute__((always_inline)) { return si == 0 ? up0 : (si == 1 ? up1 : up2); };
+    auto kb_first = [&]() { KB k; k.s = 0; k.c0 = 0; k.kc = min(KC, cpad0); k.up = up0; return k; };
+    auto kb_next = [&](KB k) __attribute__((always_inline)) {
         k.c0 += KC;
-        if (k.c0 >= a.src[k.s].Cpad) { k.c0 = 0; ++k.s; }
-        if (k.s < a.nsrc) { k.kc = min(KC, a.src[k.s].Cpad - k.c0); k.up = VEC ? a.src[k.s].up : 0; }
+        if (k.c0 >= cpad_of(k.s)) { k.c0 = 0; ++k.s; }
+        if (k.s < a.nsrc) { k.kc = min(KC, cpad_of(k.s) - k.c0); k.up = up_of(k.s); }
         else { k.kc = 0; k.up = 0; }
         return k;
     };
@@ -258,12 +279,15 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     // range of the descriptor, which the hardware turns into zeros.
     const int b0 = bgrp * NIMG;
     const int nimg_here = min(NIMG, a.B - b0);
-    auto make_rsrc = [&](int si) {
-        const ConvSrc src = a.src[si < a.nsrc ? si : 0];
-        const size_t per_img = (size_t)src.C * ((a.H >> src.up) * (a.W >> src.up));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(src.ptr + (size_t)b0 * per_img), 0, (int)(per_img * nimg_here * 4), 0x00020000);
+    auto make_rsrc = [&](const float* ptr, int C, int up) {
+        const size_t per_img = (size_t)C * ((a.H >> up) * (a.W >> up));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(ptr + (size_t)b0 * per_img), 0, (int)(per_img * nimg_here * 4), 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(0), rs1 = make_rsrc(1), rs2 = make_rsrc(2);
+    // (unused sources alias source 0: constant indices only, see cpad_of above)
+    const bool has1 = a.nsrc > 1, has2 = a.nsrc > 2;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, a.src[0].C, a.src[0].up);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(has1 ? a.src[1].ptr : a.src[0].ptr, has1 ? a.src[1].C : a.src[0].C, has1 ? a.src[1].up : a.src[0].up);
+    const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(has2 ? a.src[2].ptr : a.src[0].ptr, has2 ? a.src[2].C : a.src[0].C, has2 ? a.src[2].up : a.src[0].up);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * a.krows * NB), 0, a.krows * NB * 4, 0x00020000);
     auto buf_dma16 = [&](int si, float* lds_dst, int voff, int soff) {
         auto l = (__attribute__((address_space(3))) void*)lds_dst;
@@ -273,12 +297,16 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     };
     // one DMA instruction (op j of K-block k) into buffer `buf`; wrow = first weight row of that K-block
     auto dma_op = [&](int j, const KB& k, int wrow, float* buf) {
-        const ConvSrc src = a.src[k.s];
+        ConvSrc src;
+        src.ptr = k.s == 0 ? a.src[0].ptr : (k.s == 1 ? a.src[1].ptr : a.src[2].ptr);
+        src.C = k.s == 0 ? a.src[0].C : (k.s == 1 ? a.src[1].C : a.src[2].C);
+        src.Cpad = cpad_of(k.s);
+        src.up = k.s == 0 ? a.src[0].up : (k.s == 1 ? a.src[1].up : a.src[2].up);
         if (j < NWR) {
             const int n16 = k.kc * 9 * (NB / 4);
             const int base = j * 256 + wv * 64, ch = base + lane;
             if (ch < n16)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(buf + KC * PLANE + (size_t)base * 4), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(buf + INF + (size_t)base * 4), 16,
                                                          tid * 16, (wrow * NB + j * 1024) * 4, 0, 0);
             return;
         }
@@ -318,12 +346,59 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
         }
     };
 
+    // Branch-free variant (FAST): no exec masking, no per-lane predicates, no control flow -- the nine DMA instructions of a
+    // K-block cost ~4 instructions each instead of ~12 (every non-MFMA instruction in the wave's stream costs matrix-pipe
+    // time).  The K-block's byte offset is folded into the lane offset with a SATURATING add, so that the descriptor's
+    // range check sees the whole offset: channels >= C (padding) and rows >= krows fall out of range and read zeros,
+    // `no next K-block` is an offset of 2^31, and an invalid slot (-1) stays 0xffffffff.  NIMG == 1 here (TW == 16).
+    const int vw_full = tid * 16;                                   // weight rounds 0..3: chunk j*256 + tid
+    const int vw_last = (1024 + (wv & 1) * 64 + lane) * 16;         // round 4 holds 128 chunks: waves 2,3 repeat waves 0,1
+    static_assert(!FAST || NI != 4 || (KC * 9 * (NB / 4)) % 256 == 128, "FAST staging: the last weight round of NI = 4 must hold 128 chunks");
+    const int aH = a.H, aW = a.W;
+    // descriptor of the source a K-block reads, from SCALAR selects of base pointer and size (selecting between whole
+    // descriptors ends in a scratch table + waterfall loop)
+    auto src_base = [&](const float* ptr, int C, int up) __attribute__((always_inline)) { return ptr + (size_t)b0 * C * ((a.H >> up) * (a.W >> up)); };
+    auto src_bytes = [&](int C, int up) __attribute__((always_inline)) { return C * ((a.H >> up) * (a.W >> up)) * nimg_here * 4; };
+    const float* const sp0 = src_base(a.src[0].ptr, a.src[0].C, a.src[0].up);
+    const float* const sp1 = has1 ? src_base(a.src[1].ptr, a.src[1].C, a.src[1].up) : sp0;
+    const float* const sp2 = has2 ? src_base(a.src[2].ptr, a.src[2].C, a.src[2].up) : sp0;
+    const int sn0 = src_bytes(a.src[0].C, a.src[0].up);
+    const int sn1 = has1 ? src_bytes(a.src[1].C, a.src[1].up) : sn0;
+    const int sn2 = has2 ? src_bytes(a.src[2].C, a.src[2].up) : sn0;
+    const unsigned long long su0 = (unsigned long long)sp0, sd1 = (unsigned long long)sp1 - su0, sd2 = (unsigned long long)sp2 - (unsigned long long)sp1;
+    auto rsrc_of = [=](int si) __attribute__((always_inline)) {
+        // additive form + readfirstlane: plain 3-way selects were turned into a table in scratch memory indexed by si
+        const unsigned long long u = su0 + (si > 0 ? sd1 : 0ull) + (si > 1 ? sd2 : 0ull);
+        const int n = sn0 + (si > 0 ? sn1 - sn0 : 0) + (si > 1 ? sn2 - sn1 : 0);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+    };
+    // (captures by VALUE: with by-reference captures the closure -- pointers to these locals -- stayed in scratch memory)
+    auto dma_fast = [=](int j, const KB k, const __amdgpu_buffer_rsrc_t rs_k, unsigned soff_in, unsigned soff_w, float* buf) __attribute__((always_inline)) {
+        if (j < NWR) {
+            const unsigned soff = soff_w;
+            const bool lastw = NI == 4 && (j == NWR - 1);
+            const unsigned vo = __builtin_elementwise_add_sat((unsigned)(lastw ? vw_last : vw_full + j * 4096), soff);
+            float* dst = buf + INF + (lastw ? (1024 + (wv & 1) * 64) * 4 : (j * 256 + wv * 64) * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, 0, 0, 0);
+            return;
+        }
+        const int r = j - NWR;
+        const unsigned soff = soff_in;
+        const int slot = k.up ? (r < NRU ? su_off[r < NRU ? r : 0] : -1) : (r < NR ? sl_off[r < NR ? r : 0] : -1);
+        const unsigned vo = __builtin_elementwise_add_sat((unsigned)slot, soff);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(buf + (r * 256 + wv * 64) * 4), 16, (int)vo, 0, 0, 0);
+    };
+
     int nkb = 0;
-    for (int s = 0; s < a.nsrc; ++s) nkb += (a.src[s].Cpad + KC - 1) / KC;
+    for (int s = 0; s < a.nsrc; ++s) nkb += (cpad_of(s) + KC - 1) / KC;
     KB cur_kb = kb_first();
     int wrow = 0;  // first packed weight row of the current K-block
 #pragma unroll
-    for (int j = 0; j < NOPS; ++j) dma_op(j, cur_kb, wrow, lds);
+    for (int j = 0; j < NOPS; ++j) {
+        if constexpr (FAST) dma_fast(j, cur_kb, rsrc_of(0), 0u, 0u, lds);
+        else dma_op(j, cur_kb, wrow, lds);
+    }
     // (the first K-block is in flight: everything below up to the wait overlaps its latency)
 
     // ---- A-operand gather addresses: lane row r = lane&15 = 4*rq + rreg -> pixel (dy, dx); k-slot j = lane>>4.
@@ -364,13 +439,17 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
         const KB nxt_kb = kb_next(cur_kb);
         const int wrow_nxt = wrow + cur_kb.kc * 9;
         const bool more_kb = (kb + 1 < nkb) && EIG_ABLATE != 1;
+        const __amdgpu_buffer_rsrc_t rs_nxt = rsrc_of(nxt_kb.s);
+        // byte offsets of the next K-block inside its source / the weight slab; 2^31 = `nothing to stage` (out of range)
+        const unsigned soff_in_nxt = more_kb ? (unsigned)(nxt_kb.c0 * ((aH >> nxt_kb.up) * (aW >> nxt_kb.up)) * 4) : 0x80000000u;
+        const unsigned soff_w_nxt = more_kb ? (unsigned)(wrow_nxt * NB * 4) : 0x80000000u;
 
         // The two tile layouts (full resolution / unpooled source) differ only in the nine gather addresses, the four
         // sub-tile offsets and the channel stride, all wave-uniform per K-block: ONE loop body.
         // Two instantiations of the 18-step body (full-resolution tile / unpooled source) so that every LDS offset of
         // the operand gather is an immediate: the four A reads of a step pair up into two ds_read2_b32, no address VALU.
         const float* const in_lds = cur;
-        const float* const w_lds = cur + KC * PLANE + boff;
+        const float* const w_lds = cur + INF + boff;
         auto body = [&](auto up_tag) {
             constexpr bool UP = decltype(up_tag)::value;
             constexpr int PL = UP ? PLANE_U : PLANE;
@@ -400,7 +479,11 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
                         for (int ni = 0; ni < NI; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
                 }
-                if (more_kb) {
+                if constexpr (FAST) {
+#pragma unroll
+                    for (int j = 0; j < NOPS; ++j)
+                        if (j * NSTEP / NOPS == st) dma_fast(j, nxt_kb, rs_nxt, soff_in_nxt, soff_w_nxt, nxt);
+                } else if (more_kb) {
 #pragma unroll
                     for (int j = 0; j < NOPS; ++j)
                         if (j * NSTEP / NOPS == st) dma_op(j, nxt_kb, wrow_nxt, nxt);
