@@ -456,7 +456,10 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
             const int* const ad = UP ? addrU : addrA;
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
-                if (st < 9 || cur_kb.kc > 4) {  // second period only for a full K-block (wave-uniform)
+                // second period only for a full K-block (wave-uniform).  FAST: always -- a 4-channel K-block's upper
+                // channels are staged as zeros (out of range), so the extra steps add exact zeros, and the straight-line
+                // body keeps the DMA instructions free of control flow
+                if (FAST || st < 9 || cur_kb.kc > 4) {
                     const int per = st / 9, s9 = st % 9;
                     float av[4], bv[NI];
 #pragma unroll
