@@ -35,7 +35,7 @@
 #include <type_traits>
 
 #ifndef EIG_ABLATE
-#define EIG_ABLATE 0  // measurement-only builds (scripts/ablate_conv.py): 1 = no staging after the first K-block
+#define EIG_ABLATE 0  // measurement-only builds (scripts/ablate_conv.py): 1 = no staging after the first K-block, 2 = ConvLSTM gate math removed
 #endif
 
 namespace eig {
@@ -559,6 +559,11 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
                 float zf = acc[mi][1][reg] + bf; zf = fmaf(a.peep[pstride + pbase + pix], cold, zf);
                 const float zc = acc[mi][2][reg] + bc;
                 float zo = acc[mi][3][reg] + bo; zo = fmaf(a.peep[2 * pstride + pbase + pix], cold, zo);
+                if (EIG_ABLATE == 2) {  // measurement only: gate math removed
+                    a.c_state[cbase + pix] = zi + zf;
+                    a.h_out[cbase + pix] = zc + zo;
+                    continue;
+                }
                 const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
                 const float gi = gg * ii;
                 const float cnew = fmaf(ff, cold, gi);
