@@ -24,6 +24,9 @@
 // by 4 per step, (channel, tap) = divmod(k, 9), so the per-lane LDS offset pattern has period 9 steps (= 4 channels):
 // nine precomputed address registers + immediates, no address VALU in the loop.
 // (Layers whose width is not a multiple of 4 use 4-byte flat-address DMA into [KC][NIMG][TH+2][TW+2]: VEC = false.)
+// The wide instantiations (16x16 tiles, NI >= 3) stage BRANCH-FREE: a DMA is v_add_u32 ... clamp + s_add m0 + buffer_load,
+// everything that must not be read (padded channels, rows past the slab, `no next K-block`) is pushed out of the
+// descriptor's range by a saturating add -- every non-MFMA instruction in the loop costs matrix-pipe time.
 //
 // Row <-> pixel map of a 16-row MFMA sub-tile: 2 image rows x 8 columns; row r = 4q + reg covers
 // (dy, dx) = (reg >> 1, 2q + (reg & 1)), so the four accumulator registers of a lane are one 2x2 pooling window
