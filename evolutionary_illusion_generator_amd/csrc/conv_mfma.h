@@ -656,6 +656,59 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     timeline_record(0);
 }
 
+// ConvP of the image layer (C = 1 or 3 channels in and out, K = 9 C <= 27): with 27 multiply-adds per output the matrix
+// pipe is irrelevant and the MFMA kernel's fixed cost per block (prologue, one DMA round trip, epilogue for 216 MFMAs)
+// is everything -- the operator is HBM-bound (read R_0 and the next frame, write P_0, the uint8 frame and E_0: 18 B per
+// pixel and channel).  One thread per pixel, all C outputs; the haloed tile goes through LDS.  Arithmetic = the same fp32
+// fma chain in (channel, ky, kx) order as the MFMA path (out-of-image taps multiply a staged 0, as there), then the
+// epilogue of EPI_CONVP verbatim, so the results are bit-identical.
+constexpr int P0_TX = 64, P0_TY = 4;
+template <int C>
+__global__ void __launch_bounds__(P0_TX * P0_TY) convp0_direct_kernel(const float* __restrict__ src, const float* __restrict__ wgt /*[C][C][3][3]*/,
+                                                                     const ConvArgs a)
+{
+    __shared__ float tile[C][P0_TY + 2][P0_TX + 2];
+    const int tx = threadIdx.x & (P0_TX - 1), ty = threadIdx.x / P0_TX;
+    const int x0 = blockIdx.x * P0_TX, y0 = blockIdx.y * P0_TY, b = blockIdx.z;
+    const int HW = a.H * a.W;
+    const float* sb = src + (size_t)b * C * HW;
+    for (int i = threadIdx.x; i < C * (P0_TY + 2) * (P0_TX + 2); i += P0_TX * P0_TY) {
+        const int c = i / ((P0_TY + 2) * (P0_TX + 2));
+        const int r = i - c * ((P0_TY + 2) * (P0_TX + 2));
+        const int yy = r / (P0_TX + 2), xx = r - yy * (P0_TX + 2);
+        const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+        tile[c][yy][xx] = (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? sb[(size_t)c * HW + gy * a.W + gx] : 0.0f;
+    }
+    __syncthreads();
+    const int gy = y0 + ty, gx = x0 + tx;
+    if (gy >= a.H || gx >= a.W) return;
+    const int pix = gy * a.W + gx;
+#pragma unroll
+    for (int o = 0; o < C; ++o) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) acc = fmaf(tile[c][ty + ky][tx + kx], wgt[((o * C + c) * 3 + ky) * 3 + kx], acc);
+        const size_t base = ((size_t)b * C + o) * HW;
+        float v = relu_f(acc + a.bias[o]);
+        if (a.clip) v = fminf(v, 1.0f);
+        a.Pout[base + pix] = v;
+        if (a.frame) a.frame[(size_t)b * a.frame_bstride + (size_t)o * HW + pix] = (uint8_t)(int)(v * 255.0f);
+        if (a.E0) {
+            float x;
+            if (a.img) x = (float)a.img[base + pix] / 255.0f;
+            else if (a.requant) x = (float)(uint8_t)(int)(v * 255.0f) / 255.0f;
+            else x = v;
+            const size_t e = ((size_t)b * 2 * C + o) * HW + pix;
+            a.E0[e] = relu_f(x - v);
+            a.E0[e + (size_t)C * HW] = relu_f(v - x);
+        }
+    }
+}
+
 // E_0 for the first step: P_0 = 0  ->  E = [relu(x), relu(-x)] = [x, 0]
 __global__ void e0_init_kernel(const uint8_t* img, float* E0, int C, int HW, int B)
 {

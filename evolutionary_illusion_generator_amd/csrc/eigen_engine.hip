@@ -45,6 +45,7 @@ struct ConvOp {
     int src_C[3] = {0, 0, 0}, src_up[3] = {0, 0, 0};
     int H = 0, W = 0, Cout = 0, n_nblk = 0, krows = 0;
     float* d_wpk = nullptr;
+    float* d_wraw = nullptr;  // image-layer ConvP only: the unpacked OIHW weights for convp0_direct_kernel
     double macs = 0;  // algorithmic multiply-accumulates per image (real channels only)
     double ms = 0;    // profiling accumulator
     int launches = 0;
@@ -230,6 +231,13 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     }
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
+    static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
+    if (op.epi == EPI_CONVP && op.d_wraw && direct_p0) {  // image layer: HBM-bound, one thread per pixel (conv_mfma.h)
+        const dim3 g((op.W + P0_TX - 1) / P0_TX, (op.H + P0_TY - 1) / P0_TY, batch);
+        if (op.Cout == 3) hipLaunchKernelGGL(convp0_direct_kernel<3>, g, dim3(P0_TX * P0_TY), 0, st, a.src[0].ptr, op.d_wraw, a);
+        else hipLaunchKernelGGL(convp0_direct_kernel<1>, g, dim3(P0_TX * P0_TY), 0, st, a.src[0].ptr, op.d_wraw, a);
+        r = hipGetLastError();
+    } else
     switch (op.epi) {
         case EPI_LSTM: r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec); break;
         case EPI_LSTM_PACKED: r = (op.TW == 16) ? launch_inst<1, 16, EPI_LSTM_PACKED>(a, grid, st, vec) : launch_inst<1, 8, EPI_LSTM_PACKED>(a, grid, st, vec); break;
@@ -279,7 +287,7 @@ int eigen_destroy(eigen_engine* e)
     (void)hipSetDevice(e->cfg.device);
     for (int l = 0; l < e->L; ++l) {
         Layer& y = e->layer[l];
-        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk};
+        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw};
         for (float* p : ptrs) if (p) (void)hipFree(p);
     }
     if (e->d_planes) (void)hipFree(e->d_planes);
@@ -405,7 +413,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
         // ---- ConvA_l: E_{l-1} (2 C_{l-1} ch at the finer resolution) -> C_l, fused relu / 2x2 max-pool / error unit
         if (l > 0) {
             ConvOp& op = y.convA;
-            op = ConvOp();
+            { float *k0 = op.d_wpk, *k1 = op.d_wraw; op = ConvOp(); op.d_wpk = k0; op.d_wraw = k1; }  // keep the allocations: upload() frees them
             op.epi = EPI_CONVA; op.layer = l; op.nsrc = 1; op.src_C[0] = 2 * e->layer[l - 1].C; op.src_up[0] = 0;
             op.H = e->layer[l - 1].H; op.W = e->layer[l - 1].W; op.Cout = C;
             choose_ni(C, false, &op.NI, &op.n_nblk);
@@ -419,7 +427,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
         // ---- ConvLSTM_l: sources E_l, unpooled R_{l+1}, h_l ; 4 gates fused on N
         {
             ConvOp& op = y.lstm;
-            op = ConvOp();
+            { float *k0 = op.d_wpk, *k1 = op.d_wraw; op = ConvOp(); op.d_wpk = k0; op.d_wraw = k1; }  // keep the allocations: upload() frees them
             op.epi = EPI_LSTM; op.layer = l; op.H = y.H; op.W = y.W; op.Cout = C;
             op.nsrc = 0;
             op.src_C[op.nsrc] = 2 * C; op.src_up[op.nsrc] = 0; op.nsrc++;
@@ -448,7 +456,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
         // ---- ConvP_l
         {
             ConvOp& op = y.convP;
-            op = ConvOp();
+            { float *k0 = op.d_wpk, *k1 = op.d_wraw; op = ConvOp(); op.d_wpk = k0; op.d_wraw = k1; }  // keep the allocations: upload() frees them
             op.epi = EPI_CONVP; op.layer = l; op.nsrc = 1; op.src_C[0] = C; op.src_up[0] = 0;
             op.H = y.H; op.W = y.W; op.Cout = C;
             choose_ni(C, false, &op.NI, &op.n_nblk);
@@ -458,6 +466,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             const float* sw[3][4] = {{convP_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
             std::vector<float> pk = pack_weights(op, sw, 0);
             if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.biasP, convP_b, C)) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvP%d)", l);
+            if (l == 0 && (C == 1 || C == 3) && upload(&op.d_wraw, convP_w, (size_t)C * C * 9)) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvP0 direct)");
         }
     }
     e->have_weights = true;
