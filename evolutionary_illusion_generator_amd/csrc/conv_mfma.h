@@ -574,35 +574,45 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
                 a.h_out[cbase + pix] = oo * det_tanhf(cnew);
             }
         } else if (EPI == EPI_LSTM_PACKED) {
-            // C <= 4 (layer 0): ONE 16-column tile holds the 4 gates x 4 channel slots, column = gate*4 + channel.
-            // Lanes of gate 0 fetch the other three gates of their channel from lanes col+4, +8, +12.
-            const int ch = col & 3;
-            const bool active = (col < 4) && (ch < a.Cout);
+            // C <= 4 (layer 0): ONE 16-column tile holds the 4 gates x 4 channel slots, column = 4*gate + channel, so the
+            // four gates of a cell sit in four lanes (same pixel rows q, columns ch, ch+4, ch+8, ch+12) and each of those
+            // lanes holds them for the four pixels of its 2x2 window (reg 0..3).  A 4x4 transpose across the four lanes
+            // gives lane (group g = col>>2, channel ch) ALL FOUR gates of pixel reg = g: one cell per lane and sub-tile
+            // instead of four cells in a quarter of the lanes (the gate math is ~190 instructions per cell).
+            // Round d: every lane offers its register (g+d)&3, lane g pulls from group (g-d)&3 -> that group's gate, pixel g.
+            const int ch = col & 3, g = col >> 2;
+            const bool active = ch < a.Cout;
             const int cc = active ? ch : 0;
+            float r[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int sel = (g + d) & 3;
+                const float v = sel == 0 ? acc[mi][0][0] : (sel == 1 ? acc[mi][0][1] : (sel == 2 ? acc[mi][0][2] : acc[mi][0][3]));
+                r[d] = (d == 0) ? v : __shfl(v, (lane & ~12) | (((g - d) & 3) << 2), 64);
+            }
+            // r[d] is gate (g-d)&3; gate s arrived in round (g-s)&3
+            auto gate = [&](int s) {
+                const int d = (g - s) & 3;
+                return d == 0 ? r[0] : (d == 1 ? r[1] : (d == 2 ? r[2] : r[3]));
+            };
+            const float ai = gate(0), af = gate(1), ac = gate(2), ao = gate(3);
+            const int gy = gy0 + (g >> 1), gx = gx0 + (g & 1);
+            if (!active || gy >= a.H || gx >= a.W) continue;
             const float bi = a.bias[cc], bf = a.bias[a.Cout + cc], bc = a.bias[2 * a.Cout + cc], bo = a.bias[3 * a.Cout + cc];
             const size_t cbase = ((size_t)b * a.Cout + cc) * HW;
             const size_t pbase = (size_t)cc * HW;
             const size_t pstride = (size_t)a.Cout * HW;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const float ai = acc[mi][0][reg];
-                const float af = __shfl(ai, lane + 4, 64);
-                const float ac = __shfl(ai, lane + 8, 64);
-                const float ao = __shfl(ai, lane + 12, 64);
-                const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);
-                if (!active || gy >= a.H || gx >= a.W) continue;
-                const int pix = gy * a.W + gx;
-                const float cold = a.c_state[cbase + pix];
-                float zi = ai + bi; zi = fmaf(a.peep[pbase + pix], cold, zi);
-                float zf = af + bf; zf = fmaf(a.peep[pstride + pbase + pix], cold, zf);
-                const float zc = ac + bc;
-                float zo = ao + bo; zo = fmaf(a.peep[2 * pstride + pbase + pix], cold, zo);
-                const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
-                const float gi = gg * ii;
-                const float cnew = fmaf(ff, cold, gi);
-                a.c_state[cbase + pix] = cnew;
-                a.h_out[cbase + pix] = oo * det_tanhf(cnew);
-            }
+            const int pix = gy * a.W + gx;
+            const float cold = a.c_state[cbase + pix];
+            float zi = ai + bi; zi = fmaf(a.peep[pbase + pix], cold, zi);
+            float zf = af + bf; zf = fmaf(a.peep[pstride + pbase + pix], cold, zf);
+            const float zc = ac + bc;
+            float zo = ao + bo; zo = fmaf(a.peep[2 * pstride + pbase + pix], cold, zo);
+            const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
+            const float gi = gg * ii;
+            const float cnew = fmaf(ff, cold, gi);
+            a.c_state[cbase + pix] = cnew;
+            a.h_out[cbase + pix] = oo * det_tanhf(cnew);
         } else if (EPI == EPI_CONVA) {
             const int Ho = a.H >> 1, Wo = a.W >> 1;
             float pv[NI];
