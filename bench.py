@@ -189,9 +189,9 @@ def main():
                            "algorithmic_flops_per_launch": fl / max(n_l, 1),
                            "all_conv_kernels": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "frac": all_fl / (all_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                                                 "total_ms": all_ms, "launches": sum(r["launches"] for r in rows)},
-                           "per_op": [{"layer": r["layer"], "op": r["epi"], "ms": round(r["ms"], 3), "launches": r["launches"],
+                           "per_op": [{"layer": r["layer"], "op": r["epi"] + ("(step 0: zero sources skipped)" if r.get("step0") else ""), "ms": round(r["ms"], 3), "launches": r["launches"],
                                        "tflops": (r["flops_per_image"] * args.pop * r["launches"] / (r["ms"] * 1e-3) / 1e12) if r["ms"] > 0 else 0.0}
-                                      for r in rows]}
+                                      for r in rows if r["launches"] > 0]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         grid = grids.create_grid(STRUCTURE, W, H, 10)
         cb, cpu_fit = cpu_baseline(cfg, population, wts, grid)

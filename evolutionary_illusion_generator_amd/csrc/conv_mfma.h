@@ -52,7 +52,7 @@ struct ConvSrc {
     int C;             // real channels
     int Cpad;          // padded to a multiple of 4
     int up;            // 1: half resolution, nearest-unpooled x2 on the fly
-    int _pad;
+    int Ct;            // channels of the TENSOR (image stride); C < Ct reads only its first C channels (step-0 operators)
 };
 
 struct ConvArgs {
@@ -282,15 +282,15 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     // range of the descriptor, which the hardware turns into zeros.
     const int b0 = bgrp * NIMG;
     const int nimg_here = min(NIMG, a.B - b0);
-    auto make_rsrc = [&](const float* ptr, int C, int up) {
-        const size_t per_img = (size_t)C * ((a.H >> up) * (a.W >> up));
-        return __builtin_amdgcn_make_buffer_rsrc((void*)(ptr + (size_t)b0 * per_img), 0, (int)(per_img * nimg_here * 4), 0x00020000);
+    auto make_rsrc = [&](const float* ptr, int C, int Ct, int up) {
+        const size_t plane = (size_t)((a.H >> up) * (a.W >> up));
+        return __builtin_amdgcn_make_buffer_rsrc((void*)(ptr + (size_t)b0 * Ct * plane), 0, (int)(((size_t)(nimg_here - 1) * Ct + C) * plane * 4), 0x00020000);
     };
     // (unused sources alias source 0: constant indices only, see cpad_of above)
     const bool has1 = a.nsrc > 1, has2 = a.nsrc > 2;
-    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, a.src[0].C, a.src[0].up);
-    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(has1 ? a.src[1].ptr : a.src[0].ptr, has1 ? a.src[1].C : a.src[0].C, has1 ? a.src[1].up : a.src[0].up);
-    const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(has2 ? a.src[2].ptr : a.src[0].ptr, has2 ? a.src[2].C : a.src[0].C, has2 ? a.src[2].up : a.src[0].up);
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, a.src[0].C, a.src[0].Ct, a.src[0].up);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(has1 ? a.src[1].ptr : a.src[0].ptr, has1 ? a.src[1].C : a.src[0].C, has1 ? a.src[1].Ct : a.src[0].Ct, has1 ? a.src[1].up : a.src[0].up);
+    const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(has2 ? a.src[2].ptr : a.src[0].ptr, has2 ? a.src[2].C : a.src[0].C, has2 ? a.src[2].Ct : a.src[0].Ct, has2 ? a.src[2].up : a.src[0].up);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * a.krows * NB), 0, a.krows * NB * 4, 0x00020000);
     auto buf_dma16 = [&](int si, float* lds_dst, int voff, int soff) {
         auto l = (__attribute__((address_space(3))) void*)lds_dst;
@@ -305,6 +305,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
         src.C = k.s == 0 ? a.src[0].C : (k.s == 1 ? a.src[1].C : a.src[2].C);
         src.Cpad = cpad_of(k.s);
         src.up = k.s == 0 ? a.src[0].up : (k.s == 1 ? a.src[1].up : a.src[2].up);
+        src.Ct = k.s == 0 ? a.src[0].Ct : (k.s == 1 ? a.src[1].Ct : a.src[2].Ct);
         if (j < NWR) {
             const int n16 = k.kc * 9 * (NB / 4);
             const int base = j * 256 + wv * 64, ch = base + lane;
@@ -323,14 +324,14 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
             if (!k.up) {
                 if (r < NR) {
                     int vo = sl_off[r < NR ? r : 0];
-                    if (NIMG > 1) vo = vo < 0 ? vo : vo + sl_img[r < NR ? r : 0] * src.C * chs * 4;
+                    if (NIMG > 1) vo = vo < 0 ? vo : vo + sl_img[r < NR ? r : 0] * src.Ct * chs * 4;
                     if (tail && k.c0 + p / PER_C >= src.C) vo = -1;
                     if (p < k.kc * PER_C) buf_dma16(k.s, buf + (r * 256 + wv * 64) * 4, vo, soff);
                 }
             } else {
                 if (r < NRU) {
                     int vo = su_off[r < NRU ? r : 0];
-                    if (NIMG > 1) vo = vo < 0 ? vo : vo + su_img[r < NRU ? r : 0] * src.C * chs * 4;
+                    if (NIMG > 1) vo = vo < 0 ? vo : vo + su_img[r < NRU ? r : 0] * src.Ct * chs * 4;
                     if (tail && k.c0 + p / PER_CU >= src.C) vo = -1;
                     if (p < k.kc * PER_CU) buf_dma16(k.s, buf + (r * 256 + wv * 64) * 4, vo, soff);
                 }
@@ -341,7 +342,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
                 const bool pok = sl_off[r] >= 0;
                 const int gy = pok ? sl_off[r] / a.W : 0, gx = pok ? sl_off[r] - gy * a.W : 0;
                 const float* g = (pok && (k.c0 + c < src.C))
-                                     ? src.ptr + ((size_t)sl_img[r] * src.C + k.c0 + c) * chs + (gy >> src.up) * Ws + (gx >> src.up) : a.zeros;
+                                     ? src.ptr + ((size_t)sl_img[r] * src.Ct + k.c0 + c) * chs + (gy >> src.up) * Ws + (gx >> src.up) : a.zeros;
                 if (tid + r * 256 < PLANE)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(buf + c * PLANE + r * 256 + wv * 64), 4, 0, 0);
@@ -360,14 +361,14 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     const int aH = a.H, aW = a.W;
     // descriptor of the source a K-block reads, from SCALAR selects of base pointer and size (selecting between whole
     // descriptors ends in a scratch table + waterfall loop)
-    auto src_base = [&](const float* ptr, int C, int up) __attribute__((always_inline)) { return ptr + (size_t)b0 * C * ((a.H >> up) * (a.W >> up)); };
-    auto src_bytes = [&](int C, int up) __attribute__((always_inline)) { return C * ((a.H >> up) * (a.W >> up)) * nimg_here * 4; };
-    const float* const sp0 = src_base(a.src[0].ptr, a.src[0].C, a.src[0].up);
-    const float* const sp1 = has1 ? src_base(a.src[1].ptr, a.src[1].C, a.src[1].up) : sp0;
-    const float* const sp2 = has2 ? src_base(a.src[2].ptr, a.src[2].C, a.src[2].up) : sp0;
-    const int sn0 = src_bytes(a.src[0].C, a.src[0].up);
-    const int sn1 = has1 ? src_bytes(a.src[1].C, a.src[1].up) : sn0;
-    const int sn2 = has2 ? src_bytes(a.src[2].C, a.src[2].up) : sn0;
+    auto src_base = [&](const float* ptr, int Ct, int up) __attribute__((always_inline)) { return ptr + (size_t)b0 * Ct * ((a.H >> up) * (a.W >> up)); };
+    auto src_bytes = [&](int C, int Ct, int up) __attribute__((always_inline)) { return ((nimg_here - 1) * Ct + C) * ((a.H >> up) * (a.W >> up)) * 4; };
+    const float* const sp0 = src_base(a.src[0].ptr, a.src[0].Ct, a.src[0].up);
+    const float* const sp1 = has1 ? src_base(a.src[1].ptr, a.src[1].Ct, a.src[1].up) : sp0;
+    const float* const sp2 = has2 ? src_base(a.src[2].ptr, a.src[2].Ct, a.src[2].up) : sp0;
+    const int sn0 = src_bytes(a.src[0].C, a.src[0].Ct, a.src[0].up);
+    const int sn1 = has1 ? src_bytes(a.src[1].C, a.src[1].Ct, a.src[1].up) : sn0;
+    const int sn2 = has2 ? src_bytes(a.src[2].C, a.src[2].Ct, a.src[2].up) : sn0;
     const unsigned long long su0 = (unsigned long long)sp0, sd1 = (unsigned long long)sp1 - su0, sd2 = (unsigned long long)sp2 - (unsigned long long)sp1;
     auto rsrc_of = [=](int si) __attribute__((always_inline)) {
         // additive form + readfirstlane: plain 3-way selects were turned into a table in scratch memory indexed by si

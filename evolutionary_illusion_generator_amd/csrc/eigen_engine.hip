@@ -43,6 +43,7 @@ struct ConvOp {
     int epi = 0, NI = 4, TW = 16, layer = 0;
     int nsrc = 0;
     int src_C[3] = {0, 0, 0}, src_up[3] = {0, 0, 0};
+    int src_Ct[3] = {0, 0, 0};  // channels of the source TENSOR when only its first src_C channels are read (0: = src_C)
     int H = 0, W = 0, Cout = 0, n_nblk = 0, krows = 0;
     float* d_wpk = nullptr;
     float* d_wraw = nullptr;  // image-layer ConvP only: the unpacked OIHW weights for convp0_direct_kernel
@@ -57,6 +58,10 @@ struct Layer {
     float *c = nullptr, *P = nullptr, *E = nullptr;
     float *bias_lstm = nullptr, *peep = nullptr, *biasA = nullptr, *biasP = nullptr;
     ConvOp convA, lstm, convP;
+    // Step-0 operators: after reset_state() h_l = 0 and P_l = 0, hence the second half of every E_l (relu(P - A), A >= 0)
+    // is 0 as well.  Their terms fma(0, w, acc) leave the chain untouched, so the first step runs the same chains over the
+    // non-zero sources only: ConvA reads the first half of E_{l-1}, the ConvLSTM the first half of E_l and R_{l+1}.
+    ConvOp convA_t0, lstm_t0;
 };
 
 template <typename T> struct DevBuf {
@@ -147,6 +152,7 @@ static std::vector<float> pack_weights(const ConvOp& op, const float* const srcw
         size_t row = 0;
         for (int s = 0; s < op.nsrc; ++s) {
             const int Cin = op.src_C[s], Cp = pad4(Cin);
+            const int Cw = op.src_Ct[s] ? op.src_Ct[s] : Cin;  // input channels of the weight tensor
             for (int c = 0; c < Cp; ++c)
                 for (int tap = 0; tap < 9; ++tap, ++row) {
                     if (c >= Cin) continue;
@@ -159,7 +165,7 @@ static std::vector<float> pack_weights(const ConvOp& op, const float* const srcw
                         if (o >= op.Cout) continue;
                         // LDS/slab column order: [16 lanes (n % 16)][NI tiles (n / 16)] so that a lane reads its NI values
                         // of a row with one ds_read_b128 (conv_mfma.h: boff)
-                        dst[(n % 16) * op.NI + (n / 16)] = srcw[s][g][((size_t)o * Cin + c) * 9 + tap];
+                        dst[(n % 16) * op.NI + (n / 16)] = srcw[s][g][((size_t)o * Cw + c) * 9 + tap];
                     }
                 }
         }
@@ -211,7 +217,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     a.tilesY = (op.H + TH - 1) / TH;
     a.n_nblk = op.n_nblk; a.krows = op.krows; a.wpk = op.d_wpk; a.Cout = op.Cout; a.zeros = e->d_zeros;
     a.nsrc = op.nsrc;
-    for (int s = 0; s < op.nsrc; ++s) { a.src[s].C = op.src_C[s]; a.src[s].Cpad = pad4(op.src_C[s]); a.src[s].up = op.src_up[s]; }
+    for (int s = 0; s < op.nsrc; ++s) { a.src[s].C = op.src_C[s]; a.src[s].Cpad = pad4(op.src_C[s]); a.src[s].up = op.src_up[s]; a.src[s].Ct = op.src_Ct[s] ? op.src_Ct[s] : op.src_C[s]; }
     const int ntile = ((batch + NIMG - 1) / NIMG) * a.tilesX * a.tilesY;
     const int grid = op.n_nblk * ((ntile + 7) / 8) * 8;  // XCD-aware tile map (conv_mfma.h): tiles padded to a multiple of 8
     // 16-byte DMA staging needs chunk-aligned rows: W % 4 == 0, and W % 8 == 0 when a half-resolution source is read
@@ -287,7 +293,7 @@ int eigen_destroy(eigen_engine* e)
     (void)hipSetDevice(e->cfg.device);
     for (int l = 0; l < e->L; ++l) {
         Layer& y = e->layer[l];
-        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw};
+        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw, y.convA_t0.d_wpk, y.lstm_t0.d_wpk};
         for (float* p : ptrs) if (p) (void)hipFree(p);
     }
     if (e->d_planes) (void)hipFree(e->d_planes);
@@ -423,6 +429,13 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             const float* sw[3][4] = {{convA_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
             std::vector<float> pk = pack_weights(op, sw, 0);
             if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.biasA, convA_b, C)) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d)", l);
+            ConvOp& t0 = y.convA_t0;  // step 0: first half of E_{l-1} only (Layer::convA_t0)
+            { float* k0 = t0.d_wpk; t0 = op; t0.d_wpk = k0; t0.d_wraw = nullptr; }
+            t0.src_C[0] = e->layer[l - 1].C; t0.src_Ct[0] = 2 * e->layer[l - 1].C;
+            t0.krows = pad4(t0.src_C[0]) * 9;
+            t0.macs = (double)op.H * op.W * C * t0.src_C[0] * 9;
+            std::vector<float> pk0 = pack_weights(t0, sw, 0);
+            if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d, step 0)", l);
         }
         // ---- ConvLSTM_l: sources E_l, unpooled R_{l+1}, h_l ; 4 gates fused on N
         {
@@ -452,6 +465,15 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             for (int g = 0; g < 3; ++g) memcpy(&pp[g * chw], peep[g], sizeof(float) * chw);
             if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.bias_lstm, bias.data(), bias.size()) || upload(&y.peep, pp.data(), pp.size()))
                 return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d)", l);
+            ConvOp& t0 = y.lstm_t0;  // step 0: first half of E_l and R_{l+1}; h_l = 0 is not read (Layer::lstm_t0)
+            { float* k0 = t0.d_wpk; t0 = op; t0.d_wpk = k0; t0.d_wraw = nullptr; }
+            t0.nsrc = op.nsrc - 1;
+            t0.src_C[0] = C; t0.src_Ct[0] = 2 * C;
+            t0.src_C[t0.nsrc] = 0; t0.src_up[t0.nsrc] = 0;
+            t0.krows = 0; t0.macs = 0;
+            for (int s2 = 0; s2 < t0.nsrc; ++s2) { t0.krows += pad4(t0.src_C[s2]) * 9; t0.macs += (double)y.H * y.W * 4 * C * t0.src_C[s2] * 9; }
+            std::vector<float> pk0 = pack_weights(t0, sw, op.epi == EPI_LSTM_PACKED ? 2 : 1);
+            if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, step 0)", l);
         }
         // ---- ConvP_l
         {
@@ -597,6 +619,7 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
         HIPCHK(hipMemsetAsync(y.P, 0, n, st));
     }
     int cur = 0;  // h[cur] holds the state of the previous step
+    static const bool skip_zero_sources = !(getenv("EIGEN_NO_T0") && atoi(getenv("EIGEN_NO_T0")));  // A/B measurements only
     hipLaunchKernelGGL(e0_init_kernel, dim3(1024), dim3(256), 0, st, d_images, e->layer[0].E, e->C0, (int)HW, batch);
     HIPCHK(hipGetLastError());
     for (int t = 0; t < n_steps; ++t) {
@@ -607,7 +630,7 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
             memset(&a, 0, sizeof(a));
             a.src[0].ptr = e->layer[l - 1].E;
             a.bias = y.biasA; a.P = y.P; a.E = y.E;
-            HIPCHK(launch_conv(e, y.convA, a, batch, st));
+            HIPCHK(launch_conv(e, (t == 0 && skip_zero_sources) ? y.convA_t0 : y.convA, a, batch, st));
         }
         // top-down: R_l, then P_l
         for (int l = L - 1; l >= 0; --l) {
@@ -618,9 +641,10 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
                 int s = 0;
                 a.src[s++].ptr = y.E;
                 if (l < L - 1) a.src[s++].ptr = e->layer[l + 1].h[cur ^ 1];  // R_{l+1} of THIS step
-                a.src[s++].ptr = y.h[cur];
+                const bool t0 = (t == 0 && skip_zero_sources);
+                if (!t0) a.src[s++].ptr = y.h[cur];
                 a.bias = y.bias_lstm; a.c_state = y.c; a.h_out = y.h[cur ^ 1]; a.peep = y.peep;
-                HIPCHK(launch_conv(e, y.lstm, a, batch, st));
+                HIPCHK(launch_conv(e, t0 ? y.lstm_t0 : y.lstm, a, batch, st));
             }
             // P_l (l > 0) is only read by ConvA_l of the NEXT step: nothing reads it after the last one
             if (l == 0 || t + 1 < n_steps) {
@@ -767,8 +791,8 @@ int eigen_get_timings(eigen_engine* e, double* h_ms6)
     if (!e || !h_ms6) return fail(EIGEN_ERR_INVALID, "null argument");
     double conv = 0; int launches = 0;
     for (int l = 0; l < e->L; ++l) {
-        conv += e->layer[l].convA.ms + e->layer[l].lstm.ms + e->layer[l].convP.ms;
-        launches += e->layer[l].convA.launches + e->layer[l].lstm.launches + e->layer[l].convP.launches;
+        conv += e->layer[l].convA.ms + e->layer[l].lstm.ms + e->layer[l].convP.ms + e->layer[l].convA_t0.ms + e->layer[l].lstm_t0.ms;
+        launches += e->layer[l].convA.launches + e->layer[l].lstm.launches + e->layer[l].convP.launches + e->layer[l].convA_t0.launches + e->layer[l].lstm_t0.launches;
     }
     for (int i = 0; i < 4; ++i) h_ms6[i] = e->ms[i];
     h_ms6[4] = conv; h_ms6[5] = launches;
@@ -777,19 +801,20 @@ int eigen_get_timings(eigen_engine* e, double* h_ms6)
 
 // Per-op profile of the roll-out convolutions.  enable=1 brackets every conv launch with HIP events on its stream
 // (serialising the stream per launch); rows of h_out (8 doubles each, up to max_ops):
-// [layer, epi, NI, TW, launches, total_ms, algorithmic FLOPs per launch per image (2*MACs), n_nblk]
+// [layer, epi (+16 for the step-0 operators), NI, TW, launches, total_ms, FLOPs per launch per image (2*MACs of the terms executed), n_nblk]
 int eigen_conv_profile(eigen_engine* e, int32_t enable, int32_t reset, double* h_out, int32_t max_ops, int32_t* n_ops)
 {
     if (!e) return fail(EIGEN_ERR_INVALID, "null argument");
     e->profile_convs = enable != 0;
     int n = 0;
     for (int l = 0; l < e->L; ++l) {
-        ConvOp* ops[3] = {l > 0 ? &e->layer[l].convA : nullptr, &e->layer[l].lstm, &e->layer[l].convP};
+        ConvOp* ops[5] = {l > 0 ? &e->layer[l].convA : nullptr, &e->layer[l].lstm, &e->layer[l].convP,
+                          l > 0 ? &e->layer[l].convA_t0 : nullptr, &e->layer[l].lstm_t0};
         for (ConvOp* op : ops) {
             if (!op) continue;
             if (h_out && n < max_ops) {
                 double* r = h_out + (size_t)n * 8;
-                r[0] = op->layer; r[1] = op->epi; r[2] = op->NI; r[3] = op->TW; r[4] = op->launches; r[5] = op->ms; r[6] = 2.0 * op->macs; r[7] = op->n_nblk;
+                r[0] = op->layer; r[1] = op->epi + ((op == &e->layer[l].convA_t0 || op == &e->layer[l].lstm_t0) ? 16 : 0); r[2] = op->NI; r[3] = op->TW; r[4] = op->launches; r[5] = op->ms; r[6] = 2.0 * op->macs; r[7] = op->n_nblk;
             }
             if (reset) { op->ms = 0; op->launches = 0; }
             ++n;
