@@ -45,7 +45,7 @@ namespace eig {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { EPI_RAW = 0, EPI_LSTM = 1, EPI_CONVA = 2, EPI_CONVP = 3, EPI_LSTM_PACKED = 4 };
+enum { EPI_RAW = 0, EPI_LSTM = 1, EPI_CONVA = 2, EPI_CONVP = 3, EPI_LSTM_PACKED = 4, EPI_UP4 = 5 };
 
 struct ConvSrc {
     const float* ptr;  // [B][C][H>>up][W>>up]
@@ -82,7 +82,10 @@ struct ConvArgs {
     int requant;
     int tile_map;       // block -> tile order, see the kernel
     // EPI_RAW
-    float* raw;         // [B][Cout][H][W]
+    float* raw;         // [B][Cout][H][W];  EPI_UP4: [B][4 parity classes][n_nblk*NB][H][W]
+    // Partial chains of an unpooled source (written by an EPI_UP4 launch at HALF this resolution) the accumulators start
+    // from, [B][4][n_nblk*NB][H/2][W/2]; nullptr: start from 0.
+    const float* acc_init;
     const float* zeros; // >= 64 zero bytes in device memory: DMA source for out-of-image / padded-channel positions
     unsigned long long* dbg;  // EIG_TIMING builds only: per-block cycle counters
 };
@@ -180,6 +183,11 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     constexpr int TH = G::TH, NIMG = G::NIMG, S = G::S, XO = G::XO, PH = G::PH, PLANE = G::PLANE;
     constexpr int SU = G::SU, PHU = G::PHU, PLANE_U = G::PLANE_U;
     constexpr int NB = NI * 16;
+    // EPI_UP4: the 2x2 form of `unpool x2 -> conv3x3`.  The launch runs at the SOURCE resolution; a block
+    // computes, for its parity class (py, px), the partial chains of the output pixels (2Y+py, 2X+px) of its tile:
+    // k = (channel, a, b), 4 taps per channel, tap (a, b) reads source pixel (Y+a-1+py, X+b-1+px) -- inside the same
+    // haloed tile a 3x3 convolution stages.  The ConvLSTM launch that follows starts its accumulators from the result.
+    constexpr int TAPS = (EPI == EPI_UP4) ? 4 : 9;
     const unsigned long long t_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool FAST = conv_fast_dma<NI, TW, VEC>();
@@ -200,10 +208,13 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     const int ngroups = (a.B + NIMG - 1) / NIMG;
     const int ntile = ngroups * tiles;
     const int xcd = blockIdx.x & 7, xi = blockIdx.x >> 3;
-    const int nblk = xi % a.n_nblk;
+    const int nnb = (EPI == EPI_UP4) ? a.n_nblk * 4 : a.n_nblk;  // EPI_UP4: the four parity classes of a tile are neighbours too
+    const int nbe = xi % nnb;
+    const int nblk = (EPI == EPI_UP4) ? nbe >> 2 : nbe;
+    const int cls = (EPI == EPI_UP4) ? nbe & 3 : 0;
     // tile_map 1: every XCD owns a CONTIGUOUS range of tiles, so the tiles in flight on one XCD are spatial neighbours and
     // their overlapping halos (1.7x the tile in the 16-byte-chunk layout) are L2 hits; 0: tiles interleaved over the XCDs.
-    const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + xi / a.n_nblk : (xi / a.n_nblk) * 8 + xcd;
+    const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + xi / nnb : (xi / nnb) * 8 + xcd;
     if (tlin >= ntile) return;  // grid is padded to a multiple of 8 tiles
     const int bgrp = tlin / tiles;
     const int t = tlin - bgrp * tiles;
@@ -257,15 +268,18 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     // The DMA instructions of K-block kb+1 are INTERLEAVED with the 18 MFMA steps of K-block kb (one every other
     // step): a DMA issued while the wave would anyway be waiting for the matrix pipe costs nothing, whereas a burst
     // of them ahead of the MFMAs measured ~0.7 % of the K-block time per instruction.  ONE barrier per K-block.
-    constexpr int NWR = (KC * 9 * (NB / 4) + 255) / 256;          // weight DMA rounds per K-block
+    constexpr int NWR = (KC * TAPS * (NB / 4) + 255) / 256;       // weight DMA rounds per K-block
     constexpr int NIN = VEC ? (NR > NRU ? NR : NRU) : KC * NR;    // input DMA ops per K-block
     constexpr int NOPS = NWR + NIN;
-    constexpr int NSTEP = KC * 9 / 4;                             // 18
+    constexpr int NSTEP = KC * TAPS / 4;                          // 18 (8 for the 2x2 form)
     struct KB { int s, c0, kc, up; };
     // per-source scalars picked with selects (indexing a.src[] with a run-time index would put the argument struct in scratch
     // and turn everything derived from it -- descriptors, LDS-DMA bases -- into per-lane values)
     const int cpad0 = a.src[0].Cpad, cpad1 = a.src[1].Cpad, cpad2 = a.src[2].Cpad;
-    const int up0 = VEC ? a.src[0].up : 0, up1 = VEC ? a.src[1].up : 0, up2 = VEC ? a.src[2].up : 0;
+    // (unpooled sources no longer reach this path: they are evaluated in their 2x2 form by an EPI_UP4 launch at the source
+    //  resolution; the in-kernel unpooling code below is kept, compiled out, for A/B measurements)
+    constexpr bool UPS = false;
+    const int up0 = (UPS && VEC) ? a.src[0].up : 0, up1 = (UPS && VEC) ? a.src[1].up : 0, up2 = (UPS && VEC) ? a.src[2].up : 0;
     auto cpad_of = [&](int si) __attribute__((always_inline)) { return si == 0 ? cpad0 : (si == 1 ? cpad1 : cpad2); };
     auto up_of = [&](int si) __attribute__((always_inline)) { return si == 0 ? up0 : (si == 1 ? up1 : up2); };
     auto kb_first = [&]() { KB k; k.s = 0; k.c0 = 0; k.kc = min(KC, cpad0); k.up = up0; return k; };
@@ -291,7 +305,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, a.src[0].C, a.src[0].Ct, a.src[0].up);
     const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(has1 ? a.src[1].ptr : a.src[0].ptr, has1 ? a.src[1].C : a.src[0].C, has1 ? a.src[1].Ct : a.src[0].Ct, has1 ? a.src[1].up : a.src[0].up);
     const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(has2 ? a.src[2].ptr : a.src[0].ptr, has2 ? a.src[2].C : a.src[0].C, has2 ? a.src[2].Ct : a.src[0].Ct, has2 ? a.src[2].up : a.src[0].up);
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * a.krows * NB), 0, a.krows * NB * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + ((size_t)cls * a.n_nblk + nblk) * a.krows * NB), 0, a.krows * NB * 4, 0x00020000);
     auto buf_dma16 = [&](int si, float* lds_dst, int voff, int soff) {
         auto l = (__attribute__((address_space(3))) void*)lds_dst;
         if (si == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, l, 16, voff, soff, 0, 0);
@@ -307,7 +321,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
         src.up = k.s == 0 ? a.src[0].up : (k.s == 1 ? a.src[1].up : a.src[2].up);
         src.Ct = k.s == 0 ? a.src[0].Ct : (k.s == 1 ? a.src[1].Ct : a.src[2].Ct);
         if (j < NWR) {
-            const int n16 = k.kc * 9 * (NB / 4);
+            const int n16 = k.kc * TAPS * (NB / 4);
             const int base = j * 256 + wv * 64, ch = base + lane;
             if (ch < n16)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(buf + INF + (size_t)base * 4), 16,
@@ -357,7 +371,8 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     // `no next K-block` is an offset of 2^31, and an invalid slot (-1) stays 0xffffffff.  NIMG == 1 here (TW == 16).
     const int vw_full = tid * 16;                                   // weight rounds 0..3: chunk j*256 + tid
     const int vw_last = (1024 + (wv & 1) * 64 + lane) * 16;         // round 4 holds 128 chunks: waves 2,3 repeat waves 0,1
-    static_assert(!FAST || NI != 4 || (KC * 9 * (NB / 4)) % 256 == 128, "FAST staging: the last weight round of NI = 4 must hold 128 chunks");
+    static_assert(!FAST || NI != 4 || TAPS != 9 || (KC * 9 * (NB / 4)) % 256 == 128, "FAST staging: the last weight round of NI = 4 must hold 128 chunks");
+    static_assert(!FAST || TAPS != 4 || NI != 4 || (KC * 4 * (NB / 4)) % 256 == 0, "FAST staging, 2x2 form: whole weight rounds");
     const int aH = a.H, aW = a.W;
     // descriptor of the source a K-block reads, from SCALAR selects of base pointer and size (selecting between whole
     // descriptors ends in a scratch table + waterfall loop)
@@ -381,7 +396,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     auto dma_fast = [=](int j, const KB k, const __amdgpu_buffer_rsrc_t rs_k, unsigned soff_in, unsigned soff_w, float* buf) __attribute__((always_inline)) {
         if (j < NWR) {
             const unsigned soff = soff_w;
-            const bool lastw = NI == 4 && (j == NWR - 1);
+            const bool lastw = TAPS == 9 && NI == 4 && (j == NWR - 1);
             const unsigned vo = __builtin_elementwise_add_sat((unsigned)(lastw ? vw_last : vw_full + j * 4096), soff);
             float* dst = buf + INF + (lastw ? (1024 + (wv & 1) * 64) * 4 : (j * 256 + wv * 64) * 4);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, 0, 0, 0);
@@ -424,6 +439,10 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
             addrU[s] = baseU + c * PLANE_U + ((dy + ky - 1) >> 1) * SU + ((dx + kx - 1) >> 1);
         }
     }
+    // 2x2 form: k = 4*step + q -> channel = step, tap (a, b) = (q >> 1, q & 1): one address, the channel is an immediate
+    const int addr4 = ((TW == 16) ? (wv * 4 + ((col & 3) >> 1)) * S + 2 * (col >> 2) + (col & 1) + XO
+                                  : wv * PH * S + ((col & 3) >> 1) * S + 2 * (col >> 2) + (col & 1) + XO) +
+                      ((q >> 1) + (cls >> 1)) * S + (q & 1) + (cls & 1);
     const int boff = q * NB + col * NI;  // weight slab row k = [16 channels][NI tiles]: a lane's NI values are contiguous
 
     f32x4 acc[4][NI];
@@ -431,6 +450,31 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (a.acc_init) {  // continue the chains an EPI_UP4 launch began: register `reg` of a lane IS parity class `reg` of its 2x2 window
+        const int Hs = a.H >> 1, Ws = a.W >> 1;
+        const size_t cstride = (size_t)a.n_nblk * NB * Hs * Ws;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            int img, py0, px0;
+            if (TW == 16) {
+                const int sidx = wv * 4 + mi;
+                img = 0; py0 = 2 * (sidx >> 1); px0 = 8 * (sidx & 1) + 2 * q;
+            } else {
+                img = wv; py0 = 2 * mi; px0 = 2 * q;
+            }
+            const int b = bgrp * NIMG + img;
+            const int gy0 = tyi * TH + py0, gx0 = txi * TW + px0;
+            if (b >= a.B || gy0 >= a.H || gx0 >= a.W) continue;
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const float* p = a.acc_init + (((size_t)b * 4) * a.n_nblk * NB + nblk * NB + ni * 16 + col) * ((size_t)Hs * Ws) + (gy0 >> 1) * Ws + (gx0 >> 1);
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    if (gy0 + (reg >> 1) < a.H && gx0 + (reg & 1) < a.W) acc[mi][ni][reg] = p[reg * cstride];
+            }
+        }
+    }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -441,7 +485,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
         float* const cur = lds + (kb & 1) * BUF;
         float* const nxt = lds + ((kb & 1) ^ 1) * BUF;
         const KB nxt_kb = kb_next(cur_kb);
-        const int wrow_nxt = wrow + cur_kb.kc * 9;
+        const int wrow_nxt = wrow + cur_kb.kc * TAPS;
         const bool more_kb = (kb + 1 < nkb) && EIG_ABLATE != 1;
         const __amdgpu_buffer_rsrc_t rs_nxt = rsrc_of(nxt_kb.s);
         // byte offsets of the next K-block inside its source / the weight slab; 2^31 = `nothing to stage` (out of range)
@@ -463,14 +507,14 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
                 // second period only for a full K-block (wave-uniform).  FAST: always -- a 4-channel K-block's upper
                 // channels are staged as zeros (out of range), so the extra steps add exact zeros, and the straight-line
                 // body keeps the DMA instructions free of control flow
-                if (FAST || st < 9 || cur_kb.kc > 4) {
+                if (FAST || (TAPS == 9 ? (st < 9 || cur_kb.kc > 4) : st < cur_kb.kc)) {
                     const int per = st / 9, s9 = st % 9;
                     float av[4], bv[NI];
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) {
                         const int moff = UP ? ((TW == 16) ? ((mi >> 1) * SU + (mi & 1) * 4) : (mi * SU))
                                             : ((TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S));
-                        av[mi] = in_lds[ad[s9] + per * 4 * PL + moff];
+                        av[mi] = (TAPS == 9) ? in_lds[ad[s9] + per * 4 * PL + moff] : in_lds[addr4 + st * PL + moff];
                     }
                     if (NI == 4) {  // one ds_read_b128
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(w_lds + st * 4 * NB);
@@ -540,6 +584,16 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
                 const int o = nblk * NB + ni * 16 + col;
                 if (o >= a.Cout) continue;
                 float* dst = a.raw + ((size_t)b * a.Cout + o) * HW;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);
+                    if (gy < a.H && gx < a.W) dst[gy * a.W + gx] = acc[mi][ni][reg];
+                }
+            }
+        } else if (EPI == EPI_UP4) {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                float* dst = a.raw + (((size_t)b * 4 + cls) * a.n_nblk * NB + nblk * NB + ni * 16 + col) * HW;
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);

@@ -62,6 +62,9 @@ struct Layer {
     // is 0 as well.  Their terms fma(0, w, acc) leave the chain untouched, so the first step runs the same chains over the
     // non-zero sources only: ConvA reads the first half of E_{l-1}, the ConvLSTM the first half of E_l and R_{l+1}.
     ConvOp convA_t0, lstm_t0;
+    // The unpooled source R_{l+1} of the ConvLSTM in its 2x2 form (conv_mfma.h: EPI_UP4), launched at the resolution of
+    // layer l+1 ahead of the ConvLSTM launch, which starts its accumulators from the result (eigen_engine::d_raw4).
+    ConvOp up4;
 };
 
 template <typename T> struct DevBuf {
@@ -107,6 +110,8 @@ struct eigen_engine {
     int *d_ncorners = nullptr, *d_counts = nullptr;
     double* d_fitness = nullptr;
     float* d_zeros = nullptr;  // DMA source for zero fill (conv_mfma.h)
+    float* d_raw4 = nullptr;   // partial chains of the unpooled source, [B][4 classes][n_nblk*NB][H/2][W/2], reused by all layers
+    size_t raw4_floats = 0;
     // timing
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pev0 = nullptr, pev1 = nullptr;
@@ -173,6 +178,49 @@ static std::vector<float> pack_weights(const ConvOp& op, const float* const srcw
     return out;
 }
 
+// Weights of the 2x2 form of `unpool x2 -> conv3x3` for parity class (py, px) of the output pixel (oracle/eig_oracle.c:
+// presum_up_weights states the same rule).  Output row 2Y+py reads source rows Y-1, Y, Y (py = 0) or Y, Y, Y+1 (py = 1): tap a
+// stands for source row Y+a-1+py and collects ky in {0} / {1,2} (py = 0) or {0,1} / {2} (py = 1); columns likewise.  The
+// collected weights are added in fp32 in (ky, kx) row-major order starting from the first one.
+static float presum_up_weight(const float* w9, int py, int px, int a, int b)
+{
+    const int ky0 = py ? (a ? 2 : 0) : (a ? 1 : 0), ky1 = py ? (a ? 2 : 1) : (a ? 2 : 0);
+    const int kx0 = px ? (b ? 2 : 0) : (b ? 1 : 0), kx1 = px ? (b ? 2 : 1) : (b ? 2 : 0);
+    volatile float s = 0.0f;  // volatile: one fp32 rounding per addition whatever the host compiler's flags
+    bool first = true;
+    for (int ky = ky0; ky <= ky1; ++ky)
+        for (int kx = kx0; kx <= kx1; ++kx) {
+            if (first) { s = w9[ky * 3 + kx]; first = false; }
+            else s = s + w9[ky * 3 + kx];
+        }
+    return s;
+}
+
+// Pack the 2x2-form weights of ONE unpooled source into [4 classes][n_nblk][krows = Cpad*4][NB]; row = (channel, a, b);
+// column order as pack_weights (lstm: 0 plain, 1 four 16-channel gate tiles, 2 packed gates for C <= 4).
+static std::vector<float> pack_weights_up4(const ConvOp& op, const float* const srcw[4], int lstm)
+{
+    const int NB = op.NI * 16;
+    const int Cin = op.src_C[0], Cp = pad4(Cin);
+    std::vector<float> out((size_t)4 * op.n_nblk * op.krows * NB, 0.0f);
+    for (int cls = 0; cls < 4; ++cls)
+        for (int nb = 0; nb < op.n_nblk; ++nb)
+            for (int c = 0; c < Cin; ++c)
+                for (int tap = 0; tap < 4; ++tap) {
+                    float* dst = &out[(((size_t)cls * op.n_nblk + nb) * op.krows + (size_t)c * 4 + tap) * NB];
+                    for (int n = 0; n < NB; ++n) {
+                        int g = 0, o;
+                        if (lstm == 1) { g = n / 16; o = nb * 16 + (n % 16); }
+                        else if (lstm == 2) { g = n / 4; o = n % 4; }
+                        else o = nb * NB + n;
+                        if (o >= op.Cout) continue;
+                        dst[(n % 16) * op.NI + (n / 16)] = presum_up_weight(srcw[g] + ((size_t)o * Cin + c) * 9, cls >> 1, cls & 1, tap >> 1, tap & 1);
+                    }
+                }
+    (void)Cp;
+    return out;
+}
+
 template <int NI, int TW, int EPI, bool VEC> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
     constexpr int lds = conv_lds_bytes<NI, TW, VEC>();
@@ -219,7 +267,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     a.nsrc = op.nsrc;
     for (int s = 0; s < op.nsrc; ++s) { a.src[s].C = op.src_C[s]; a.src[s].Cpad = pad4(op.src_C[s]); a.src[s].up = op.src_up[s]; a.src[s].Ct = op.src_Ct[s] ? op.src_Ct[s] : op.src_C[s]; }
     const int ntile = ((batch + NIMG - 1) / NIMG) * a.tilesX * a.tilesY;
-    const int grid = op.n_nblk * ((ntile + 7) / 8) * 8;  // XCD-aware tile map (conv_mfma.h): tiles padded to a multiple of 8
+    const int grid = op.n_nblk * (op.epi == EPI_UP4 ? 4 : 1) * ((ntile + 7) / 8) * 8;  // XCD-aware tile map (conv_mfma.h): tiles padded to a multiple of 8
     // 16-byte DMA staging needs chunk-aligned rows: W % 4 == 0, and W % 8 == 0 when a half-resolution source is read
     bool vec = (op.W % 4) == 0;
     for (int s = 0; s < op.nsrc; ++s) if (op.src_up[s] && ((op.W % 8) != 0 || (op.H % 2) != 0)) vec = false;
@@ -249,6 +297,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         case EPI_LSTM_PACKED: r = (op.TW == 16) ? launch_inst<1, 16, EPI_LSTM_PACKED>(a, grid, st, vec) : launch_inst<1, 8, EPI_LSTM_PACKED>(a, grid, st, vec); break;
         case EPI_CONVA: r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st, vec); break;
         case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st, vec); break;
+        case EPI_UP4: r = launch_epi<EPI_UP4>(op.NI, op.TW, a, grid, st, vec); break;
         default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec); break;
     }
 #if EIG_TIMING
@@ -293,14 +342,14 @@ int eigen_destroy(eigen_engine* e)
     (void)hipSetDevice(e->cfg.device);
     for (int l = 0; l < e->L; ++l) {
         Layer& y = e->layer[l];
-        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw, y.convA_t0.d_wpk, y.lstm_t0.d_wpk};
+        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw, y.convA_t0.d_wpk, y.lstm_t0.d_wpk, y.up4.d_wpk};
         for (float* p : ptrs) if (p) (void)hipFree(p);
     }
     if (e->d_planes) (void)hipFree(e->d_planes);
     e->g_node_off.release(); e->g_edge_off.release(); e->g_edge_src.release(); e->g_out_node.release();
     e->g_node_act.release(); e->g_node_bias.release(); e->g_node_resp.release(); e->g_edge_w.release();
     void* misc[] = {e->d_images, e->d_frames, e->d_eig, e->d_cand, e->d_corners, e->d_next, e->d_vectors, e->d_status,
-                    e->d_ncorners, e->d_counts, e->d_fitness, e->d_zeros};
+                    e->d_ncorners, e->d_counts, e->d_fitness, e->d_zeros, e->d_raw4};
     for (void* p : misc) if (p) (void)hipFree(p);
     for (int i = 0; i < 2; ++i)
         for (int l = 0; l < FLOW_MAX_LEVELS; ++l) if (e->d_gray[i][l]) (void)hipFree(e->d_gray[i][l]);
@@ -437,27 +486,22 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             std::vector<float> pk0 = pack_weights(t0, sw, 0);
             if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d, step 0)", l);
         }
-        // ---- ConvLSTM_l: sources E_l, unpooled R_{l+1}, h_l ; 4 gates fused on N
+        // ---- ConvLSTM_l: 4 gates fused on N.  Chain order: unpooled R_{l+1} in its 2x2 form (own launch, Layer::up4), E_l, h_l
         {
             ConvOp& op = y.lstm;
             { float *k0 = op.d_wpk, *k1 = op.d_wraw; op = ConvOp(); op.d_wpk = k0; op.d_wraw = k1; }  // keep the allocations: upload() frees them
             op.epi = EPI_LSTM; op.layer = l; op.H = y.H; op.W = y.W; op.Cout = C;
-            op.nsrc = 0;
-            op.src_C[op.nsrc] = 2 * C; op.src_up[op.nsrc] = 0; op.nsrc++;
-            if (l < L - 1) { op.src_C[op.nsrc] = e->layer[l + 1].C; op.src_up[op.nsrc] = 1; op.nsrc++; }
-            op.src_C[op.nsrc] = C; op.src_up[op.nsrc] = 0; op.nsrc++;
+            op.nsrc = 2;
+            op.src_C[0] = 2 * C; op.src_C[1] = C;
             choose_ni(C, true, &op.NI, &op.n_nblk);
             if (C <= 4) { op.epi = EPI_LSTM_PACKED; op.NI = 1; op.n_nblk = 1; }  // 4 gates x <=4 channels in one MFMA tile
+            const int lstm_mode = (op.epi == EPI_LSTM_PACKED) ? 2 : 1;
             op.TW = choose_tw(op.H, op.W);
             op.krows = 0; op.macs = 0;
             for (int s = 0; s < op.nsrc; ++s) { op.krows += pad4(op.src_C[s]) * 9; op.macs += (double)y.H * y.W * 4 * C * op.src_C[s] * 9; }
             const float* sw[3][4];
-            int s = 0;
-            for (int g = 0; g < 4; ++g) sw[s][g] = wx0[g];
-            s++;
-            if (l < L - 1) { for (int g = 0; g < 4; ++g) sw[s][g] = wx1[g]; s++; }
-            for (int g = 0; g < 4; ++g) sw[s][g] = wh[g];
-            std::vector<float> pk = pack_weights(op, sw, op.epi == EPI_LSTM_PACKED ? 2 : 1);
+            for (int g = 0; g < 4; ++g) { sw[0][g] = wx0[g]; sw[1][g] = wh[g]; sw[2][g] = nullptr; }
+            std::vector<float> pk = pack_weights(op, sw, lstm_mode);
             std::vector<float> bias(4 * (size_t)C);
             for (int g = 0; g < 4; ++g) memcpy(&bias[(size_t)g * C], bh[g], sizeof(float) * C);
             const size_t chw = (size_t)C * y.H * y.W;
@@ -465,15 +509,30 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             for (int g = 0; g < 3; ++g) memcpy(&pp[g * chw], peep[g], sizeof(float) * chw);
             if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.bias_lstm, bias.data(), bias.size()) || upload(&y.peep, pp.data(), pp.size()))
                 return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d)", l);
-            ConvOp& t0 = y.lstm_t0;  // step 0: first half of E_l and R_{l+1}; h_l = 0 is not read (Layer::lstm_t0)
+            ConvOp& t0 = y.lstm_t0;  // step 0: first half of E_l only; h_l = 0 is not read (Layer::lstm_t0)
             { float* k0 = t0.d_wpk; t0 = op; t0.d_wpk = k0; t0.d_wraw = nullptr; }
-            t0.nsrc = op.nsrc - 1;
-            t0.src_C[0] = C; t0.src_Ct[0] = 2 * C;
-            t0.src_C[t0.nsrc] = 0; t0.src_up[t0.nsrc] = 0;
-            t0.krows = 0; t0.macs = 0;
-            for (int s2 = 0; s2 < t0.nsrc; ++s2) { t0.krows += pad4(t0.src_C[s2]) * 9; t0.macs += (double)y.H * y.W * 4 * C * t0.src_C[s2] * 9; }
-            std::vector<float> pk0 = pack_weights(t0, sw, op.epi == EPI_LSTM_PACKED ? 2 : 1);
+            t0.nsrc = 1;
+            t0.src_C[0] = C; t0.src_Ct[0] = 2 * C; t0.src_C[1] = 0;
+            t0.krows = pad4(C) * 9; t0.macs = (double)y.H * y.W * 4 * C * C * 9;
+            std::vector<float> pk0 = pack_weights(t0, sw, lstm_mode);
             if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, step 0)", l);
+            ConvOp& u = y.up4;
+            { float* k0 = u.d_wpk; u = ConvOp(); u.d_wpk = k0; }
+            if (l < L - 1) {  // R_{l+1}, at ITS resolution; columns = the ConvLSTM's
+                const Layer& yu = e->layer[l + 1];
+                u.epi = EPI_UP4; u.layer = l; u.nsrc = 1; u.src_C[0] = e->layer[l + 1].C; u.H = yu.H; u.W = yu.W; u.Cout = C;
+                u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W);
+                u.krows = pad4(u.src_C[0]) * 4;
+                u.macs = (double)y.H * y.W * 4 * C * u.src_C[0] * 4;  // 4 taps per output pixel and channel instead of 9
+                std::vector<float> pku = pack_weights_up4(u, wx1, lstm_mode);
+                if (upload(&u.d_wpk, pku.data(), pku.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, unpooled source)", l);
+                const size_t need = (size_t)e->B * 4 * u.n_nblk * u.NI * 16 * u.H * u.W;
+                if (need > e->raw4_floats) {
+                    if (e->d_raw4) { (void)hipFree(e->d_raw4); e->d_raw4 = nullptr; e->raw4_floats = 0; }
+                    if (hipMalloc((void**)&e->d_raw4, need * sizeof(float)) != hipSuccess) return fail(EIGEN_ERR_HIP, "hipMalloc(%zu) for the unpooled-source partial chains", need * sizeof(float));
+                    e->raw4_floats = need;
+                }
+            }
         }
         // ---- ConvP_l
         {
@@ -639,8 +698,15 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
                 ConvArgs a;
                 memset(&a, 0, sizeof(a));
                 int s = 0;
+                if (l < L - 1) {  // R_{l+1} of THIS step, 2x2 form -> partial chains
+                    ConvArgs u;
+                    memset(&u, 0, sizeof(u));
+                    u.src[0].ptr = e->layer[l + 1].h[cur ^ 1];
+                    u.raw = e->d_raw4;
+                    HIPCHK(launch_conv(e, y.up4, u, batch, st));
+                    a.acc_init = e->d_raw4;
+                }
                 a.src[s++].ptr = y.E;
-                if (l < L - 1) a.src[s++].ptr = e->layer[l + 1].h[cur ^ 1];  // R_{l+1} of THIS step
                 const bool t0 = (t == 0 && skip_zero_sources);
                 if (!t0) a.src[s++].ptr = y.h[cur];
                 a.bias = y.bias_lstm; a.c_state = y.c; a.h_out = y.h[cur ^ 1]; a.peep = y.peep;
@@ -791,8 +857,8 @@ int eigen_get_timings(eigen_engine* e, double* h_ms6)
     if (!e || !h_ms6) return fail(EIGEN_ERR_INVALID, "null argument");
     double conv = 0; int launches = 0;
     for (int l = 0; l < e->L; ++l) {
-        conv += e->layer[l].convA.ms + e->layer[l].lstm.ms + e->layer[l].convP.ms + e->layer[l].convA_t0.ms + e->layer[l].lstm_t0.ms;
-        launches += e->layer[l].convA.launches + e->layer[l].lstm.launches + e->layer[l].convP.launches + e->layer[l].convA_t0.launches + e->layer[l].lstm_t0.launches;
+        conv += e->layer[l].convA.ms + e->layer[l].lstm.ms + e->layer[l].convP.ms + e->layer[l].convA_t0.ms + e->layer[l].lstm_t0.ms + e->layer[l].up4.ms;
+        launches += e->layer[l].convA.launches + e->layer[l].lstm.launches + e->layer[l].convP.launches + e->layer[l].convA_t0.launches + e->layer[l].lstm_t0.launches + e->layer[l].up4.launches;
     }
     for (int i = 0; i < 4; ++i) h_ms6[i] = e->ms[i];
     h_ms6[4] = conv; h_ms6[5] = launches;
@@ -808,8 +874,8 @@ int eigen_conv_profile(eigen_engine* e, int32_t enable, int32_t reset, double* h
     e->profile_convs = enable != 0;
     int n = 0;
     for (int l = 0; l < e->L; ++l) {
-        ConvOp* ops[5] = {l > 0 ? &e->layer[l].convA : nullptr, &e->layer[l].lstm, &e->layer[l].convP,
-                          l > 0 ? &e->layer[l].convA_t0 : nullptr, &e->layer[l].lstm_t0};
+        ConvOp* ops[6] = {l > 0 ? &e->layer[l].convA : nullptr, &e->layer[l].lstm, &e->layer[l].convP,
+                          l > 0 ? &e->layer[l].convA_t0 : nullptr, &e->layer[l].lstm_t0, l < e->L - 1 ? &e->layer[l].up4 : nullptr};
         for (ConvOp* op : ops) {
             if (!op) continue;
             if (h_out && n < max_ops) {
@@ -830,23 +896,53 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
     if (!e || !d_src || !cin || !up || !h_w || !d_out) return fail(EIGEN_ERR_INVALID, "null argument");
     if (n_src < 1 || n_src > 3) return fail(EIGEN_ERR_INVALID, "n_src must be 1..3");
     HIPCHK(hipSetDevice(e->cfg.device));
+    // canonical chain order: the unpooled source first, in its 2x2 form (EPI_UP4 launch at the source
+    // resolution), then the full-resolution sources in list order
+    int n_up = 0, i_up = -1, n_full = 0;
+    for (int s = 0; s < n_src; ++s) { if (up[s]) { ++n_up; i_up = s; } else ++n_full; }
+    if (n_up > 1 || n_full < 1) return fail(EIGEN_ERR_INVALID, "at most one unpooled source and at least one full-resolution source");
+    if (n_up && ((H | W) & 1)) return fail(EIGEN_ERR_INVALID, "an unpooled source needs even H and W");
     ConvOp op;
-    op.epi = EPI_RAW; op.nsrc = n_src; op.H = H; op.W = W; op.Cout = cout;
+    op.epi = EPI_RAW; op.nsrc = 0; op.H = H; op.W = W; op.Cout = cout;
     choose_ni(cout, false, &op.NI, &op.n_nblk);
     op.TW = choose_tw(H, W);
     op.krows = 0;
     const float* sw[3][4] = {{nullptr}, {nullptr}, {nullptr}};
-    for (int s = 0; s < n_src; ++s) { op.src_C[s] = cin[s]; op.src_up[s] = up[s]; op.krows += pad4(cin[s]) * 9; sw[s][0] = h_w[s]; }
+    ConvArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int s = 0; s < n_src; ++s) {
+        if (up[s]) continue;
+        op.src_C[op.nsrc] = cin[s]; op.krows += pad4(cin[s]) * 9; sw[op.nsrc][0] = h_w[s]; a.src[op.nsrc].ptr = d_src[s];
+        op.nsrc++;
+    }
     std::vector<float> pk = pack_weights(op, sw, 0);
     HIPCHK(hipMalloc((void**)&op.d_wpk, pk.size() * sizeof(float)));
     HIPCHK(hipMemcpy(op.d_wpk, pk.data(), pk.size() * sizeof(float), hipMemcpyHostToDevice));
-    ConvArgs a;
-    memset(&a, 0, sizeof(a));
-    for (int s = 0; s < n_src; ++s) a.src[s].ptr = d_src[s];
     a.raw = d_out;
+    ConvOp u;
+    ConvArgs ua;
+    memset(&ua, 0, sizeof(ua));
+    float* d_raw4 = nullptr;
+    if (n_up) {
+        u.epi = EPI_UP4; u.nsrc = 1; u.src_C[0] = cin[i_up]; u.H = H / 2; u.W = W / 2; u.Cout = cout;
+        u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W);
+        u.krows = pad4(cin[i_up]) * 4;
+        const float* uw[4] = {h_w[i_up], nullptr, nullptr, nullptr};
+        std::vector<float> pku = pack_weights_up4(u, uw, 0);
+        HIPCHK(hipMalloc((void**)&u.d_wpk, pku.size() * sizeof(float)));
+        HIPCHK(hipMemcpy(u.d_wpk, pku.data(), pku.size() * sizeof(float), hipMemcpyHostToDevice));
+        HIPCHK(hipMalloc((void**)&d_raw4, (size_t)batch * 4 * u.n_nblk * u.NI * 16 * u.H * u.W * sizeof(float)));
+        ua.src[0].ptr = d_src[i_up];
+        ua.raw = d_raw4;
+        a.acc_init = d_raw4;
+    }
+    auto launch_both = [&]() -> hipError_t {
+        if (n_up) { hipError_t ru = launch_conv(e, u, ua, batch, (hipStream_t)stream); if (ru != hipSuccess) return ru; }
+        return launch_conv(e, op, a, batch, (hipStream_t)stream);
+    };
     const bool prof = e->profile_convs;
     e->profile_convs = false;
-    hipError_t r = launch_conv(e, op, a, batch, (hipStream_t)stream);  // also the warm-up of a timed run
+    hipError_t r = launch_both();  // also the warm-up of a timed run
 #if EIG_TIMING
     {
         const int TH_ = (op.TW == 16) ? 16 : 8, NIMG_ = 256 / (TH_ * op.TW);
@@ -869,7 +965,7 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
 #endif
     if (iters > 0 && r == hipSuccess) {
         (void)hipEventRecord(e->pev0, (hipStream_t)stream);
-        for (int i = 0; i < iters && r == hipSuccess; ++i) r = launch_conv(e, op, a, batch, (hipStream_t)stream);
+        for (int i = 0; i < iters && r == hipSuccess; ++i) r = launch_both();
         (void)hipEventRecord(e->pev1, (hipStream_t)stream);
         (void)hipEventSynchronize(e->pev1);
         float ms = 0;
@@ -879,6 +975,8 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
     e->profile_convs = prof;
     hipError_t r2 = hipStreamSynchronize((hipStream_t)stream);
     (void)hipFree(op.d_wpk);
+    if (u.d_wpk) (void)hipFree(u.d_wpk);
+    if (d_raw4) (void)hipFree(d_raw4);
     if (r != hipSuccess) return fail(EIGEN_ERR_HIP, "conv launch: %s", hipGetErrorString(r));
     if (r2 != hipSuccess) return fail(EIGEN_ERR_HIP, "conv sync: %s", hipGetErrorString(r2));
     return EIGEN_OK;

@@ -221,13 +221,13 @@ class Engine:
         return dict(render_ms=ms[0], prednet_ms=ms[1], flow_ms=ms[2], score_ms=ms[3], conv_ms=ms[4], conv_launches=int(ms[5]))
 
     def conv_profile(self, enable, reset=True):
-        out = np.zeros((5 * MAX_LAYERS, 8), dtype=np.float64)
+        out = np.zeros((6 * MAX_LAYERS, 8), dtype=np.float64)
         n = ctypes.c_int32(0)
         _check(self.lib.eigen_conv_profile(self._h, ctypes.c_int32(int(enable)), ctypes.c_int32(int(reset)), _ptr(out),
                                            ctypes.c_int32(out.shape[0]), ctypes.byref(n)))
         rows = []
         for r in out[:n.value]:
-            rows.append(dict(layer=int(r[0]), epi={1: "lstm", 2: "convA", 3: "convP", 4: "lstm"}.get(int(r[1]) & 15, "raw"), step0=bool(int(r[1]) >> 4),
+            rows.append(dict(layer=int(r[0]), epi={1: "lstm", 2: "convA", 3: "convP", 4: "lstm", 5: "up4"}.get(int(r[1]) & 15, "raw"), step0=bool(int(r[1]) >> 4),
                              NI=int(r[2]), TW=int(r[3]),
                              launches=int(r[4]), ms=float(r[5]), flops_per_image=float(r[6]), n_nblk=int(r[7])))
         return rows

@@ -3,32 +3,52 @@ import numpy as np
 import pytest
 
 
+def _fma32(v, w, acc):  # fused multiply-add: exact product, one rounding
+    return np.float32(np.float64(v) * np.float64(w) + np.float64(acc))
+
+
 def test_conv_chain_is_the_documented_fma_chain(oracle_lib):
+    """the unpooled source first, in its 2x2 form with pre-summed weights (4 terms per channel), then the
+    full-resolution sources as 9-term (c, ky, kx) chains; and that 2x2 form IS unpool -> conv3x3 up to summation order."""
     rng = np.random.default_rng(0)
-    H, W = 6, 7
-    srcs = [rng.normal(0, 1, (5, H, W)).astype(np.float32), rng.normal(0, 1, (3, H // 2 + 0, W // 2 + 0)).astype(np.float32)]
-    srcs[1] = rng.normal(0, 1, (3, 3, 4)).astype(np.float32)  # half resolution of 6x8 -> use W=8
     H, W = 6, 8
-    srcs[0] = rng.normal(0, 1, (5, H, W)).astype(np.float32)
+    srcs = [rng.normal(0, 1, (5, H, W)).astype(np.float32), rng.normal(0, 1, (3, H // 2, W // 2)).astype(np.float32)]
     ws = [rng.normal(0, 0.3, (4, 5, 3, 3)).astype(np.float32), rng.normal(0, 0.3, (4, 3, 3, 3)).astype(np.float32)]
     got = oracle_lib.conv_chain(srcs, [0, 1], ws, H, W)
     ref = np.zeros((4, H, W), np.float32)
+    plain = np.zeros((4, H, W), np.float64)  # unpool x2 -> conv3x3 + conv3x3 in float64
+    rows = {0: ([0], [1, 2]), 1: ([0, 1], [2])}  # parity -> 3x3 taps collected by 2x2 tap 0 / 1
     for o in range(4):
         for y in range(H):
             for x in range(W):
                 acc = np.float32(0)
-                for s, (src, w, up) in enumerate(zip(srcs, ws, [0, 1])):
+                py, px, Y, X = y & 1, x & 1, y >> 1, x >> 1
+                for c in range(srcs[1].shape[0]):
+                    for a in range(2):
+                        for b in range(2):
+                            wsum = None
+                            for ky in rows[py][a]:
+                                for kx in rows[px][b]:
+                                    wsum = ws[1][o, c, ky, kx] if wsum is None else np.float32(wsum + ws[1][o, c, ky, kx])
+                            sy, sx = Y + a - 1 + py, X + b - 1 + px
+                            v = srcs[1][c, sy, sx] if (0 <= sy < H // 2 and 0 <= sx < W // 2) else np.float32(0)
+                            acc = _fma32(v, wsum, acc)
+                for c in range(srcs[0].shape[0]):
+                    for ky in range(3):
+                        for kx in range(3):
+                            yy, xx = y + ky - 1, x + kx - 1
+                            v = srcs[0][c, yy, xx] if (0 <= yy < H and 0 <= xx < W) else np.float32(0)
+                            acc = _fma32(v, ws[0][o, c, ky, kx], acc)
+                ref[o, y, x] = acc
+                for src, w, up in zip(srcs, ws, [0, 1]):
                     for c in range(src.shape[0]):
                         for ky in range(3):
                             for kx in range(3):
                                 yy, xx = y + ky - 1, x + kx - 1
-                                v = np.float32(0)
                                 if 0 <= yy < H and 0 <= xx < W:
-                                    v = src[c, yy >> up, xx >> up]
-                                # fused multiply-add: exact product, one rounding
-                                acc = np.float32(np.float64(v) * np.float64(w[o, c, ky, kx]) + np.float64(acc))
-                ref[o, y, x] = acc
+                                    plain[o, y, x] += np.float64(src[c, yy >> up, xx >> up]) * np.float64(w[o, c, ky, kx])
     assert np.array_equal(got, ref)
+    assert np.max(np.abs(got - plain)) < 5e-6  # same function, fp32 summation order aside
 
 
 def test_det_math32_accuracy(oracle_lib):
