@@ -9,15 +9,19 @@
 //
 // Canonical arithmetic: every output is ONE fp32 fma chain over k = (source, channel, ky, kx);
 // the f32 MFMA is exactly such a chain in k order, so the result is bit-identical to oracle/eig_oracle.c.
+// The ConvLSTM's unpooled source R_{l+1} heads the chain in its 2x2 form: the 3x3 window of an output pixel covers only
+// 2x2 distinct pixels of the half-resolution source (which ones depends on the pixel's parity class), so the nine weights
+// are pre-summed per class on the host and an EPI_UP4 launch AT THE SOURCE RESOLUTION runs 4 terms per channel instead of
+// 9 for each class; the ConvLSTM launch that follows loads the partial chains into its accumulators (ConvArgs::acc_init:
+// the four registers of a lane are the four classes of one source pixel) and continues with E_l and h_l.
 // Channel counts are padded to multiples of 4 with zero weights AFTER the real channels of each source, which
 // appends exact no-op terms (fma(a, 0, acc) == acc) and leaves the chain of real terms untouched.
 //
 // Per K-block (KC = 8 channels of one source) both operands travel global -> LDS by LDS-DMA (buffer_load ... lds,
 // 16 B per lane; no staging registers, no ds_write pass) into the buffer NOT being computed on:
-//   - the input tile with its halo as ALIGNED 16-byte chunks of the source rows, [KC][NIMG][TH+2][TW+8] fp32 (an
-//     unpooled R_{l+1} source is staged at its own resolution, the x2 nearest unpooling happens in the gather
-//     address); buffer descriptors make the DMA free of per-lane address arithmetic and turn out-of-image /
-//     padded-channel slots into hardware zero fill;
+//   - the input tile with its halo as ALIGNED 16-byte chunks of the source rows, [KC][NIMG][TH+2][TW+8] fp32; buffer
+//     descriptors make the DMA free of per-lane address arithmetic and turn out-of-image / padded-channel slots into
+//     hardware zero fill;
 //   - the weight slab [KC*9][16 channels][NI tiles] fp32 (a lane's NI values of a row are one ds_read_b128).
 // The DMA instructions of K-block k+1 are interleaved with the KC*9/4 = 18 MFMA steps of K-block k; one barrier per
 // K-block.  The A operand is gathered from the halo tile at (pixel + tap) -- im2col never exists in memory.  k advances
@@ -158,15 +162,15 @@ constexpr int KC = EIG_KC;  // channels per K-block
 template <int NI, int TW, bool VEC> constexpr bool conv_fast_dma() { return VEC && TW == 16 && KC == 8 && NI >= 3; }  // narrow tiles: the padding would cost a block per CU
 // weight area: NI == 4 keeps its exact 4.5 rounds (the half round is issued by all four waves, two of them repeating the
 // other two); narrower slabs are rounded up to whole rounds, the extra lanes fetch the following rows into the padding
-template <int NI, int TW, bool VEC> constexpr int conv_w_floats()
+template <int NI, int TW, bool VEC, int TAPS = 9> constexpr int conv_w_floats()
 {
-    return (conv_fast_dma<NI, TW, VEC>() && NI != 4) ? ((KC * 9 * NI * 4 + 255) / 256) * 1024 : KC * 9 * NI * 16;
+    return (conv_fast_dma<NI, TW, VEC>() && !(NI == 4 && TAPS == 9)) ? ((KC * TAPS * NI * 4 + 255) / 256) * 1024 : KC * TAPS * NI * 16;
 }
 template <int NI, int TW, bool VEC> constexpr int conv_in_floats()
 {
     return conv_fast_dma<NI, TW, VEC>() ? ((KC * TileGeom<TW, VEC>::PLANE / 4 + 255) / 256) * 1024 : KC * TileGeom<TW, VEC>::PLANE;
 }
-template <int NI, int TW, bool VEC> constexpr int conv_lds_bytes() { return 2 * (conv_in_floats<NI, TW, VEC>() + conv_w_floats<NI, TW, VEC>()) * 4; }
+template <int NI, int TW, bool VEC, int TAPS = 9> constexpr int conv_lds_bytes() { return 2 * (conv_in_floats<NI, TW, VEC>() + conv_w_floats<NI, TW, VEC, TAPS>()) * 4; }
 
 #ifndef EIG_TIMING
 #define EIG_TIMING 0  // measurement-only builds: per-wave s_memtime breakdown of the K loop into a.dbg
@@ -176,8 +180,11 @@ template <int NI, int TW, bool VEC> constexpr int conv_lds_bytes() { return 2 * 
 #endif
 constexpr int CONV_THREADS = 256;  // 4 waves per block
 
+#ifndef EIG_UP4_OCC
+#define EIG_UP4_OCC 3  // the 2x2-form pass: 8 KB of weights per K-block and a store-only epilogue leave room for a third block per CU
+#endif
 template <int NI, int TW, int EPI, bool VEC>
-__global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const ConvArgs a)
+__global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW == 16 && VEC) ? EIG_UP4_OCC : EIG_CONV_OCC) conv3x3_mfma(const ConvArgs a)
 {
     using G = TileGeom<TW, VEC>;
     constexpr int TH = G::TH, NIMG = G::NIMG, S = G::S, XO = G::XO, PH = G::PH, PLANE = G::PLANE;
@@ -192,7 +199,7 @@ __global__ void __launch_bounds__(CONV_THREADS, EIG_CONV_OCC) conv3x3_mfma(const
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool FAST = conv_fast_dma<NI, TW, VEC>();
     constexpr int INF = conv_in_floats<NI, TW, VEC>();  // floats of the input area (KC * PLANE, padded for FAST)
-    constexpr int BUF = INF + conv_w_floats<NI, TW, VEC>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
+    constexpr int BUF = INF + conv_w_floats<NI, TW, VEC, (EPI == EPI_UP4) ? 4 : 9>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;

@@ -223,7 +223,7 @@ static std::vector<float> pack_weights_up4(const ConvOp& op, const float* const 
 
 template <int NI, int TW, int EPI, bool VEC> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
-    constexpr int lds = conv_lds_bytes<NI, TW, VEC>();
+    constexpr int lds = conv_lds_bytes<NI, TW, VEC, (EPI == EPI_UP4) ? 4 : 9>();
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
