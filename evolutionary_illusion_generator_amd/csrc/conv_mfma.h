@@ -601,6 +601,12 @@ __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 float* dst = a.raw + (((size_t)b * 4 + cls) * a.n_nblk * NB + nblk * NB + ni * 16 + col) * HW;
+                if (VEC && gx0 + 1 < a.W) {  // W % 4 == 0, gx0 even: the two pixels of a window row are one aligned 8-byte store
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f32x2*>(dst + gy0 * a.W + gx0) = (f32x2){acc[mi][ni][0], acc[mi][ni][1]};
+                    if (gy0 + 1 < a.H) *reinterpret_cast<f32x2*>(dst + (gy0 + 1) * a.W + gx0) = (f32x2){acc[mi][ni][2], acc[mi][ni][3]};
+                    continue;
+                }
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);

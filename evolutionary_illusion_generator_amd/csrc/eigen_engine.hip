@@ -273,7 +273,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     for (int s = 0; s < op.nsrc; ++s) if (op.src_up[s] && ((op.W % 8) != 0 || (op.H % 2) != 0)) vec = false;
 #if EIG_TIMING
     unsigned long long* tl_dbg = nullptr;
-    if (getenv("EIGEN_TIMELINE") && op.epi == EPI_LSTM && ++op.tl_seen == 6) {  // a steady-state launch of every ConvLSTM op
+    if (getenv("EIGEN_TIMELINE") && (op.epi == EPI_LSTM || (op.epi == EPI_UP4 && op.NI == 4)) && ++op.tl_seen == 6) {  // a steady-state launch of every ConvLSTM op and 2x2-form pass
         (void)hipMalloc((void**)&tl_dbg, (size_t)grid * 32 * 8);
         (void)hipMemset(tl_dbg, 0, (size_t)grid * 32 * 8);
         a.dbg = tl_dbg;
@@ -306,7 +306,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         std::vector<unsigned long long> h((size_t)grid * 32);
         (void)hipMemcpy(h.data(), tl_dbg, h.size() * 8, hipMemcpyDeviceToHost);
         char name[256];
-        snprintf(name, sizeof(name), "%s/timeline_H%d_C%d.bin", getenv("EIGEN_TIMELINE"), op.H, op.Cout);
+        snprintf(name, sizeof(name), "%s/timeline_H%d_C%d%s.bin", getenv("EIGEN_TIMELINE"), op.H, op.Cout, op.epi == EPI_UP4 ? "_up4" : "");
         if (FILE* f = fopen(name, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
         (void)hipFree(tl_dbg);
         a.dbg = nullptr;
