@@ -12,8 +12,8 @@
 // The ConvLSTM's unpooled source R_{l+1} heads the chain in its 2x2 form: the 3x3 window of an output pixel covers only
 // 2x2 distinct pixels of the half-resolution source (which ones depends on the pixel's parity class), so the nine weights
 // are pre-summed per class on the host and an EPI_UP4 launch AT THE SOURCE RESOLUTION runs 4 terms per channel instead of
-// 9 for each class; the ConvLSTM launch that follows loads the partial chains into its accumulators (ConvArgs::acc_init:
-// the four registers of a lane are the four classes of one source pixel) and continues with E_l and h_l.
+// 9 for each class; the ConvLSTM launch that follows runs its own chain over E_l and h_l and adds the two (ConvArgs::acc_init:
+// the four registers of a lane are the four classes of one source pixel; one fp32 addition, as chainer adds its convolutions).
 // Channel counts are padded to multiples of 4 with zero weights AFTER the real channels of each source, which
 // appends exact no-op terms (fma(a, 0, acc) == acc) and leaves the chain of real terms untouched.
 //
@@ -87,8 +87,8 @@ struct ConvArgs {
     int tile_map;       // block -> tile order, see the kernel
     // EPI_RAW
     float* raw;         // [B][Cout][H][W];  EPI_UP4: [B][4 parity classes][n_nblk*NB][H][W]
-    // Partial chains of an unpooled source (written by an EPI_UP4 launch at HALF this resolution) the accumulators start
-    // from, [B][4][n_nblk*NB][H/2][W/2]; nullptr: start from 0.
+    // Chain of an unpooled source (written by an EPI_UP4 launch at HALF this resolution), [B][4][n_nblk*NB][H/2][W/2], added to
+    // this launch's chain with one fp32 addition after the K loop; nullptr: none.
     const float* acc_init;
     const float* zeros; // >= 64 zero bytes in device memory: DMA source for out-of-image / padded-channel positions
     unsigned long long* dbg;  // EIG_TIMING builds only: per-block cycle counters
@@ -416,6 +416,7 @@ __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(buf + (r * 256 + wv * 64) * 4), 16, (int)vo, 0, 0, 0);
     };
 
+    const unsigned long long t_setup = EIG_TIMING ? __builtin_readcyclecounter() : 0;  // slots and descriptors ready
     int nkb = 0;
     for (int s = 0; s < a.nsrc; ++s) nkb += (cpad_of(s) + KC - 1) / KC;
     KB cur_kb = kb_first();
@@ -458,9 +459,27 @@ __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (a.acc_init) {  // continue the chains an EPI_UP4 launch began: register `reg` of a lane IS parity class `reg` of its 2x2 window
+    const unsigned long long t_prewait = EIG_TIMING ? __builtin_readcyclecounter() : 0;  // first K-block issued, gather addresses ready
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // The chain of the unpooled source (an EPI_UP4 launch at half this resolution wrote it) is added to this launch's chain with
+    // one fp32 addition after the K loop.  Register `reg` of a lane is parity class `reg` of source pixel (gy0/2, gx0/2): four
+    // 4-byte loads per accumulator tile at the same offset of the four class planes, 16 cache lines per instruction.  Issued in
+    // one burst they saturate the wave's 63 outstanding vector-memory operations and the CU's address path (measured: 21K
+    // cycles in front of the first MFMA, scripts/timeline.py), so they are SPREAD over the MFMA steps of K-block 0, three or four
+    // per step, and land long before the K loop ends.
+    constexpr bool HAS_UP = (EPI == EPI_LSTM || EPI == EPI_LSTM_PACKED || EPI == EPI_RAW);  // operators that can have an unpooled source
+    constexpr int NUPL = HAS_UP ? 16 * NI : 0;  // loads per lane
+    f32x4 upc[4][HAS_UP ? NI : 1];
+    const bool has_up = HAS_UP && a.acc_init != nullptr;
+    int up_off[4];
+    const float* up_base = a.acc_init;
+    int up_hw = 0, up_cstride = 0;
+    if (has_up) {
         const int Hs = a.H >> 1, Ws = a.W >> 1;
-        const size_t cstride = (size_t)a.n_nblk * NB * Hs * Ws;
+        up_hw = Hs * Ws;
+        up_cstride = a.n_nblk * NB * up_hw;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi) {
             int img, py0, px0;
@@ -472,22 +491,19 @@ __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW
             }
             const int b = bgrp * NIMG + img;
             const int gy0 = tyi * TH + py0, gx0 = txi * TW + px0;
-            if (b >= a.B || gy0 >= a.H || gx0 >= a.W) continue;
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const float* p = a.acc_init + (((size_t)b * 4) * a.n_nblk * NB + nblk * NB + ni * 16 + col) * ((size_t)Hs * Ws) + (gy0 >> 1) * Ws + (gx0 >> 1);
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg)
-                    if (gy0 + (reg >> 1) < a.H && gx0 + (reg & 1) < a.W) acc[mi][ni][reg] = p[reg * cstride];
-            }
+            // element offset inside this wave's image block [4][n_nblk*NB][Hs][Ws] (the image is wave-uniform); windows outside
+            // the image read element 0 instead -- their accumulators are never stored
+            up_off[mi] = (b < a.B && gy0 < a.H && gx0 < a.W) ? ((nblk * NB + col) * up_hw + (gy0 >> 1) * Ws + (gx0 >> 1)) * 4 : 0;
         }
+        const int bw = __builtin_amdgcn_readfirstlane(bgrp * NIMG + (TW == 16 ? 0 : wv));
+        up_base = a.acc_init + (size_t)(bw < a.B ? bw : 0) * 4 * up_cstride;
     }
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    // buffer loads: the lane part of the address is one of FOUR byte offsets (up_off), the (tile, class) part a scalar -- with flat
+    // addresses the compiler hoists 64 loop-invariant 64-bit pointers out of the K loop (128 VGPRs, spilled)
+    const __amdgpu_buffer_rsrc_t rs_up = __builtin_amdgcn_make_buffer_rsrc((void*)up_base, 0, has_up ? 4 * up_cstride * 4 : 0, 0x00020000);
 
     unsigned long long t_mfma = 0, t_wait = 0, t_bar = 0, t_all0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
-    for (int kb = 0; kb < nkb; ++kb) {
+    auto kiter = [&](const int kb, auto kfirst_tag) __attribute__((always_inline)) {
         const unsigned long long tk0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
         float* const cur = lds + (kb & 1) * BUF;
         float* const nxt = lds + ((kb & 1) ^ 1) * BUF;
@@ -505,8 +521,9 @@ __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW
         // the operand gather is an immediate: the four A reads of a step pair up into two ds_read2_b32, no address VALU.
         const float* const in_lds = cur;
         const float* const w_lds = cur + INF + boff;
-        auto body = [&](auto up_tag) {
+        auto body = [&](auto up_tag, auto first_tag) {
             constexpr bool UP = decltype(up_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;  // K-block 0 of an operator with an unpooled-source chain: issue its loads
             constexpr int PL = UP ? PLANE_U : PLANE;
             const int* const ad = UP ? addrU : addrA;
 #pragma unroll
@@ -546,10 +563,21 @@ __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW
                     for (int j = 0; j < NOPS; ++j)
                         if (j * NSTEP / NOPS == st) dma_op(j, nxt_kb, wrow_nxt, nxt);
                 }
+                if constexpr (FIRST) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                            for (int reg = 0; reg < 4; ++reg)
+                                if (((mi * NI + ni) * 4 + reg) * NSTEP / NUPL == st)
+                                    upc[mi][ni][reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_up, up_off[mi], (ni * 16 * up_hw + reg * up_cstride) * 4, 0));
+                    __builtin_amdgcn_sched_barrier(0);  // keep them in their step: left alone the scheduler sinks all of them to the end of the K-block
+                }
             }
         };
-        if (VEC && cur_kb.up) body(std::true_type{});
-        else body(std::false_type{});
+        if (VEC && cur_kb.up) body(std::true_type{}, std::false_type{});
+        else body(std::false_type{}, kfirst_tag);
         wrow = wrow_nxt;
         cur_kb = nxt_kb;
         const unsigned long long tk1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
@@ -557,10 +585,22 @@ __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW
         const unsigned long long tk2 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
         __syncthreads();
         if (EIG_TIMING) { const unsigned long long tk3 = __builtin_readcyclecounter(); t_mfma += tk1 - tk0; t_wait += tk2 - tk1; t_bar += tk3 - tk2; }
+    };
+    // K-block 0 of an operator with an unpooled-source chain is peeled: its steps carry that chain's loads
+    int kb_begin = 0;
+    if constexpr (HAS_UP) {
+        if (has_up) { kiter(0, std::true_type{}); kb_begin = 1; }
     }
+    for (int kb = kb_begin; kb < nkb; ++kb) kiter(kb, std::false_type{});
     const unsigned long long t_loop1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
 
     // ---------------------------------------------------------------- epilogue
+    if (has_up) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < (HAS_UP ? NI : 1); ++ni) acc[mi][ni] = acc[mi][ni] + upc[mi][ni];
+    }
     const int HW = a.H * a.W;
     auto timeline_record = [&](unsigned long long t_mid) {  // measurement builds only (EIG_TIMING): per-wave timeline
         if (EIG_TIMING && a.dbg && lane == 0) {
@@ -569,7 +609,7 @@ __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
             unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wv) * 8;
             d[0] = t_entry; d[1] = t_all0; d[2] = t_loop1; d[3] = __builtin_readcyclecounter();
-            d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32); d[5] = t_mfma; d[6] = t_mid; d[7] = t_bar;
+            d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32); d[5] = t_mfma; d[6] = t_setup; d[7] = t_prewait; (void)t_mid; (void)t_bar;
         }
     };
 #pragma unroll

@@ -63,7 +63,7 @@ struct Layer {
     // non-zero sources only: ConvA reads the first half of E_{l-1}, the ConvLSTM the first half of E_l and R_{l+1}.
     ConvOp convA_t0, lstm_t0;
     // The unpooled source R_{l+1} of the ConvLSTM in its 2x2 form (conv_mfma.h: EPI_UP4), launched at the resolution of
-    // layer l+1 ahead of the ConvLSTM launch, which starts its accumulators from the result (eigen_engine::d_raw4).
+    // layer l+1 ahead of the ConvLSTM launch, which adds the result to its own chain (eigen_engine::d_raw4).
     ConvOp up4;
 };
 
@@ -486,7 +486,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             std::vector<float> pk0 = pack_weights(t0, sw, 0);
             if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d, step 0)", l);
         }
-        // ---- ConvLSTM_l: 4 gates fused on N.  Chain order: unpooled R_{l+1} in its 2x2 form (own launch, Layer::up4), E_l, h_l
+        // ---- ConvLSTM_l: 4 gates fused on N.  Chain over E_l, h_l + chain of the unpooled R_{l+1} in its 2x2 form (own launch, Layer::up4)
         {
             ConvOp& op = y.lstm;
             { float *k0 = op.d_wpk, *k1 = op.d_wraw; op = ConvOp(); op.d_wpk = k0; op.d_wraw = k1; }  // keep the allocations: upload() frees them
@@ -896,8 +896,8 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
     if (!e || !d_src || !cin || !up || !h_w || !d_out) return fail(EIGEN_ERR_INVALID, "null argument");
     if (n_src < 1 || n_src > 3) return fail(EIGEN_ERR_INVALID, "n_src must be 1..3");
     HIPCHK(hipSetDevice(e->cfg.device));
-    // canonical chain order: the unpooled source first, in its 2x2 form (EPI_UP4 launch at the source
-    // resolution), then the full-resolution sources in list order
+    // canonical arithmetic: one chain over the full-resolution sources in list order, plus the chain of the
+    // unpooled source in its 2x2 form (EPI_UP4 launch at the source resolution), one fp32 addition
     int n_up = 0, i_up = -1, n_full = 0;
     for (int s = 0; s < n_src; ++s) { if (up[s]) { ++n_up; i_up = s; } else ++n_full; }
     if (n_up > 1 || n_full < 1) return fail(EIGEN_ERR_INVALID, "at most one unpooled source and at least one full-resolution source");

@@ -27,7 +27,9 @@
  *     k = (source, input channel c, ky, kx) in that nesting order (= OIHW flattening c*9+ky*3+kx),
  *     zero padding included as explicit 0*w terms; bias / peephole are added after the chain;
  *   - a source that is nearest-neighbour unpooled x2 before its 3x3 convolution (R_{l+1} inside
- *     ConvLSTM_l) comes FIRST in the chain and is evaluated in the algebraically identical 2x2
+ *     ConvLSTM_l) is a chain of its own, started from 0 and added to the chain of the
+ *     full-resolution sources with ONE fp32 addition (chainer's ConvLSTM likewise adds the outputs
+ *     of separate convolutions), and it is evaluated in the algebraically identical 2x2
  *     form: the 3x3 window of output pixel (y, x) covers only 2x2 distinct pixels of the
  *     half-resolution source, which ones depends on the parity class (y&1, x&1), so its nine
  *     weights are summed per distinct source pixel beforehand (presum_up_weights below: fp32
@@ -126,6 +128,7 @@ typedef struct {
     float* E[EIG_MAX_LAYERS];
     float* pad;  /* zero-padded source planes scratch */
     float* gate; /* 4 gate pre-activations scratch */
+    float* up;   /* chain of the unpooled source scratch */
     float* tmp;  /* ConvA full-resolution scratch */
 } prednet_t;
 
@@ -303,13 +306,14 @@ static void prednet_alloc(prednet_t* n)
     }
     n->pad = (float*)malloc(sizeof(float) * maxpad);
     n->gate = (float*)malloc(sizeof(float) * maxgate);
+    n->up = (float*)malloc(sizeof(float) * maxgate);
     n->tmp = (float*)malloc(sizeof(float) * (maxtmp ? maxtmp : 1));
 }
 
 static void prednet_free(prednet_t* n)
 {
     for (int l = 0; l < n->L; l++) { free(n->h[l]); free(n->hn[l]); free(n->c[l]); free(n->P[l]); free(n->E[l]); }
-    free(n->pad); free(n->gate); free(n->tmp);
+    free(n->pad); free(n->gate); free(n->up); free(n->tmp);
 }
 
 static void prednet_reset(prednet_t* n)
@@ -359,14 +363,17 @@ static void prednet_step(prednet_t* n, const float* x)
         const int H = n->H[l], W = n->W[l], C = n->ch[l];
         const size_t hw = (size_t)H * W;
         memset(n->gate, 0, sizeof(float) * 4 * C * hw);
-        /* chain order of sources: unpooled R_{l+1} (2x2 form, see the header), E_l, h_l
-         * (ConvLSTM.__call__: x_*1, x_*0, h_*) */
-        if (l < L - 1) /* h[l+1] already holds R_{l+1} of this step */
-            for (int g = 0; g < 4; g++) conv_up2x2_chain(n->gate + (size_t)g * C * hw, n->h[l + 1], n->wx1[l][g], C, n->ch[l + 1], H, W);
+        /* one chain over the full-resolution sources E_l, h_l (ConvLSTM.__call__: x_*0, h_*) ... */
         fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
         for (int g = 0; g < 4; g++) conv3x3_chain(n->gate + (size_t)g * C * hw, n->pad, n->wx0[l][g], C, 2 * C, H, W);
         fill_padded(n->pad, n->h[l], C, H, W, 0);
         for (int g = 0; g < 4; g++) conv3x3_chain(n->gate + (size_t)g * C * hw, n->pad, n->wh[l][g], C, C, H, W);
+        /* ... plus the chain of the unpooled R_{l+1} (x_*1; 2x2 form, see the header): one fp32 addition */
+        if (l < L - 1) { /* h[l+1] already holds R_{l+1} of this step */
+            memset(n->up, 0, sizeof(float) * 4 * C * hw);
+            for (int g = 0; g < 4; g++) conv_up2x2_chain(n->up + (size_t)g * C * hw, n->h[l + 1], n->wx1[l][g], C, n->ch[l + 1], H, W);
+            for (size_t i = 0; i < 4 * C * hw; i++) n->gate[i] = n->gate[i] + n->up[i];
+        }
         /* gate epilogue */
         const float* gi = n->gate;
         const float* gf = n->gate + (size_t)C * hw;
@@ -452,8 +459,8 @@ int eig_oracle_prednet_rollout(int L, const int* channels, int W, int H, const f
 }
 
 /* Single conv chain exposed for kernel-level parity tests:
- * out[o][y][x] = chain over the unpooled sources first (up[s] = 1: [Cin_s][H/2][W/2], 2x2 form), then over the
- * full-resolution sources, each group in list order. */
+ * out[o][y][x] = chain over the full-resolution sources in list order + (one fp32 addition) chain over the
+ * unpooled sources (up[s] = 1: [Cin_s][H/2][W/2], 2x2 form), if there are any. */
 int eig_oracle_conv_chain(int ns, const float* const* src, const int* cin, const int* up,
                           const float* const* w, int Cout, int H, int W, float* out)
 {
@@ -461,12 +468,19 @@ int eig_oracle_conv_chain(int ns, const float* const* src, const int* cin, const
     for (int s = 0; s < ns; s++) if ((size_t)cin[s] > maxc) maxc = (size_t)cin[s];
     float* pad = (float*)malloc(sizeof(float) * maxc * (H + 2) * (W + 2));
     memset(out, 0, sizeof(float) * (size_t)Cout * H * W);
-    for (int s = 0; s < ns; s++)
-        if (up[s]) conv_up2x2_chain(out, src[s], w[s], Cout, cin[s], H, W);
     for (int s = 0; s < ns; s++) {
         if (up[s]) continue;
         fill_padded(pad, src[s], cin[s], H, W, 0);
         conv3x3_chain(out, pad, w[s], Cout, cin[s], H, W);
+    }
+    int n_up = 0;
+    for (int s = 0; s < ns; s++) n_up += up[s] != 0;
+    if (n_up) {
+        float* u = (float*)calloc((size_t)Cout * H * W, sizeof(float));
+        for (int s = 0; s < ns; s++)
+            if (up[s]) conv_up2x2_chain(u, src[s], w[s], Cout, cin[s], H, W);
+        for (size_t i = 0; i < (size_t)Cout * H * W; i++) out[i] = out[i] + u[i];
+        free(u);
     }
     free(pad);
     return 0;

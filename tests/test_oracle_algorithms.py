@@ -8,8 +8,9 @@ def _fma32(v, w, acc):  # fused multiply-add: exact product, one rounding
 
 
 def test_conv_chain_is_the_documented_fma_chain(oracle_lib):
-    """the unpooled source first, in its 2x2 form with pre-summed weights (4 terms per channel), then the
-    full-resolution sources as 9-term (c, ky, kx) chains; and that 2x2 form IS unpool -> conv3x3 up to summation order."""
+    """one 9-term (c, ky, kx) chain over the full-resolution sources plus (one fp32 addition) the chain of
+    the unpooled source in its 2x2 form with pre-summed weights (4 terms per channel); and that 2x2 form IS unpool -> conv3x3
+    up to summation order."""
     rng = np.random.default_rng(0)
     H, W = 6, 8
     srcs = [rng.normal(0, 1, (5, H, W)).astype(np.float32), rng.normal(0, 1, (3, H // 2, W // 2)).astype(np.float32)]
@@ -21,7 +22,7 @@ def test_conv_chain_is_the_documented_fma_chain(oracle_lib):
     for o in range(4):
         for y in range(H):
             for x in range(W):
-                acc = np.float32(0)
+                acc_up = np.float32(0)
                 py, px, Y, X = y & 1, x & 1, y >> 1, x >> 1
                 for c in range(srcs[1].shape[0]):
                     for a in range(2):
@@ -32,14 +33,15 @@ def test_conv_chain_is_the_documented_fma_chain(oracle_lib):
                                     wsum = ws[1][o, c, ky, kx] if wsum is None else np.float32(wsum + ws[1][o, c, ky, kx])
                             sy, sx = Y + a - 1 + py, X + b - 1 + px
                             v = srcs[1][c, sy, sx] if (0 <= sy < H // 2 and 0 <= sx < W // 2) else np.float32(0)
-                            acc = _fma32(v, wsum, acc)
+                            acc_up = _fma32(v, wsum, acc_up)
+                acc = np.float32(0)
                 for c in range(srcs[0].shape[0]):
                     for ky in range(3):
                         for kx in range(3):
                             yy, xx = y + ky - 1, x + kx - 1
                             v = srcs[0][c, yy, xx] if (0 <= yy < H and 0 <= xx < W) else np.float32(0)
                             acc = _fma32(v, ws[0][o, c, ky, kx], acc)
-                ref[o, y, x] = acc
+                ref[o, y, x] = np.float32(acc + acc_up)
                 for src, w, up in zip(srcs, ws, [0, 1]):
                     for c in range(src.shape[0]):
                         for ky in range(3):
