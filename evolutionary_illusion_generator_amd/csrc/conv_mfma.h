@@ -181,7 +181,7 @@ template <int NI, int TW, bool VEC, int TAPS = 9> constexpr int conv_lds_bytes()
 constexpr int CONV_THREADS = 256;  // 4 waves per block
 
 #ifndef EIG_UP4_OCC
-#define EIG_UP4_OCC 3  // the 2x2-form pass: 8 KB of weights per K-block and a store-only epilogue leave room for a third block per CU
+#define EIG_UP4_OCC 2  // the 2x2-form pass would fit a third block per CU (88 VGPRs, 48 KB of LDS); measured: no faster (96.9 vs 95.8 ms)
 #endif
 template <int NI, int TW, int EPI, bool VEC>
 __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW == 16 && VEC) ? EIG_UP4_OCC : EIG_CONV_OCC) conv3x3_mfma(const ConvArgs a)

@@ -20,17 +20,29 @@ ACT_IDS = {"sigmoid": 0, "tanh": 1, "abs": 2, "gauss": 3, "identity": 4, "sin": 
 
 
 def _required_for_output(inputs, outputs, connections):
+    """neat.graphs.required_for_output: layer by layer, t = sources of connections into the set seen so far that are not
+    in it yet.  (Only the layer added last can contribute new sources, so each connection is looked at once.)"""
+    incoming = {}
+    for (a, b) in connections:
+        incoming.setdefault(b, []).append(a)
+    inputs = set(inputs)
     required = set(outputs)
-    frontier = set(outputs)
+    seen = set(outputs)
+    last = list(seen)
     while True:
-        t = {a for (a, b) in connections if b in frontier and a not in frontier}
+        t = set()
+        for b in last:
+            for a in incoming.get(b, ()):
+                if a not in seen:
+                    t.add(a)
         if not t:
             break
-        layer = {x for x in t if x not in inputs}
+        layer = t - inputs
         if not layer:
             break
         required |= layer
-        frontier |= t
+        seen |= t
+        last = t
     return required
 
 
@@ -59,6 +71,14 @@ def flatten_genome(genome, config, n_leaves=2):
 
     Leaves are numbered in ``config.genome_config.input_keys`` order; ``edge_src = -(i+1)`` is leaf i and
     ``-(n_leaves+1)`` the constant 1.0."""
+    act, bias, resp, edge_off, edge_src, edge_w, out_node = _flatten_lists(genome, config, n_leaves)
+    return dict(act=np.asarray(act, np.uint8), bias=np.asarray(bias, np.float64), resp=np.asarray(resp, np.float64),
+                edge_off=np.asarray(edge_off, np.int32), edge_src=np.asarray(edge_src, np.int32),
+                edge_w=np.asarray(edge_w, np.float64), out_node=np.asarray(out_node, np.int32))
+
+
+def _flatten_lists(genome, config, n_leaves=2):
+    """flatten_genome's work on plain Python lists (GenomeBatch concatenates these and converts once per batch)."""
     gc = config.genome_config
     in_keys, out_keys = list(gc.input_keys), list(gc.output_keys)
     if len(in_keys) != n_leaves:
@@ -155,28 +175,27 @@ def flatten_genome(genome, config, n_leaves=2):
             act.append(ACT_IDS["identity"]); bias.append(0.0); resp.append(1.0)
             edge_src.append(ONE); edge_w.append(float(const32[o])); edge_off.append(len(edge_src))
         out_node.append(index[o])
-    return dict(act=np.asarray(act, np.uint8), bias=np.asarray(bias, np.float64), resp=np.asarray(resp, np.float64),
-                edge_off=np.asarray(edge_off, np.int32), edge_src=np.asarray(edge_src, np.int32),
-                edge_w=np.asarray(edge_w, np.float64), out_node=np.asarray(out_node, np.int32))
+    return act, bias, resp, edge_off, edge_src, edge_w, out_node
 
 
 class GenomeBatch:
     """Concatenation of flattened genomes = the arrays behind ``eigen_genome_batch``."""
 
     def __init__(self, genomes, config, c_out, n_leaves=2):
-        flats = [flatten_genome(g, config, n_leaves) for g in genomes]
-        for f, g in zip(flats, genomes):
-            if len(f["out_node"]) < c_out:
-                raise ValueError("genome %r has %d outputs, %d are rendered" % (getattr(g, "key", None), len(f["out_node"]), c_out))
-        self.n_genomes, self.c_out = len(flats), c_out
-        self.node_off = np.zeros(len(flats) + 1, np.int32)
-        np.cumsum([len(f["act"]) for f in flats], out=self.node_off[1:])
-        eo, base = [np.zeros(1, np.int32)], 0
-        for f in flats:
-            eo.append(f["edge_off"][1:] + base)
-            base += int(f["edge_off"][-1])
-        self.edge_off = np.ascontiguousarray(np.concatenate(eo).astype(np.int32))
-        cat = lambda k, dt: np.ascontiguousarray(np.concatenate([f[k] for f in flats]).astype(dt))
-        self.node_act, self.node_bias, self.node_resp = cat("act", np.uint8), cat("bias", np.float64), cat("resp", np.float64)
-        self.edge_src, self.edge_w = cat("edge_src", np.int32), cat("edge_w", np.float64)
-        self.out_node = np.ascontiguousarray(np.concatenate([f["out_node"][:c_out] for f in flats]).astype(np.int32))
+        node_off, act, bias, resp, edge_off, edge_src, edge_w, out_node = [0], [], [], [], [0], [], [], []
+        for g in genomes:
+            a, b, r, eo, es, ew, on = _flatten_lists(g, config, n_leaves)
+            if len(on) < c_out:
+                raise ValueError("genome %r has %d outputs, %d are rendered" % (getattr(g, "key", None), len(on), c_out))
+            base = len(edge_src)
+            act += a; bias += b; resp += r; edge_src += es; edge_w += ew
+            edge_off += [base + o for o in eo[1:]]
+            out_node += on[:c_out]
+            node_off.append(len(act))
+        self.n_genomes, self.c_out = len(genomes), c_out
+        self.node_off = np.asarray(node_off, np.int32)
+        self.edge_off = np.asarray(edge_off, np.int32)
+        self.node_act = np.asarray(act, np.uint8)
+        self.node_bias, self.node_resp = np.asarray(bias, np.float64), np.asarray(resp, np.float64)
+        self.edge_src, self.edge_w = np.asarray(edge_src, np.int32), np.asarray(edge_w, np.float64)
+        self.out_node = np.asarray(out_node, np.int32)
