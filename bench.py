@@ -71,6 +71,8 @@ def main():
                          "c2: configs[1] circles_bw 160x120 gray (channels 1,16,32,64) pop 50; c4: configs[3] per-GPU share, "
                          "bands.txt (8 hidden, 6 outputs) 256x256 colour Bands pop 64; "
                          "c5: configs[4] per-GPU share, 512x512 colour Free structure, pop 128")
+    ap.add_argument("--flow", default="lk", choices=["lk", "farneback"],
+                    help="supplementary: 'farneback' swaps the reference's Lucas-Kanade call for the dense Farneback option (no CPU leg)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -110,12 +112,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from evolutionary_illusion_generator_amd import fitness, grids, synth, weights
+    if args.flow != "lk":
+        fitness.FLOW_METHOD = args.flow
+        args.no_cpu_baseline = True
     cfg = synth.make_config(2, n_outputs)
     global_pop = args.pop * world
     population = synth.make_population(global_pop, cfg, seed=0, num_hidden=n_hidden)  # identical on every rank (seeded)
     genomes = [g for _, g in population]
     wts = weights.synthetic_prednet_weights(CHANNELS, W, H, seed=0)
-    eng = fitness.get_engine(wts, W, H, CHANNELS, max_batch=args.pop)
+    eng = fitness.get_engine(wts, W, H, CHANNELS, max_batch=args.pop, **({} if args.flow == "lk" else {"flow": args.flow}))
 
     def step():
         def evaluate(lo, hi):
@@ -150,10 +155,10 @@ def main():
         "ms_per_step": 1000.0 * dt / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s pop=%d/GPU, %dx%d, PredNet %s, 21 steps, LK + %s score" % (
+        "config": {"workload": "%s pop=%d/GPU, %dx%d, PredNet %s, 21 steps, %s + %s score" % (
                        {"headline": "neat_configs/circles.txt colour", "ref160": "neat_configs/circles.txt colour", "c2": "neat_configs/circles_bw.txt gray",
                         "c4": "neat_configs/bands.txt colour (first 3 of 6 outputs)", "c5": "neat_configs/free.txt colour"}[args.shape], args.pop, W, H,
-                       ",".join(map(str, CHANNELS)), ["horizontal-symmetry", "rotation-symmetry", "swarm", "rotation-symmetry"][STRUCTURE]),
+                       ",".join(map(str, CHANNELS)), {"lk": "LK", "farneback": "Farneback dense flow"}[args.flow], ["horizontal-symmetry", "rotation-symmetry", "swarm", "rotation-symmetry"][STRUCTURE]),
                    "global_pop": global_pop, "image": [W, H], "channels": CHANNELS, "structure": ["Bands", "Circles", "Free", "CirclesFree"][STRUCTURE],
                    "parallelism": "pop-shard x%d + all-gather(fitness f64)" % world},
         "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items() if k.endswith("_ms") and k != "conv_ms"},

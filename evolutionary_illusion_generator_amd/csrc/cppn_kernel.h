@@ -35,7 +35,7 @@ struct CppnArgs {
     int c_out;                // outputs evaluated per genome
     int c_dim;                // channels written per genome
     int bg;                   // 0 / 1
-    int mode;                 // 0: gradient colour/gray; 1: gray rounded (gradient==0, c_dim==1); 2: 5-colour palette;
+    int mode;                 // 0: gradient colour/gray; 1: gray rounded (gradient==0, c_dim==1); 2: 5-colour palette; 4: h,s,v nodes -> RGB;
                               // 3: raw float64 node values to out_f64 (the create_cppn node call itself)
     int max_nodes;            // LDS column count
     uint8_t* out;             // [G][c_dim][N]
@@ -133,6 +133,41 @@ __global__ void __launch_bounds__(CPPN_THREADS) cppn_render_kernel(const CppnArg
             if (is_bg) o = (uint8_t)(a.bg * 255);
             out[(size_t)c * a.N] = o;
         }
+        return;
+    }
+    if (a.mode == 4) {  // get_equilum_image_from_cppn (generate_illusion.py:333-367): the three nodes are h, s, v; the reference hands
+        // the whole array to colorsys.hsv_to_rgb (TypeError) -- here the conversion it names runs per pixel, operation by
+        // operation as CPython's colorsys does, then the usual uint8(v * 255).  bg fills h, s AND v, as the reference does.
+        double hsv[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            double v = vals[(size_t)a.out_node[g * a.c_out + c] * CPPN_THREADS + tid];
+            if (is_bg) v = (double)a.bg;
+            hsv[c] = v;
+        }
+        const double h = hsv[0], sat = hsv[1], v = hsv[2];
+        double r, gg, b;
+        if (sat == 0.0) { r = gg = b = v; }
+        else {
+            const double h6 = h * 6.0;
+            double i = trunc(h6);                        // int(): toward zero
+            if (!(fabs(i) < 9007199254740992.0)) i = 0.0;  // int() raises for NaN / inf, and f = 0 beyond 2^53 anyway: build-defined, sextant 0
+            const double f = h6 - i;
+            const double pp = v * (1.0 - sat);
+            const double qq = v * (1.0 - sat * f);
+            const double tt = v * (1.0 - sat * (1.0 - f));
+            double im = fmod(i, 6.0);                    // exact; Python's % is non-negative
+            if (im < 0.0) im += 6.0;
+            if (im == 0.0) { r = v; gg = tt; b = pp; }
+            else if (im == 1.0) { r = qq; gg = v; b = pp; }
+            else if (im == 2.0) { r = pp; gg = v; b = tt; }
+            else if (im == 3.0) { r = pp; gg = qq; b = v; }
+            else if (im == 4.0) { r = tt; gg = pp; b = v; }
+            else { r = v; gg = pp; b = qq; }
+        }
+        out[0] = quant_u8(r * 255.0);
+        out[(size_t)a.N] = quant_u8(gg * 255.0);
+        out[(size_t)2 * a.N] = quant_u8(b * 255.0);
         return;
     }
     for (int c = 0; c < a.c_dim; ++c) {

@@ -14,6 +14,7 @@
 #include "../../include/eigen_engine.h"
 #include "conv_mfma.h"
 #include "cppn_kernel.h"
+#include "farneback_kernels.h"
 #include "flow_kernels.h"
 #include "score_kernels.h"
 
@@ -110,6 +111,8 @@ struct eigen_engine {
     int *d_ncorners = nullptr, *d_counts = nullptr;
     double* d_fitness = nullptr;
     float* d_zeros = nullptr;  // DMA source for zero fill (conv_mfma.h)
+    // Farneback dense flow (cfg.flow_method == EIGEN_FLOW_FARNEBACK): allocated on first use
+    float *fb_I = nullptr, *fb_R0 = nullptr, *fb_R1 = nullptr, *fb_M = nullptr, *fb_V = nullptr, *fb_flow[2] = {nullptr, nullptr};
     float* d_raw4 = nullptr;   // partial chains of the unpooled source, [B][4 classes][n_nblk*NB][H/2][W/2], reused by all layers
     size_t raw4_floats = 0;
     // timing
@@ -122,6 +125,86 @@ struct eigen_engine {
 
 // ------------------------------------------------------------------------------------------------ helpers
 static int pad4(int c) { return (c + 3) & ~3; }
+
+// ---- Farneback constants (host; the same double-precision recipe as oracle/farneback.c, checked by tests/test_gpu_parity.py) ----
+static int fb_levels_used(int H, int W, int levels)  // calcOpticalFlowFarneback: no level below 32 pixels
+{
+    int k = 0;
+    double scale = 1;
+    for (; k < levels; ++k) {
+        scale *= 0.5;
+        if (W * scale < 32 || H * scale < 32) break;
+    }
+    return k;
+}
+static int fb_grid_step(int H, int W, int step, int max_vectors)
+{
+    int s = step;
+    while ((H / s) * (W / s) > max_vectors) s += step;
+    return s;
+}
+static FbBlur fb_blur_kernel(int k)  // GaussianBlur of pyramid level k: sigma = (2^k - 1) / 2, ksize = max(cvRound(5 sigma) | 1, 3)
+{
+    FbBlur b;
+    memset(&b, 0, sizeof(b));
+    const double sigma = ((double)(1 << k) - 1) * 0.5;
+    int ksize = (int)lrint(sigma * 5) | 1;
+    if (ksize < 3) ksize = 3;
+    b.r = ksize / 2;
+    if (sigma <= 0 && ksize == 3) { b.k[0] = 0.5f; b.k[1] = 0.25f; return b; }
+    const double sx = sigma > 0 ? sigma : ((ksize - 1) * 0.5 - 1) * 0.3 + 0.8;
+    const double s2 = -0.5 / (sx * sx);
+    std::vector<double> c(ksize);
+    double sum = 0;
+    for (int i = 0; i < ksize; ++i) { const double x = i - (ksize - 1) * 0.5; c[i] = exp(s2 * x * x); sum += c[i]; }
+    sum = 1.0 / sum;
+    for (int j = 0; j <= b.r; ++j) b.k[j] = (float)(c[b.r + j] * sum);
+    return b;
+}
+static FbConst fb_poly_constants(int n, double sigma)  // FarnebackPrepareGaussian
+{
+    FbConst c;
+    memset(&c, 0, sizeof(c));
+    c.poly_n = n;
+    if (sigma < 1.1920928955078125e-07) sigma = n * 0.3;
+    std::vector<double> gd(2 * n + 1);
+    std::vector<float> gf(2 * n + 1);
+    double s = 0;
+    for (int x = -n; x <= n; ++x) { gd[x + n] = exp(-x * x / (2 * sigma * sigma)); s += gd[x + n]; }
+    s = 1.0 / s;
+    for (int x = -n; x <= n; ++x) gf[x + n] = (float)(gd[x + n] * s);
+    for (int x = 0; x <= n; ++x) { c.g[x] = gf[x + n]; c.xg[x] = (float)(x * gf[x + n]); c.xxg[x] = (float)(x * x * gf[x + n]); }
+    double G[6][6];
+    memset(G, 0, sizeof(G));
+    for (int y = -n; y <= n; ++y)
+        for (int x = -n; x <= n; ++x) {
+            const double w = (double)gf[y + n] * (double)gf[x + n];
+            G[0][0] += w;
+            G[1][1] += w * x * x;
+            G[3][3] += w * x * x * x * x;
+            G[5][5] += w * x * x * y * y;
+        }
+    G[2][2] = G[0][3] = G[0][4] = G[3][0] = G[4][0] = G[1][1];
+    G[4][4] = G[3][3];
+    G[3][4] = G[4][3] = G[5][5];
+    double A[6][12];  // Gauss-Jordan with partial pivoting
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 12; ++j) A[i][j] = j < 6 ? G[i][j] : (j - 6 == i ? 1.0 : 0.0);
+    for (int col = 0; col < 6; ++col) {
+        int p = col;
+        for (int r = col + 1; r < 6; ++r) if (fabs(A[r][col]) > fabs(A[p][col])) p = r;
+        if (p != col) for (int j = 0; j < 12; ++j) std::swap(A[col][j], A[p][j]);
+        const double d = 1.0 / A[col][col];
+        for (int j = 0; j < 12; ++j) A[col][j] *= d;
+        for (int r = 0; r < 6; ++r) {
+            if (r == col) continue;
+            const double f = A[r][col];
+            if (f != 0.0) for (int j = 0; j < 12; ++j) A[r][j] -= f * A[col][j];
+        }
+    }
+    c.ig[0] = (float)A[1][7]; c.ig[1] = (float)A[0][9]; c.ig[2] = (float)A[3][9]; c.ig[3] = (float)A[5][11];
+    return c;
+}
 
 static void choose_ni(int Cout, bool lstm, int* NI, int* n_nblk)
 {
@@ -332,7 +415,8 @@ void eigen_config_defaults(eigen_config* c)
 {
     c->n_repeat = 20; c->n_ext = 2; c->requant_feedback = 0;
     c->lk_max_corners = 100; c->lk_block_size = 7; c->lk_win = 15; c->lk_max_level = 2; c->lk_max_iter = 10;
-    c->reserved0 = 0;
+    c->flow_method = EIGEN_FLOW_LK;
+    c->fb_levels = 3; c->fb_winsize = 15; c->fb_iterations = 3; c->fb_poly_n = 5; c->fb_step = 16; c->reserved1 = 0; c->fb_poly_sigma = 1.2;
     c->lk_quality_level = 0.3; c->lk_min_distance = 7.0; c->lk_epsilon = 0.03; c->lk_min_eig_thr = 1e-4;
 }
 
@@ -349,7 +433,8 @@ int eigen_destroy(eigen_engine* e)
     e->g_node_off.release(); e->g_edge_off.release(); e->g_edge_src.release(); e->g_out_node.release();
     e->g_node_act.release(); e->g_node_bias.release(); e->g_node_resp.release(); e->g_edge_w.release();
     void* misc[] = {e->d_images, e->d_frames, e->d_eig, e->d_cand, e->d_corners, e->d_next, e->d_vectors, e->d_status,
-                    e->d_ncorners, e->d_counts, e->d_fitness, e->d_zeros, e->d_raw4};
+                    e->d_ncorners, e->d_counts, e->d_fitness, e->d_zeros, e->d_raw4,
+                    e->fb_I, e->fb_R0, e->fb_R1, e->fb_M, e->fb_V, e->fb_flow[0], e->fb_flow[1]};
     for (void* p : misc) if (p) (void)hipFree(p);
     for (int i = 0; i < 2; ++i)
         for (int l = 0; l < FLOW_MAX_LEVELS; ++l) if (e->d_gray[i][l]) (void)hipFree(e->d_gray[i][l]);
@@ -377,6 +462,15 @@ int eigen_create(const eigen_config* cfg, eigen_engine** out)
     if (cfg->lk_block_size < 1 || cfg->lk_block_size > EIG_MAXB) return fail(EIGEN_ERR_INVALID, "lk_block_size must be in 1..%d", EIG_MAXB);
     if (cfg->lk_max_level < 0 || cfg->lk_max_level >= FLOW_MAX_LEVELS) return fail(EIGEN_ERR_INVALID, "lk_max_level must be in 0..%d", FLOW_MAX_LEVELS - 1);
     if (cfg->n_repeat < 1 || cfg->n_ext < 0) return fail(EIGEN_ERR_INVALID, "n_repeat >= 1 and n_ext >= 0 required");
+    if (cfg->flow_method != EIGEN_FLOW_LK && cfg->flow_method != EIGEN_FLOW_FARNEBACK) return fail(EIGEN_ERR_INVALID, "unknown flow_method %d", cfg->flow_method);
+    if (cfg->flow_method == EIGEN_FLOW_FARNEBACK) {
+        if (cfg->fb_poly_n < 1 || cfg->fb_poly_n > FB_MAX_POLY_N) return fail(EIGEN_ERR_INVALID, "fb_poly_n must be in 1..%d", FB_MAX_POLY_N);
+        if (cfg->fb_winsize < 1 || !(cfg->fb_winsize & 1) || cfg->fb_winsize / 2 > FB_MAX_WIN_R) return fail(EIGEN_ERR_INVALID, "fb_winsize must be odd and <= %d", 2 * FB_MAX_WIN_R + 1);
+        if (cfg->fb_levels < 0 || cfg->fb_levels > 4) return fail(EIGEN_ERR_INVALID, "fb_levels must be in 0..4 (Gaussian radius <= %d)", FB_MAX_BLUR_R);
+        if (cfg->fb_iterations < 1 || cfg->fb_step < 1) return fail(EIGEN_ERR_INVALID, "fb_iterations >= 1 and fb_step >= 1 required");
+        const int lv = fb_levels_used(cfg->height, cfg->width, cfg->fb_levels);
+        if ((cfg->height % (1 << lv)) || (cfg->width % (1 << lv))) return fail(EIGEN_ERR_INVALID, "Farneback flow with %d pyramid levels needs an image divisible by %d", lv, 1 << lv);
+    }
     for (int l = 0; l < L; ++l) if (cfg->channels[l] < 1) return fail(EIGEN_ERR_INVALID, "channels[%d] < 1", l);
     HIPCHK(hipSetDevice(cfg->device));
     hipDeviceProp_t prop;
@@ -591,7 +685,7 @@ static int render_cppn_impl(eigen_engine* e, const eigen_genome_batch* g, int32_
     hipStream_t st = (hipStream_t)stream;
     const int G = g->n_genomes;
     if (G < 1) return fail(EIGEN_ERR_INVALID, "n_genomes < 1");
-    const int need_out = (mode == 0) ? e->C0 : 1;
+    const int need_out = (mode == 0) ? e->C0 : (mode == 4 ? 3 : 1);
     if (g->c_out < need_out) return fail(EIGEN_ERR_INVALID, "genome batch provides %d outputs per genome, %d needed", g->c_out, need_out);
     const int total_nodes = g->node_off[G];
     const int total_edges = g->edge_off[total_nodes];
@@ -648,6 +742,12 @@ static int render_cppn_impl(eigen_engine* e, const eigen_genome_batch* g, int32_
 int eigen_render_cppn(eigen_engine* e, const eigen_genome_batch* g, int32_t bg, int32_t gradient, uint8_t* d_images, void* stream)
 {
     if (!e || !g || !d_images) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (gradient == 2) {  // get_equilum_image_from_cppn: three output nodes read as h, s, v
+        if (e->C0 != 3) return fail(EIGEN_ERR_INVALID, "the h,s,v renderer needs c_dim = 3");
+        if (g->c_out < 3) return fail(EIGEN_ERR_INVALID, "the h,s,v renderer needs 3 outputs per genome, the batch has %d", g->c_out);
+        return render_cppn_impl(e, g, bg, 4, d_images, nullptr, stream);
+    }
+    if (gradient != 0 && gradient != 1) return fail(EIGEN_ERR_INVALID, "gradient must be 0, 1 or 2 (h,s,v renderer)");
     return render_cppn_impl(e, g, bg, (gradient == 1) ? 0 : (e->C0 == 1 ? 1 : 2), d_images, nullptr, stream);
 }
 
@@ -738,6 +838,49 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
     return EIGEN_OK;
 }
 
+// Dense Farneback flow between the gray images d_gray[0][0] -> d_gray[1][0], sampled into vectors (farneback_kernels.h)
+static int farneback_flow(eigen_engine* e, int batch, float* d_vectors, int32_t* d_counts, hipStream_t st)
+{
+    const int H = e->H, W = e->W;
+    const size_t HW = (size_t)H * W, B = (size_t)e->B;
+    const eigen_config& c = e->cfg;
+    if (!e->fb_I) {
+        hipError_t r = hipMalloc((void**)&e->fb_I, B * HW * sizeof(float));
+        float** five[] = {&e->fb_R0, &e->fb_R1, &e->fb_M, &e->fb_V};
+        for (float** p : five) if (r == hipSuccess) r = hipMalloc((void**)p, B * 5 * HW * sizeof(float));
+        for (int i = 0; i < 2 && r == hipSuccess; ++i) r = hipMalloc((void**)&e->fb_flow[i], B * 2 * HW * sizeof(float));
+        if (r != hipSuccess) return fail(EIGEN_ERR_HIP, "hipMalloc for the Farneback workspaces: %s", hipGetErrorString(r));
+    }
+    const int levels = fb_levels_used(H, W, c.fb_levels);
+    const FbConst pc = fb_poly_constants(c.fb_poly_n, c.fb_poly_sigma);
+    const int m = c.fb_winsize / 2;
+    int cur = 0;
+    for (int k = levels; k >= 0; --k) {
+        const int Hk = H >> k, Wk = W >> k, hw = Hk * Wk;
+        const dim3 g1((hw + 255) / 256, batch);
+        float* fl = e->fb_flow[cur];
+        if (k == levels) HIPCHK(hipMemsetAsync(fl, 0, (size_t)batch * 2 * hw * sizeof(float), st));
+        else hipLaunchKernelGGL(fb_upsample_kernel, g1, dim3(256), 0, st, e->fb_flow[cur ^ 1], H >> (k + 1), W >> (k + 1), fl, Hk, Wk);
+        const FbBlur bl = fb_blur_kernel(k);
+        const dim3 gp((Wk + FB_PX - 1) / FB_PX, (Hk + FB_PY - 1) / FB_PY, batch);
+        for (int i = 0; i < 2; ++i) {
+            hipLaunchKernelGGL(fb_blur_down_kernel, g1, dim3(256), 0, st, e->d_gray[i][0], H, W, k, bl, e->fb_I);
+            hipLaunchKernelGGL(fb_polyexp_kernel, gp, dim3(FB_PX, FB_PY), 0, st, e->fb_I, Hk, Wk, pc, i == 0 ? e->fb_R0 : e->fb_R1);
+        }
+        hipLaunchKernelGGL(fb_update_matrices_kernel, g1, dim3(256), 0, st, e->fb_R0, e->fb_R1, fl, Hk, Wk, e->fb_M);
+        for (int it = 0; it < c.fb_iterations; ++it) {
+            hipLaunchKernelGGL(fb_box_v_kernel, g1, dim3(256), 0, st, e->fb_M, Hk, Wk, m, e->fb_V);
+            hipLaunchKernelGGL(fb_box_h_solve_kernel, dim3((Wk + FB_HT - 1) / FB_HT, Hk, batch), dim3(FB_HT), 0, st, e->fb_V, Hk, Wk, m, fl);
+            if (it + 1 < c.fb_iterations) hipLaunchKernelGGL(fb_update_matrices_kernel, g1, dim3(256), 0, st, e->fb_R0, e->fb_R1, fl, Hk, Wk, e->fb_M);
+        }
+        cur ^= 1;
+    }
+    const int step = fb_grid_step(H, W, c.fb_step, e->K);
+    hipLaunchKernelGGL(fb_sample_kernel, dim3(batch), dim3(64), 0, st, e->fb_flow[cur ^ 1], H, W, step, e->K, d_vectors, d_counts);
+    HIPCHK(hipGetLastError());
+    return EIGEN_OK;
+}
+
 int eigen_flow(eigen_engine* e, const uint8_t* d_img0, int64_t stride0, const uint8_t* d_img1, int64_t stride1, int32_t batch,
                float* d_vectors, int32_t* d_counts, void* stream)
 {
@@ -749,6 +892,7 @@ int eigen_flow(eigen_engine* e, const uint8_t* d_img0, int64_t stride0, const ui
     const eigen_config& c = e->cfg;
     hipLaunchKernelGGL(gray_kernel, dim3((HW + 255) / 256, batch), dim3(256), 0, st, d_img0, (long long)stride0, e->C0, HW, e->d_gray[0][0], batch);
     hipLaunchKernelGGL(gray_kernel, dim3((HW + 255) / 256, batch), dim3(256), 0, st, d_img1, (long long)stride1, e->C0, HW, e->d_gray[1][0], batch);
+    if (c.flow_method == EIGEN_FLOW_FARNEBACK) return farneback_flow(e, batch, d_vectors, d_counts, st);
     for (int l = 1; l < e->n_levels; ++l)
         for (int i = 0; i < 2; ++i)
             hipLaunchKernelGGL(pyrdown_kernel, dim3((e->lvH[l] * e->lvW[l] + 255) / 256, batch), dim3(256), 0, st, e->d_gray[i][l - 1],
@@ -1002,6 +1146,20 @@ int eigen_test_det_math(eigen_engine* e, const float* d_x, int32_t n, float* d_e
     HIPCHK(hipSetDevice(e->cfg.device));
     hipLaunchKernelGGL(det_math_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_x, n, d_exp, d_sig, d_tanh);
     HIPCHK(hipGetLastError());
+    return EIGEN_OK;
+}
+
+// Stage-level access for the parity tests: the dense field of the last Farneback eigen_flow call, float [batch][2][H][W] (dx, dy planes).
+int eigen_debug_dense_flow(eigen_engine* e, int32_t batch, float* h_flow, void* stream)
+{
+    if (!e || !h_flow) return fail(EIGEN_ERR_INVALID, "null argument");
+    if (e->cfg.flow_method != EIGEN_FLOW_FARNEBACK || !e->fb_I) return fail(EIGEN_ERR_STATE, "no Farneback flow has been computed by this engine");
+    if (batch < 1 || batch > e->B) return fail(EIGEN_ERR_CAPACITY, "batch %d exceeds max_batch %d", batch, e->B);
+    HIPCHK(hipSetDevice(e->cfg.device));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    const int levels = fb_levels_used(e->H, e->W, e->cfg.fb_levels);
+    // level k writes fb_flow[(levels - k) & 1]; the full-resolution field is level 0's
+    HIPCHK(hipMemcpy(h_flow, e->fb_flow[levels & 1], sizeof(float) * (size_t)batch * 2 * e->H * e->W, hipMemcpyDeviceToHost));
     return EIGEN_OK;
 }
 

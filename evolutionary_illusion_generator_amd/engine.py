@@ -18,7 +18,7 @@ PAIR_POPULATION, PAIR_SINGLE = 0, 1
 EXPORTS = ["eigen_abi_version", "eigen_last_error", "eigen_config_defaults", "eigen_create", "eigen_destroy",
            "eigen_set_prednet_weights", "eigen_set_grid", "eigen_render_cppn", "eigen_eval_cppn_nodes", "eigen_prednet_rollout", "eigen_flow",
            "eigen_score", "eigen_eval_population", "eigen_eval_images", "eigen_test_conv", "eigen_time_conv", "eigen_test_det_math",
-           "eigen_get_timings", "eigen_conv_profile", "eigen_debug_corners", "eigen_prednet_flops_per_step"]
+           "eigen_get_timings", "eigen_conv_profile", "eigen_debug_corners", "eigen_debug_dense_flow", "eigen_prednet_flops_per_step"]
 
 
 class EigenConfig(ctypes.Structure):
@@ -26,9 +26,12 @@ class EigenConfig(ctypes.Structure):
                 ("n_layers", ctypes.c_int32), ("channels", ctypes.c_int32 * MAX_LAYERS), ("max_batch", ctypes.c_int32),
                 ("n_repeat", ctypes.c_int32), ("n_ext", ctypes.c_int32), ("requant_feedback", ctypes.c_int32),
                 ("lk_max_corners", ctypes.c_int32), ("lk_block_size", ctypes.c_int32), ("lk_win", ctypes.c_int32),
-                ("lk_max_level", ctypes.c_int32), ("lk_max_iter", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("lk_max_level", ctypes.c_int32), ("lk_max_iter", ctypes.c_int32), ("flow_method", ctypes.c_int32),
                 ("lk_quality_level", ctypes.c_double), ("lk_min_distance", ctypes.c_double),
-                ("lk_epsilon", ctypes.c_double), ("lk_min_eig_thr", ctypes.c_double)]
+                ("lk_epsilon", ctypes.c_double), ("lk_min_eig_thr", ctypes.c_double),
+                ("fb_levels", ctypes.c_int32), ("fb_winsize", ctypes.c_int32), ("fb_iterations", ctypes.c_int32),
+                ("fb_poly_n", ctypes.c_int32), ("fb_step", ctypes.c_int32), ("reserved1", ctypes.c_int32),
+                ("fb_poly_sigma", ctypes.c_double)]
 
 
 class GenomeBatchC(ctypes.Structure):
@@ -36,6 +39,9 @@ class GenomeBatchC(ctypes.Structure):
                 ("node_off", ctypes.c_void_p), ("edge_off", ctypes.c_void_p), ("node_act", ctypes.c_void_p),
                 ("node_bias", ctypes.c_void_p), ("node_resp", ctypes.c_void_p), ("edge_src", ctypes.c_void_p),
                 ("edge_w", ctypes.c_void_p), ("out_node", ctypes.c_void_p)]
+
+
+FLOW_METHODS = {"lk": 0, "farneback": 1}  # eigen_flow_method
 
 
 class EngineError(RuntimeError):
@@ -94,7 +100,7 @@ def _stream_arg(stream):
 class Engine:
     """One engine handle = one GPU rank.  Sizes are fixed at creation (workspaces live in HBM)."""
 
-    def __init__(self, width, height, channels, max_batch, device=0, n_repeat=20, n_ext=2, requant_feedback=False, **lk):
+    def __init__(self, width, height, channels, max_batch, device=0, n_repeat=20, n_ext=2, requant_feedback=False, flow="lk", **lk):
         self.lib = load_library()
         cfg = EigenConfig()
         self.lib.eigen_config_defaults(ctypes.byref(cfg))
@@ -102,10 +108,14 @@ class Engine:
         for i, c in enumerate(channels):
             cfg.channels[i] = c
         cfg.n_repeat, cfg.n_ext, cfg.requant_feedback = n_repeat, n_ext, int(requant_feedback)
-        for k, v in lk.items():
-            if not hasattr(cfg, "lk_" + k):
-                raise TypeError("unknown Lucas-Kanade parameter %r" % k)
-            setattr(cfg, "lk_" + k, v)
+        if flow not in FLOW_METHODS:
+            raise ValueError("flow must be one of %s" % sorted(FLOW_METHODS))
+        cfg.flow_method = FLOW_METHODS[flow]
+        for k, v in lk.items():  # lk_* (Lucas-Kanade) or fb_* (Farneback) parameters, prefix optional for lk
+            name = k if k.startswith("fb_") else "lk_" + k
+            if not hasattr(cfg, name):
+                raise TypeError("unknown flow parameter %r" % k)
+            setattr(cfg, name, v)
         self.cfg = cfg
         self.width, self.height, self.channels, self.max_batch = width, height, list(channels), max_batch
         self.c_dim, self.K = channels[0], cfg.lk_max_corners
@@ -231,6 +241,12 @@ class Engine:
                              NI=int(r[2]), TW=int(r[3]),
                              launches=int(r[4]), ms=float(r[5]), flops_per_image=float(r[6]), n_nblk=int(r[7])))
         return rows
+
+    def debug_dense_flow(self, batch, stream=None):
+        """float32 [batch, 2, H, W]: the dense Farneback field of the last flow call (engines created with flow="farneback")."""
+        f = np.zeros((batch, 2, self.height, self.width), np.float32)
+        _check(self.lib.eigen_debug_dense_flow(self._h, ctypes.c_int32(batch), _ptr(f), _stream_arg(stream)))
+        return f
 
     def debug_corners(self, batch, stream=None):
         c = np.zeros((batch, self.K, 2), np.float32); n = np.zeros(batch, np.int32)

@@ -139,13 +139,20 @@ def sharded_map(n_items, evaluate, group=None):
 
 
 # ----------------------------------------------------------------------------------------------- the API
+# Optical-flow method of the population path: "lk" (what the reference calls: lucas_kanade, generate_illusion.py:549-550) or
+# "farneback" (dense flow sampled on a grid, csrc/farneback_kernels.h).  get_fitnesses_neat keeps the reference's signature,
+# so the choice is a module setting; evaluate_population also takes it as an argument.
+FLOW_METHOD = "lk"
+
+
 def evaluate_population(structure, genomes, model_name, config, w, h, channels, c_dim=3, gradient=1, bg=1,
-                        pairing=PAIR_POPULATION, max_batch=None):
+                        pairing=PAIR_POPULATION, max_batch=None, flow=None):
     """Fitness (float64 array) of a list of genome objects on the local GPU, in chunks of max_batch."""
     channels = [int(c) for c in channels]
     if channels[0] != c_dim:
         raise ValueError("channels[0]=%d but c_dim=%d: PredNet's input channels are the image channels" % (channels[0], c_dim))
-    eng = get_engine(model_name, w, h, channels, max_batch=max_batch)
+    flow = flow or FLOW_METHOD
+    eng = get_engine(model_name, w, h, channels, max_batch=max_batch, **({} if flow == "lk" else {"flow": flow}))
     n_in = len(config.genome_config.input_keys)
     _set_grid(eng, structure, w, h, n_in)
     c_out = c_dim if gradient == 1 else 1
@@ -191,12 +198,21 @@ def render_images(structure, genomes, model_name, config, w, h, channels, c_dim=
     out = []
     for i in range(0, len(genomes), eng.max_batch):
         chunk = genomes[i:i + eng.max_batch]
-        gb = GenomeBatch(chunk, config, c_dim if gradient == 1 else 1, n_leaves=n_in)
+        gb = GenomeBatch(chunk, config, c_dim if gradient in (1, 2) else 1, n_leaves=n_in)
         d = torch.empty((len(chunk), c_dim, h, w), dtype=torch.uint8, device="cuda")
         eng.render_cppn(gb, d, bg=bg, gradient=gradient)
         torch.cuda.synchronize()
         out.append(d.cpu().numpy())
     return np.concatenate(out)
+
+
+def get_equilum_image_from_cppn(structure, genome, model_name, config, w, h, channels, bg=1):
+    """The reference's HSV renderer (generate_illusion.py:333-367; dead there: its colorsys call raises): output nodes 0..2 are
+    h, s, v, converted per pixel on the device (cppn_render_kernel mode 4).  Returns a PIL image like the reference does.
+    ``structure`` stands for the reference's ``inputs`` grid dict (the grid is built and cached on the device)."""
+    from PIL import Image
+    chw = render_images(structure, [genome], model_name, config, w, h, channels, c_dim=3, gradient=2, bg=bg)[0]
+    return Image.fromarray(np.ascontiguousarray(chw.transpose(1, 2, 0)))
 
 
 def save_best_artifacts(structure, genome, model_name, config, w, h, channels, c_dim, best_dir, gradient,
@@ -307,12 +323,12 @@ def _score_engine(w, h, n):
 
 
 # ------------------------------------------------------------------- stage-level entry points (import shims)
-def _aux_engine(kind, w, h, c_dim):
+def _aux_engine(kind, w, h, c_dim, **kw):
     """Render-/flow-only engine: one PredNet layer keeps the workspaces tiny; no weights are ever set."""
-    key = (kind, _local_device(), w, h, c_dim)
+    key = (kind, _local_device(), w, h, c_dim, tuple(sorted(kw.items())))
     eng = _engines.get(key)
     if eng is None:
-        eng = Engine(w, h, [c_dim], 1, device=_local_device())
+        eng = Engine(w, h, [c_dim], 1, device=_local_device(), **kw)
         eng._grid_key = None
         _engines[key] = eng
     return eng
@@ -354,15 +370,16 @@ def prednet_predictions(images, model_name, channels, w, h, n_repeat=20, n_ext=2
     return out
 
 
-def flow_vectors(img0, img1):
-    """Lucas-Kanade vectors [x, y, dx, dy] (float32 [n, 4]) between two uint8 CHW images of equal size
-    (Optical_Flow_Analyzer lucas_kanade; generate_illusion.py:549-550, fitness_calculator.py:498)."""
+def flow_vectors(img0, img1, method="lk"):
+    """Flow vectors [x, y, dx, dy] (float32 [n, 4]) between two uint8 CHW images of equal size.  method "lk": Lucas-Kanade
+    (Optical_Flow_Analyzer lucas_kanade; generate_illusion.py:549-550, fitness_calculator.py:498); "farneback": dense
+    Farneback flow sampled on a grid."""
     import torch
     a, b = np.ascontiguousarray(img0, dtype=np.uint8), np.ascontiguousarray(img1, dtype=np.uint8)
     if a.shape != b.shape or a.ndim != 3:
         raise ValueError("flow_vectors needs two CHW uint8 images of the same shape, got %s and %s" % (a.shape, b.shape))
     c, h, w = a.shape
-    eng = _aux_engine("flow", w, h, c)
+    eng = _aux_engine("flow", w, h, c, **({} if method == "lk" else {"flow": method}))
     d0, d1 = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
     vec = torch.zeros((1, eng.K, 4), dtype=torch.float32, device="cuda")
     cnt = torch.zeros(1, dtype=torch.int32, device="cuda")

@@ -72,12 +72,26 @@ typedef struct {
     int32_t lk_win;                        /* 15   */
     int32_t lk_max_level;                  /* 2    */
     int32_t lk_max_iter;                   /* 10   */
-    int32_t reserved0;
+    int32_t flow_method;                   /* EIGEN_FLOW_LK (0, what the reference calls) or EIGEN_FLOW_FARNEBACK (1) */
     double lk_quality_level;               /* 0.3  */
     double lk_min_distance;                /* 7    */
     double lk_epsilon;                     /* 0.03 */
     double lk_min_eig_thr;                 /* 1e-4 */
+    /* Dense flow after Farneback, cv::calcOpticalFlowFarneback with the parameters of OpenCV's dense-flow tutorial
+     * (pyr_scale is fixed at 0.5).  The reference never calls a dense-flow routine (its only flow call is lucas_kanade,
+     * generate_illusion.py:549-550); the option answers the north star's "Farneback/Lucas-Kanade flow".  The dense field is
+     * sampled every fb_step pixels from fb_step/2 (the grid of OpenCV's samples/python/opt_flow.py; the step grows by
+     * multiples of fb_step until the grid fits lk_max_corners vectors) into the same [x, y, dx, dy] vectors. */
+    int32_t fb_levels;                     /* 3  (levels on top of the full resolution; fewer if a level would be < 32 px) */
+    int32_t fb_winsize;                    /* 15 (odd, <= 33) */
+    int32_t fb_iterations;                 /* 3  */
+    int32_t fb_poly_n;                     /* 5  (<= 7) */
+    int32_t fb_step;                       /* 16 */
+    int32_t reserved1;
+    double fb_poly_sigma;                  /* 1.2 */
 } eigen_config;
+
+typedef enum { EIGEN_FLOW_LK = 0, EIGEN_FLOW_FARNEBACK = 1 } eigen_flow_method;
 
 /* A batch of CPPN genomes, flattened by the host (create_cppn semantics, generate_illusion.py:384-389):
  * per genome g, nodes node_off[g]..node_off[g+1]-1 are in topological order; node n has incoming edges
@@ -121,7 +135,9 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* h_tensors, in
 int eigen_set_grid(eigen_engine* e, const double* h_planes, int32_t n_planes);
 
 /* Replaces get_image_from_cppn (generate_illusion.py:372-460) for a whole batch.
- * d_images: uint8 [n_genomes][c_dim][H][W].  bg: 1 white / 0 black.  gradient: 1 / 0 as in the reference. */
+ * d_images: uint8 [n_genomes][c_dim][H][W].  bg: 1 white / 0 black.  gradient: 1 / 0 as in the reference's
+ * get_image_from_cppn (generate_illusion.py:372-460); 2 = get_equilum_image_from_cppn (:333-367, c_dim 3): the three
+ * output nodes are h, s, v, converted per pixel as colorsys.hsv_to_rgb does, bg applied to h, s and v beforehand. */
 int eigen_render_cppn(eigen_engine* e, const eigen_genome_batch* h_genomes, int32_t bg, int32_t gradient,
                       uint8_t* d_images, void* stream);
 
@@ -189,6 +205,10 @@ int eigen_get_timings(eigen_engine* e, double* h_ms6);
  *  that are identically zero after reset_state()), NI, TW, launches, total_ms, FLOPs per launch per image (2 x the
  *  multiply-accumulates executed), n_nblk].  At most 6 rows per layer.  reset=1 clears the accumulators after reading. */
 int eigen_conv_profile(eigen_engine* e, int32_t enable, int32_t reset, double* h_out, int32_t max_ops, int32_t* n_ops);
+
+/* Stage-level read-back for the parity tests: the dense field of the last eigen_flow call of an engine created with
+ * flow_method = EIGEN_FLOW_FARNEBACK, float [batch][2][H][W] (dx plane, dy plane). */
+int eigen_debug_dense_flow(eigen_engine* e, int32_t batch, float* h_flow, void* stream);
 
 /* Stage-level read-back for the parity tests: corners / tracked points / status of the last eigen_flow call. */
 int eigen_debug_corners(eigen_engine* e, int32_t batch, float* h_corners, int32_t* h_ncorners, float* h_next,

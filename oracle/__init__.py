@@ -33,8 +33,8 @@ GATES = ("i", "f", "c", "o")
 def build(force=False):
     """Compile oracle/eig_oracle.c -> oracle/libeig_oracle.so (gcc, see oracle/Makefile)."""
     so = os.path.join(_HERE, "libeig_oracle.so")
-    src = os.path.join(_HERE, "eig_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("eig_oracle.c", "farneback.c", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(so) < os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libeig_oracle.so"])
     return so
 
@@ -63,6 +63,8 @@ def lib():
         _LIB.eig_oracle_lucas_kanade.restype = ctypes.c_int
         _LIB.eig_oracle_good_features.restype = ctypes.c_int
         _LIB.eig_oracle_conv_chain.restype = ctypes.c_int
+        for f in ("eig_oracle_farneback", "eig_oracle_fb_vectors", "eig_oracle_fb_levels", "eig_oracle_fb_grid_step"):
+            getattr(_LIB, f).restype = ctypes.c_int
     return _LIB
 
 
@@ -193,3 +195,40 @@ def lucas_kanade(img0, img1, params=None):
     n = lib().eig_oracle_lucas_kanade(_p(img0, ctypes.c_uint8), _p(img1, ctypes.c_uint8), ctypes.c_int(c), ctypes.c_int(h),
                                       ctypes.c_int(w), ctypes.byref(params), _p(vec, ctypes.c_float))
     return vec[:n].copy()
+
+
+class FBParams(ctypes.Structure):
+    """cv::calcOpticalFlowFarneback parameters of OpenCV's dense-flow tutorial + the vector sampling grid (oracle/farneback.c)."""
+    _fields_ = [("levels", ctypes.c_int), ("winsize", ctypes.c_int), ("iterations", ctypes.c_int), ("poly_n", ctypes.c_int),
+                ("poly_sigma", ctypes.c_double), ("step", ctypes.c_int), ("max_vectors", ctypes.c_int)]
+
+    def __init__(self, levels=3, winsize=15, iterations=3, poly_n=5, poly_sigma=1.2, step=16, max_vectors=100):
+        super().__init__(levels, winsize, iterations, poly_n, poly_sigma, step, max_vectors)
+
+
+def farneback_flow(g0, g1, params=None):
+    """g0/g1: uint8 gray [H,W] -> dense flow float32 [H,W,2] (dx, dy)."""
+    params = params or FBParams()
+    g0 = np.ascontiguousarray(g0, dtype=np.uint8); g1 = np.ascontiguousarray(g1, dtype=np.uint8)
+    h, w = g0.shape
+    flow = np.zeros((h, w, 2), dtype=np.float32)
+    rc = lib().eig_oracle_farneback(_p(g0, ctypes.c_uint8), _p(g1, ctypes.c_uint8), ctypes.c_int(h), ctypes.c_int(w), ctypes.byref(params),
+                                    _p(flow, ctypes.c_float))
+    if rc != 0:
+        raise ValueError("farneback: unsupported size/parameters")
+    return flow
+
+
+def farneback_vectors(flow, params=None):
+    """dense flow -> float32 [n,4] rows [x, y, dx, dy] on the sampling grid."""
+    params = params or FBParams()
+    flow = np.ascontiguousarray(flow, dtype=np.float32)
+    h, w, _ = flow.shape
+    vec = np.zeros((max(params.max_vectors, 1), 4), dtype=np.float32)
+    n = lib().eig_oracle_fb_vectors(_p(flow, ctypes.c_float), ctypes.c_int(h), ctypes.c_int(w), ctypes.byref(params), _p(vec, ctypes.c_float))
+    return vec[:n].copy()
+
+
+def farneback(img0, img1, params=None):
+    """img0/img1: uint8 [C,H,W] -> float32 [n,4] vectors (gray conversion as for Lucas-Kanade)."""
+    return farneback_vectors(farneback_flow(gray(img0), gray(img1), params), params)

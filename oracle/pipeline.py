@@ -12,13 +12,15 @@ from oracle import cppn, scores
 PAIR_POPULATION, PAIR_SINGLE = 0, 1
 
 
-def image_vectors(img, weights, channels, w, h, pairing=PAIR_POPULATION, n_repeat=20, requant=False, lk_params=None):
-    """img uint8 [C,H,W] -> flow vectors float32 [n,4]."""
+def image_vectors(img, weights, channels, w, h, pairing=PAIR_POPULATION, n_repeat=20, requant=False, lk_params=None, flow="lk",
+                  fb_params=None):
+    """img uint8 [C,H,W] -> flow vectors float32 [n,4].  flow: "lk" (the reference's call) or "farneback" (oracle/farneback.c)."""
     n_ext = 1 if pairing == PAIR_POPULATION else 2
     frames = oracle.prednet_rollout(weights, channels, w, h, img, n_repeat=n_repeat, n_ext=n_ext, requant=requant)
+    fn = (lambda a, b: oracle.lucas_kanade(a, b, lk_params)) if flow == "lk" else (lambda a, b: oracle.farneback(a, b, fb_params))
     if pairing == PAIR_POPULATION:  # prediction@20 -> first extension (generate_illusion.py:543-550)
-        return oracle.lucas_kanade(frames[n_repeat - 1], frames[n_repeat], lk_params)
-    return oracle.lucas_kanade(img, frames[n_repeat + 1], lk_params)  # original -> 2nd extension (fitness_calculator.py:493-498)
+        return fn(frames[n_repeat - 1], frames[n_repeat])
+    return fn(img, frames[n_repeat + 1])  # original -> 2nd extension (fitness_calculator.py:493-498)
 
 
 def image_fitness(img, weights, channels, w, h, structure, pairing=PAIR_POPULATION, **kw):

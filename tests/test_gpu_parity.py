@@ -83,8 +83,10 @@ def _render_setup(w, h, c_dim, n, seed, structure=1):
     return cfg, pop, grid
 
 
-@pytest.mark.parametrize("c_dim,gradient,bg", [(3, 1, 1), (1, 1, 1), (3, 0, 1), (1, 0, 0), (3, 1, 0)])
+@pytest.mark.parametrize("c_dim,gradient,bg", [(3, 1, 1), (1, 1, 1), (3, 0, 1), (1, 0, 0), (3, 1, 0), (3, 2, 1), (3, 2, 0)])
 def test_cppn_render_matches_oracle(cuda, oracle_lib, c_dim, gradient, bg):
+    """gradient 1 / 0: get_image_from_cppn (generate_illusion.py:372-460); gradient 2: get_equilum_image_from_cppn (:333-367),
+    h,s,v nodes through colorsys.hsv_to_rgb per pixel."""
     import torch
     from oracle import cppn
     w, h = 64, 48
@@ -96,7 +98,7 @@ def test_cppn_render_matches_oracle(cuda, oracle_lib, c_dim, gradient, bg):
                 c.enabled = False
     e = _eng(w, h, [c_dim, 4, 8], len(pop))
     e.set_grid([grid["x_mat"], grid["y_mat"]])
-    gb = genome_mod.GenomeBatch([g for _, g in pop], cfg, c_dim if gradient == 1 else 1)
+    gb = genome_mod.GenomeBatch([g for _, g in pop], cfg, c_dim if gradient in (1, 2) else 1)
     img = torch.zeros((len(pop), c_dim, h, w), dtype=torch.uint8, device=cuda)
     e.render_cppn(gb, img, bg=bg, gradient=gradient)
     torch.cuda.synchronize()
@@ -202,6 +204,48 @@ def test_flow_vectors_bit_exact(cuda, oracle_lib, w, h, c):
         assert np.array_equal(v[b, :n[b]], ref), np.abs(v[b, :n[b]] - ref).max()
         total += len(ref)
     assert total > 50 and n[-1] == 0
+
+
+@pytest.mark.parametrize("w,h,c,B", [(64, 64, 1, 4), (160, 120, 3, 3), (256, 256, 3, 2), (96, 40, 3, 2)])
+def test_farneback_dense_flow_bit_exact(cuda, oracle_lib, w, h, c, B):
+    """The Farneback option (csrc/farneback_kernels.h) against oracle/farneback.c: dense field and sampled vectors, bit for bit."""
+    import torch
+    rng = np.random.default_rng(11)
+    i0, i1 = _textured_pairs(rng, B, c, h, w)
+    i0[-1] = 77  # a flat first frame
+    e = _eng(w, h, [c, 4, 8], B, flow="farneback")
+    d0, d1 = torch.from_numpy(i0).to(cuda), torch.from_numpy(i1).to(cuda)
+    dv = torch.zeros((B, e.K, 4), dtype=torch.float32, device=cuda)
+    dc = torch.zeros(B, dtype=torch.int32, device=cuda)
+    e.flow(d0, c * h * w, d1, c * h * w, B, dv, dc)
+    torch.cuda.synchronize()
+    dense = e.debug_dense_flow(B)
+    v, n = dv.cpu().numpy(), dc.cpu().numpy()
+    params = oracle_lib.FBParams(max_vectors=e.K)
+    moved = 0.0
+    for b in range(B):
+        ref = oracle_lib.farneback_flow(oracle_lib.gray(i0[b]), oracle_lib.gray(i1[b]), params)
+        assert np.array_equal(dense[b].transpose(1, 2, 0), ref), np.abs(dense[b].transpose(1, 2, 0) - ref).max()
+        rv = oracle_lib.farneback_vectors(ref, params)
+        assert n[b] == len(rv) and np.array_equal(v[b, :n[b]], rv)
+        moved = max(moved, float(np.abs(ref).max()))
+    assert moved > 0.05  # the shifted copies do move
+
+
+def test_farneback_end_to_end_fitness(cuda, oracle_lib):
+    """The whole path with flow="farneback": the same fitness as the oracle pipeline with its Farneback restatement."""
+    from evolutionary_illusion_generator_amd import fitness
+    from oracle import grids, pipeline
+    w, h, ch, structure = 64, 64, [1, 8, 16], 2
+    cfg = synth.make_config(2, 1)
+    pop = synth.make_population(6, cfg, seed=4)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=2)
+    got = fitness.evaluate_population(structure, [g for _, g in pop], wts, cfg, w, h, ch, c_dim=1, flow="farneback")
+    grid = grids.create_grid(structure, w, h, 10)
+    ref = np.array([pipeline.genome_fitness(g, cfg, grid, wts, ch, w, h, structure, flow="farneback") for _, g in pop])
+    assert np.allclose(got, ref, rtol=1e-9, atol=1e-12) and np.isfinite(got).all() and (got != 0).any(), (got, ref)
+    lk = fitness.evaluate_population(structure, [g for _, g in pop], wts, cfg, w, h, ch, c_dim=1)
+    assert lk.shape == got.shape  # the default path is untouched by the option (separate engine)
 
 
 @pytest.mark.parametrize("structure", [0, 1, 2, 3])

@@ -203,3 +203,56 @@ def test_fitness_is_insensitive_to_the_fp32_summation_order_within_the_north_sta
             assert abs(canonical - other) <= 1e-4 * max(abs(canonical), abs(other)), (st, canonical, other)
             nonzero += canonical != 0
     assert nonzero >= 6
+
+
+def test_hsv_renderer_is_colorsys_per_pixel():
+    """oracle/cppn.py: the h,s,v renderer (generate_illusion.py:333-367) = colorsys.hsv_to_rgb on every pixel, bg in all three
+    planes, uint8(rgb * 255); out-of-range and non-finite node values do not raise."""
+    import colorsys
+    from oracle import cppn
+    rng = np.random.default_rng(5)
+    w, h = 16, 8
+    planes = [rng.uniform(-0.5, 1.5, w * h) for _ in range(3)]
+    planes[1][:10] = 0.0                      # s == 0 -> gray
+    planes[0][10:14] = [np.nan, np.inf, -np.inf, 1e300]
+    x_mat = rng.uniform(0, 1, (h, w)); x_mat[0, :5] = -1
+    img = cppn.postprocess(planes, x_mat, 3, w, h, bg=1, gradient=2)
+    assert img.shape == (h, w, 3) and img.dtype == np.uint8
+    assert (img[0, :5] == np.array([255, 0, 0], np.uint8)).all()     # hsv(1,1,1): the reference fills h, s and v with bg
+    for i in range(20, w * h):
+        if x_mat.reshape(-1)[i] == -1:
+            continue
+        r = colorsys.hsv_to_rgb(planes[0][i], planes[1][i], planes[2][i])
+        assert (img.reshape(-1, 3)[i] == cppn.to_u8(np.array(r) * 255.0)).all()
+    for i in range(5, 10):
+        v = cppn.to_u8(np.array([planes[2][i] * 255.0]))[0]
+        assert (img.reshape(-1, 3)[i] == v).all()
+
+
+def test_farneback_oracle_recovers_a_translation(oracle_lib):
+    """oracle/farneback.c (the unpinned restatement of cv::calcOpticalFlowFarneback): a smooth texture moved by (+2, -1) px
+    gives a dense field of (+2, -1) away from the borders, and the sampled vectors sit on the documented grid."""
+    from scipy import ndimage
+    rng = np.random.default_rng(0)
+    H, W = 128, 160
+    base = ndimage.gaussian_filter(rng.normal(0, 1, (H + 40, W + 40)), 3.0)
+    base = (base - base.min()) / (base.max() - base.min()) * 255
+
+    def crop(dy, dx):
+        return ndimage.shift(base, (dy, dx), order=3)[20:20 + H, 20:20 + W].clip(0, 255).astype(np.uint8)
+
+    fl = oracle_lib.farneback_flow(crop(0, 0), crop(-1.0, 2.0))
+    core = fl[30:-30, 30:-30]
+    assert abs(np.median(core[..., 0]) - 2.0) < 0.02 and abs(np.median(core[..., 1]) + 1.0) < 0.02
+    assert np.percentile(np.abs(core[..., 0] - 2.0), 90) < 0.1 and np.percentile(np.abs(core[..., 1] + 1.0), 90) < 0.1
+    v = oracle_lib.farneback_vectors(fl)
+    assert v.shape == (80, 4)                       # 160/16 x 128/16
+    assert (v[:3, :2] == [[8, 8], [24, 8], [40, 8]]).all() and (v[10, :2] == [8, 24]).all()
+    assert np.array_equal(v[:, 2], fl[v[:, 1].astype(int), v[:, 0].astype(int), 0])
+    assert len(oracle_lib.farneback_vectors(np.zeros_like(fl))) == 0   # exactly-zero flow carries no vector
+    # identical frames: no motion away from the borders (the last row / column take UpdateMatrices' out-of-range branch)
+    z = oracle_lib.farneback_flow(crop(0, 0), crop(0, 0))
+    assert np.abs(z[30:-30, 30:-30]).max() < 1e-4 and np.abs(z).max() < 0.5
+    # level count and grid step rules
+    assert oracle_lib.lib().eig_oracle_fb_levels(256, 256, 3) == 3 and oracle_lib.lib().eig_oracle_fb_levels(120, 160, 3) == 1
+    assert oracle_lib.lib().eig_oracle_fb_grid_step(256, 256, 16, 100) == 32
