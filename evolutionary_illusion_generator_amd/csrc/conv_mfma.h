@@ -170,7 +170,11 @@ template <int NI, int TW, bool VEC> constexpr int conv_in_floats()
 {
     return conv_fast_dma<NI, TW, VEC>() ? ((KC * TileGeom<TW, VEC>::PLANE / 4 + 255) / 256) * 1024 : KC * TileGeom<TW, VEC>::PLANE;
 }
-template <int NI, int TW, bool VEC, int TAPS = 9> constexpr int conv_lds_bytes() { return 2 * (conv_in_floats<NI, TW, VEC>() + conv_w_floats<NI, TW, VEC, TAPS>()) * 4; }
+// ONEKB: operators whose whole K fits ONE K-block (ConvA of the image layer: 6 channels) never stage a second buffer
+template <int NI, int TW, bool VEC, int TAPS = 9, bool ONEKB = false> constexpr int conv_lds_bytes()
+{
+    return (ONEKB ? 1 : 2) * (conv_in_floats<NI, TW, VEC>() + conv_w_floats<NI, TW, VEC, TAPS>()) * 4;
+}
 
 #ifndef EIG_TIMING
 #define EIG_TIMING 0  // measurement-only builds: per-wave s_memtime breakdown of the K loop into a.dbg
@@ -183,8 +187,12 @@ constexpr int CONV_THREADS = 256;  // 4 waves per block
 #ifndef EIG_UP4_OCC
 #define EIG_UP4_OCC 2  // the 2x2-form pass would fit a third block per CU (88 VGPRs, 48 KB of LDS); measured: no faster (96.9 vs 95.8 ms)
 #endif
-template <int NI, int TW, int EPI, bool VEC>
-__global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW == 16 && VEC) ? EIG_UP4_OCC : EIG_CONV_OCC) conv3x3_mfma(const ConvArgs a)
+#ifndef EIG_ONEKB_OCC
+#define EIG_ONEKB_OCC 4  // single-K-block operators: one LDS buffer (32 KB), four blocks per CU -- their time is prologue + DMA round trip +
+#endif                   // epilogue around 216 MFMAs per wave, which only other blocks' MFMAs can cover
+template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false>
+__global__ void __launch_bounds__(CONV_THREADS, ONEKB ? EIG_ONEKB_OCC : ((EPI == EPI_UP4 && NI == 4 && TW == 16 && VEC) ? EIG_UP4_OCC : EIG_CONV_OCC))
+conv3x3_mfma(const ConvArgs a)
 {
     using G = TileGeom<TW, VEC>;
     constexpr int TH = G::TH, NIMG = G::NIMG, S = G::S, XO = G::XO, PH = G::PH, PLANE = G::PLANE;
@@ -554,7 +562,9 @@ __global__ void __launch_bounds__(CONV_THREADS, (EPI == EPI_UP4 && NI == 4 && TW
                         for (int ni = 0; ni < NI; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
                 }
-                if constexpr (FAST) {
+                if constexpr (ONEKB) {
+                    // nothing to stage: the only K-block is being computed on (and there is no second LDS buffer)
+                } else if constexpr (FAST) {
 #pragma unroll
                     for (int j = 0; j < NOPS; ++j)
                         if (j * NSTEP / NOPS == st) dma_fast(j, nxt_kb, rs_nxt, soff_in_nxt, soff_w_nxt, nxt);

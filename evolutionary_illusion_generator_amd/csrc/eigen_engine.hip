@@ -304,15 +304,15 @@ static std::vector<float> pack_weights_up4(const ConvOp& op, const float* const 
     return out;
 }
 
-template <int NI, int TW, int EPI, bool VEC> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
+template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
-    constexpr int lds = conv_lds_bytes<NI, TW, VEC, (EPI == EPI_UP4) ? 4 : 9>();
+    constexpr int lds = conv_lds_bytes<NI, TW, VEC, (EPI == EPI_UP4) ? 4 : 9, ONEKB>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC, ONEKB>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
     return hipGetLastError();
 }
 
@@ -378,7 +378,13 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     switch (op.epi) {
         case EPI_LSTM: r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec); break;
         case EPI_LSTM_PACKED: r = (op.TW == 16) ? launch_inst<1, 16, EPI_LSTM_PACKED>(a, grid, st, vec) : launch_inst<1, 8, EPI_LSTM_PACKED>(a, grid, st, vec); break;
-        case EPI_CONVA: r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st, vec); break;
+        case EPI_CONVA: {
+            // the image layer's ConvA (K = 9 x 6 channels): one K-block, its own instantiation (conv_mfma.h: ONEKB)
+            static const bool onekb = !(getenv("EIGEN_NO_ONEKB") && atoi(getenv("EIGEN_NO_ONEKB")));  // A/B measurements only
+            if (onekb && op.NI == 3 && op.TW == 16 && vec && op.nsrc == 1 && pad4(op.src_C[0]) <= KC) r = launch_inst2<3, 16, EPI_CONVA, true, true>(a, grid, st);
+            else r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st, vec);
+            break;
+        }
         case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st, vec); break;
         case EPI_UP4: r = launch_epi<EPI_UP4>(op.NI, op.TW, a, grid, st, vec); break;
         default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec); break;

@@ -21,7 +21,7 @@ if "--analyze-only" not in sys.argv:
     fitness.evaluate_population(1, genomes, wts, cfg, W, H, ch, c_dim=3, max_batch=pop)
     torch.cuda.synchronize()
 
-for path in sorted(glob.glob(os.path.join(out_dir, "timeline_H*.bin"))):
+for path in sorted(glob.glob(os.path.join(out_dir, "timeline_H*.bin"))):   # one file per ConvLSTM op and per 2x2-form pass (*_up4)
     r = np.fromfile(path, dtype=np.uint64).reshape(-1, 4, 8)          # [block][wave][field]
     live = r[:, 0, 0] != 0
     r = r[live]
@@ -35,10 +35,9 @@ for path in sorted(glob.glob(os.path.join(out_dir, "timeline_H*.bin"))):
     print("==", os.path.basename(path), "blocks", nb, "span %.3f ms @2.4GHz-equivalent cycles %d" % ((t_end.max() - t0) / 100e6 * 1e3, t_end.max() - t0))
     print("   per wave: prologue %.0f  loop %.0f  epilogue %.0f  total %.0f  (s_memtime ticks)" % (
         (t_l0 - t_entry).mean(), (t_l1 - t_l0).mean(), (t_end - t_l1).mean(), (t_end - t_entry).mean()))
-    t_mid = r[:, :, 6].astype(np.int64)
-    okm = t_mid > 0
-    print("   in-loop: mfma section %.0f  barrier %.0f; epilogue: loads landed after %.0f, math+stores %.0f" % (
-        r[:, :, 5].mean(), r[:, :, 7].mean(), (t_mid - t_l1)[okm].mean(), (t_end - t_mid)[okm].mean()))
+    t_setup, t_prewait = r[:, :, 6].astype(np.int64), r[:, :, 7].astype(np.int64)   # conv_mfma.h: t_setup, t_prewait
+    print("   prologue split: entry -> slots/descriptors ready %.0f, -> first K-block issued, gather addresses ready %.0f, -> landed + barrier %.0f;"
+          " MFMA sections of the K loop %.0f" % (np.median(t_setup - t_entry), np.median(t_prewait - t_setup), np.median(t_l0 - t_prewait), r[:, :, 5].mean()))
     print("   distinct SIMDs %d, CUs %d, xcc ids %s; blockIdx%%8 == xcc for %.1f%% of blocks" % (
         len(np.unique(key)), len(np.unique(key // 4)), np.unique(xcc).tolist(),
         100.0 * (xcc[:, 0] == (np.nonzero(live)[0] % 8)).mean()))
