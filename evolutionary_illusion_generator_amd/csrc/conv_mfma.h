@@ -49,7 +49,8 @@ namespace eig {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { EPI_RAW = 0, EPI_LSTM = 1, EPI_CONVA = 2, EPI_CONVP = 3, EPI_LSTM_PACKED = 4, EPI_UP4 = 5 };
+enum { EPI_RAW = 0, EPI_LSTM = 1, EPI_CONVA = 2, EPI_CONVP = 3, EPI_LSTM_PACKED = 4, EPI_UP4 = 5, EPI_UP4C = 6 };
+constexpr int epi_taps(int epi) { return (epi == EPI_UP4 || epi == EPI_UP4C) ? 4 : 9; }
 
 struct ConvSrc {
     const float* ptr;  // [B][C][H>>up][W>>up]
@@ -86,7 +87,7 @@ struct ConvArgs {
     int requant;
     int tile_map;       // block -> tile order, see the kernel
     // EPI_RAW
-    float* raw;         // [B][Cout][H][W];  EPI_UP4: [B][4 parity classes][n_nblk*NB][H][W]
+    float* raw;         // [B][Cout][H][W];  EPI_UP4: [B][4 parity classes][n_nblk*NB][H][W];  EPI_UP4C: [B][4][n_nblk*16][H][W]
     // Chain of an unpooled source (written by an EPI_UP4 launch at HALF this resolution), [B][4][n_nblk*NB][H/2][W/2], added to
     // this launch's chain with one fp32 addition after the K loop; nullptr: none.
     const float* acc_init;
@@ -202,12 +203,16 @@ conv3x3_mfma(const ConvArgs a)
     // computes, for its parity class (py, px), the partial chains of the output pixels (2Y+py, 2X+px) of its tile:
     // k = (channel, a, b), 4 taps per channel, tap (a, b) reads source pixel (Y+a-1+py, X+b-1+px) -- inside the same
     // haloed tile a 3x3 convolution stages.  The ConvLSTM launch that follows starts its accumulators from the result.
-    constexpr int TAPS = (EPI == EPI_UP4) ? 4 : 9;
+    // EPI_UP4C: the same pass for operators with <= 16 output columns (the packed image-layer ConvLSTM): ONE block computes all four
+    // classes of its tile -- the four N-tiles of the NI = 4 kernel ARE the four classes, each with its own gather (the class
+    // only shifts the tap window) and its own 16 weight columns, so the tile is staged once instead of four times.
+    constexpr int TAPS = epi_taps(EPI);
+    static_assert(EPI != EPI_UP4C || NI == 4, "EPI_UP4C: the four N-tiles are the four parity classes");
     const unsigned long long t_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool FAST = conv_fast_dma<NI, TW, VEC>();
     constexpr int INF = conv_in_floats<NI, TW, VEC>();  // floats of the input area (KC * PLANE, padded for FAST)
-    constexpr int BUF = INF + conv_w_floats<NI, TW, VEC, (EPI == EPI_UP4) ? 4 : 9>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
+    constexpr int BUF = INF + conv_w_floats<NI, TW, VEC, epi_taps(EPI)>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -542,11 +547,16 @@ conv3x3_mfma(const ConvArgs a)
                 if (FAST || (TAPS == 9 ? (st < 9 || cur_kb.kc > 4) : st < cur_kb.kc)) {
                     const int per = st / 9, s9 = st % 9;
                     float av[4], bv[NI];
+                    float avc[4][3];  // EPI_UP4C: the gathers of classes 1..3
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) {
                         const int moff = UP ? ((TW == 16) ? ((mi >> 1) * SU + (mi & 1) * 4) : (mi * SU))
                                             : ((TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S));
                         av[mi] = (TAPS == 9) ? in_lds[ad[s9] + per * 4 * PL + moff] : in_lds[addr4 + st * PL + moff];
+                        if constexpr (EPI == EPI_UP4C) {  // class c = (py, px) shifts the tap window by (py, px)
+#pragma unroll
+                            for (int c = 1; c < 4; ++c) avc[mi][c - 1] = in_lds[addr4 + ((c >> 1) * S + (c & 1)) + st * PL + moff];
+                        }
                     }
                     if (NI == 4) {  // one ds_read_b128
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(w_lds + st * 4 * NB);
@@ -560,7 +570,7 @@ conv3x3_mfma(const ConvArgs a)
                     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
-                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+                            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32((EPI == EPI_UP4C && ni > 0) ? avc[mi][ni > 0 ? ni - 1 : 0] : av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
                 }
                 if constexpr (ONEKB) {
                     // nothing to stage: the only K-block is being computed on (and there is no second LDS buffer)
@@ -647,10 +657,12 @@ conv3x3_mfma(const ConvArgs a)
                     if (gy < a.H && gx < a.W) dst[gy * a.W + gx] = acc[mi][ni][reg];
                 }
             }
-        } else if (EPI == EPI_UP4) {
+        } else if (EPI == EPI_UP4 || EPI == EPI_UP4C) {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
-                float* dst = a.raw + (((size_t)b * 4 + cls) * a.n_nblk * NB + nblk * NB + ni * 16 + col) * HW;
+                // EPI_UP4C: N-tile ni is class ni of the 16 output columns of this N-block
+                float* dst = (EPI == EPI_UP4C) ? a.raw + (((size_t)b * 4 + ni) * a.n_nblk * 16 + nblk * 16 + col) * HW
+                                               : a.raw + (((size_t)b * 4 + cls) * a.n_nblk * NB + nblk * NB + ni * 16 + col) * HW;
                 if (VEC && gx0 + 1 < a.W) {  // W % 4 == 0, gx0 even: the two pixels of a window row are one aligned 8-byte store
                     typedef float f32x2 __attribute__((ext_vector_type(2)));
                     *reinterpret_cast<f32x2*>(dst + gy0 * a.W + gx0) = (f32x2){acc[mi][ni][0], acc[mi][ni][1]};

@@ -304,9 +304,29 @@ static std::vector<float> pack_weights_up4(const ConvOp& op, const float* const 
     return out;
 }
 
+// EPI_UP4C (conv_mfma.h): the four classes are the four N-tiles of ONE block: [n_nblk][krows][16 columns][4 classes]
+static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const srcw[4], int lstm)
+{
+    const int Cin = op.src_C[0];
+    std::vector<float> out((size_t)op.n_nblk * op.krows * 64, 0.0f);
+    for (int nb = 0; nb < op.n_nblk; ++nb)
+        for (int c = 0; c < Cin; ++c)
+            for (int tap = 0; tap < 4; ++tap)
+                for (int n = 0; n < 16; ++n) {
+                    int g = 0, o;
+                    if (lstm == 2) { g = n / 4; o = n % 4; }
+                    else o = nb * 16 + n;
+                    if (o >= op.Cout) continue;
+                    for (int cls = 0; cls < 4; ++cls)
+                        out[(((size_t)nb * op.krows + (size_t)c * 4 + tap) * 16 + n) * 4 + cls] =
+                            presum_up_weight(srcw[g] + ((size_t)o * Cin + c) * 9, cls >> 1, cls & 1, tap >> 1, tap & 1);
+                }
+    return out;
+}
+
 template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
-    constexpr int lds = conv_lds_bytes<NI, TW, VEC, (EPI == EPI_UP4) ? 4 : 9, ONEKB>();
+    constexpr int lds = conv_lds_bytes<NI, TW, VEC, epi_taps(EPI), ONEKB>();
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -387,6 +407,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         }
         case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st, vec); break;
         case EPI_UP4: r = launch_epi<EPI_UP4>(op.NI, op.TW, a, grid, st, vec); break;
+        case EPI_UP4C: r = launch_inst2<4, 16, EPI_UP4C, true>(a, grid, st); break;  // chosen only for 16-wide tiles and 16-byte staging
         default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec); break;
     }
 #if EIG_TIMING
@@ -624,9 +645,15 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
                 u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W);
                 u.krows = pad4(u.src_C[0]) * 4;
                 u.macs = (double)y.H * y.W * 4 * C * u.src_C[0] * 4;  // 4 taps per output pixel and channel instead of 9
-                std::vector<float> pku = pack_weights_up4(u, wx1, lstm_mode);
-                if (upload(&u.d_wpk, pku.data(), pku.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, unpooled source)", l);
                 const size_t need = (size_t)e->B * 4 * u.n_nblk * u.NI * 16 * u.H * u.W;
+                // <= 16 columns (the packed image-layer ConvLSTM): all four classes in one block (EPI_UP4C) where the wide staging path exists
+                static const bool up4c = !(getenv("EIGEN_NO_UP4C") && atoi(getenv("EIGEN_NO_UP4C")));  // A/B measurements only
+                std::vector<float> pku;
+                if (up4c && op.NI == 1 && lstm_mode == 2 && u.TW == 16 && (u.W % 4) == 0) {
+                    u.epi = EPI_UP4C; u.NI = 4;
+                    pku = pack_weights_up4c(u, wx1, lstm_mode);
+                } else pku = pack_weights_up4(u, wx1, lstm_mode);
+                if (upload(&u.d_wpk, pku.data(), pku.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, unpooled source)", l);
                 if (need > e->raw4_floats) {
                     if (e->d_raw4) { (void)hipFree(e->d_raw4); e->d_raw4 = nullptr; e->raw4_floats = 0; }
                     if (hipMalloc((void**)&e->d_raw4, need * sizeof(float)) != hipSuccess) return fail(EIGEN_ERR_HIP, "hipMalloc(%zu) for the unpooled-source partial chains", need * sizeof(float));
