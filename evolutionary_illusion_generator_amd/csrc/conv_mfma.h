@@ -849,6 +849,83 @@ __global__ void __launch_bounds__(P0_TX * P0_TY) convp0_direct_kernel(const floa
     }
 }
 
+// ConvLSTM of the image layer (C = 1 or 3 channels, 12 gate outputs at most, K = 9 x 3C): like ConvP_0 it is bound by the fixed
+// cost of an MFMA block (prologue, two DMA round trips and the epilogue around 108 MFMAs per wave), not by arithmetic.  One thread
+// per pixel computes all 4 x C chains with the same fp32 fma order as the MFMA path -- source E_0 (channel, ky, kx), then h_0;
+// out-of-image taps multiply a staged 0 -- adds the chain of the unpooled source (one fp32 addition, ConvArgs::acc_init: class
+// (y & 1, x & 1) of source pixel (y / 2, x / 2), column = gate * 4 + channel as the packed MFMA layout has it) and runs the gate
+// epilogue of EPI_LSTM_PACKED verbatim: bit-identical results.  T0: the step-0 operator (first half of E_0 only, no h_0).
+// wgt: [4 gates][C][2C][9] for E_0 followed by [4][C][C][9] for h_0 (OIHW per gate, as the weight table holds them).
+constexpr int L0_TX = 64, L0_TY = 4;
+template <int C, bool T0>
+__global__ void __launch_bounds__(L0_TX * L0_TY) lstm0_direct_kernel(const float* __restrict__ srcE, const float* __restrict__ srcH,
+                                                                    const float* __restrict__ wgt, const ConvArgs a)
+{
+    constexpr int CE = T0 ? C : 2 * C, CH = T0 ? 0 : C;
+    __shared__ float tile[CE + (CH ? CH : 1)][L0_TY + 2][L0_TX + 2];
+    const int tx = threadIdx.x & (L0_TX - 1), ty = threadIdx.x / L0_TX;
+    const int x0 = blockIdx.x * L0_TX, y0 = blockIdx.y * L0_TY, b = blockIdx.z;
+    const int HW = a.H * a.W;
+    constexpr int PLANE = (L0_TY + 2) * (L0_TX + 2);
+    for (int i = threadIdx.x; i < (CE + CH) * PLANE; i += L0_TX * L0_TY) {
+        const int c = i / PLANE;
+        const int r = i - c * PLANE;
+        const int yy = r / (L0_TX + 2), xx = r - yy * (L0_TX + 2);
+        const int gy = y0 + yy - 1, gx = x0 + xx - 1;
+        float v = 0.0f;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W)
+            v = (c < CE) ? srcE[((size_t)b * 2 * C + c) * HW + gy * a.W + gx] : srcH[((size_t)b * C + (c - CE)) * HW + gy * a.W + gx];
+        tile[c][yy][xx] = v;
+    }
+    __syncthreads();
+    const int gy = y0 + ty, gx = x0 + tx;
+    if (gy >= a.H || gx >= a.W) return;
+    const int pix = gy * a.W + gx;
+    const float* wE = wgt;
+    const float* wH = wgt + 4 * C * 2 * C * 9;
+    const int Hs = a.H >> 1, Ws = a.W >> 1;
+    const size_t up_hw = (size_t)Hs * Ws;
+    const float* up = a.acc_init ? a.acc_init + (((size_t)b * 4 + ((gy & 1) * 2 + (gx & 1))) * 16) * up_hw + (size_t)(gy >> 1) * Ws + (gx >> 1) : nullptr;
+    // one chain at a time (measured: feeding all 4 x C chains from each staged value is slower -- 972 scalar weight operands
+    // in flight instead of a stream of them: 1.21 vs 1.07 ms per launch)
+#pragma unroll
+    for (int o = 0; o < C; ++o) {
+        float z[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < CE; ++c)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc = fmaf(tile[c][ty + ky][tx + kx], wE[(((g * C + o) * 2 * C + c) * 3 + ky) * 3 + kx], acc);
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) acc = fmaf(tile[CE + c][ty + ky][tx + kx], wH[(((g * C + o) * C + c) * 3 + ky) * 3 + kx], acc);
+            if (up) acc = acc + up[(size_t)(g * 4 + o) * up_hw];
+            z[g] = acc;
+        }
+        const float bi = a.bias[o], bf = a.bias[C + o], bc = a.bias[2 * C + o], bo = a.bias[3 * C + o];
+        const size_t cbase = ((size_t)b * C + o) * HW;
+        const size_t pbase = (size_t)o * HW;
+        const size_t pstride = (size_t)C * HW;
+        const float cold = a.c_state[cbase + pix];
+        float zi = z[0] + bi; zi = fmaf(a.peep[pbase + pix], cold, zi);
+        float zf = z[1] + bf; zf = fmaf(a.peep[pstride + pbase + pix], cold, zf);
+        const float zc = z[2] + bc;
+        float zo = z[3] + bo; zo = fmaf(a.peep[2 * pstride + pbase + pix], cold, zo);
+        const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
+        const float gi = gg * ii;
+        const float cnew = fmaf(ff, cold, gi);
+        a.c_state[cbase + pix] = cnew;
+        a.h_out[cbase + pix] = oo * det_tanhf(cnew);
+    }
+}
+
 // E_0 for the first step: P_0 = 0  ->  E = [relu(x), relu(-x)] = [x, 0]
 __global__ void e0_init_kernel(const uint8_t* img, float* E0, int C, int HW, int B)
 {

@@ -394,6 +394,20 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         if (op.Cout == 3) hipLaunchKernelGGL(convp0_direct_kernel<3>, g, dim3(P0_TX * P0_TY), 0, st, a.src[0].ptr, op.d_wraw, a);
         else hipLaunchKernelGGL(convp0_direct_kernel<1>, g, dim3(P0_TX * P0_TY), 0, st, a.src[0].ptr, op.d_wraw, a);
         r = hipGetLastError();
+    } else if (static const bool direct_l0 = !(getenv("EIGEN_LSTM0_MFMA") && atoi(getenv("EIGEN_LSTM0_MFMA")));  // A/B measurements only
+               op.epi == EPI_LSTM_PACKED && op.d_wraw && direct_l0 && (op.Cout == 1 || op.Cout == 3)) {
+        // image layer: one thread per pixel (conv_mfma.h: lstm0_direct_kernel); the step-0 operator has one source
+        const dim3 g((op.W + L0_TX - 1) / L0_TX, (op.H + L0_TY - 1) / L0_TY, batch);
+        const dim3 blk(L0_TX * L0_TY);
+        const float *sE = a.src[0].ptr, *sH = a.src[1].ptr;
+        if (op.nsrc == 1) {
+            if (op.Cout == 3) hipLaunchKernelGGL((lstm0_direct_kernel<3, true>), g, blk, 0, st, sE, sH, op.d_wraw, a);
+            else hipLaunchKernelGGL((lstm0_direct_kernel<1, true>), g, blk, 0, st, sE, sH, op.d_wraw, a);
+        } else {
+            if (op.Cout == 3) hipLaunchKernelGGL((lstm0_direct_kernel<3, false>), g, blk, 0, st, sE, sH, op.d_wraw, a);
+            else hipLaunchKernelGGL((lstm0_direct_kernel<1, false>), g, blk, 0, st, sE, sH, op.d_wraw, a);
+        }
+        r = hipGetLastError();
     } else
     switch (op.epi) {
         case EPI_LSTM: r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec); break;
@@ -453,7 +467,7 @@ int eigen_destroy(eigen_engine* e)
     (void)hipSetDevice(e->cfg.device);
     for (int l = 0; l < e->L; ++l) {
         Layer& y = e->layer[l];
-        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw, y.convA_t0.d_wpk, y.lstm_t0.d_wpk, y.up4.d_wpk};
+        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw, y.lstm.d_wraw, y.convA_t0.d_wpk, y.lstm_t0.d_wpk, y.up4.d_wpk};
         for (float* p : ptrs) if (p) (void)hipFree(p);
     }
     if (e->d_planes) (void)hipFree(e->d_planes);
@@ -630,8 +644,16 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             for (int g = 0; g < 3; ++g) memcpy(&pp[g * chw], peep[g], sizeof(float) * chw);
             if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.bias_lstm, bias.data(), bias.size()) || upload(&y.peep, pp.data(), pp.size()))
                 return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d)", l);
+            if (op.epi == EPI_LSTM_PACKED && (C == 1 || C == 3)) {  // image layer: raw OIHW weights for lstm0_direct_kernel
+                std::vector<float> raw((size_t)4 * C * 3 * C * 9);
+                for (int g = 0; g < 4; ++g) {
+                    memcpy(&raw[(size_t)g * C * 2 * C * 9], wx0[g], sizeof(float) * C * 2 * C * 9);
+                    memcpy(&raw[(size_t)4 * C * 2 * C * 9 + (size_t)g * C * C * 9], wh[g], sizeof(float) * C * C * 9);
+                }
+                if (upload(&op.d_wraw, raw.data(), raw.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d direct)", l);
+            }
             ConvOp& t0 = y.lstm_t0;  // step 0: first half of E_l only; h_l = 0 is not read (Layer::lstm_t0)
-            { float* k0 = t0.d_wpk; t0 = op; t0.d_wpk = k0; t0.d_wraw = nullptr; }
+            { float* k0 = t0.d_wpk; t0 = op; t0.d_wpk = k0; }  // (d_wraw is shared with the full operator, which owns it)
             t0.nsrc = 1;
             t0.src_C[0] = C; t0.src_Ct[0] = 2 * C; t0.src_C[1] = 0;
             t0.krows = pad4(C) * 9; t0.macs = (double)y.H * y.W * 4 * C * C * 9;
