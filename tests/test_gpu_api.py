@@ -194,3 +194,46 @@ def test_single_image_api_reproduces_the_references_glue(cuda):
         if case["fitness"] != "UnboundLocalError":
             got = fitness.calculate_fitness(case["structure"], v, None, w, h)
             assert abs(got - case["fitness"]) <= 1e-9 * abs(case["fitness"])
+
+
+_FRAMES_SCRIPT = r"""
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+from evolutionary_illusion_generator_amd import weights
+from evolutionary_illusion_generator_amd.engine import Engine
+out = []
+for (w, h, ch) in [(64, 64, [3, 12, 24, 48]), (96, 64, [1, 8, 16])]:
+    rng = np.random.default_rng(7)
+    B = 3
+    img = rng.integers(0, 256, (B, ch[0], h, w), dtype=np.uint8)
+    img[:, :, ::7] //= 3
+    e = Engine(w, h, ch, B, n_repeat=4, n_ext=2)
+    e.set_weights(weights.synthetic_prednet_weights(ch, w, h, seed=3))
+    d = torch.from_numpy(img).cuda()
+    fr = torch.zeros((B, 6, ch[0], h, w), dtype=torch.uint8, device="cuda")
+    e.prednet_rollout(d, B, 6, 0, fr)
+    torch.cuda.synchronize()
+    out.append(hashlib.sha256(fr.cpu().numpy().tobytes()).hexdigest())
+print("FRAMES", *out)
+"""
+
+
+def test_specialised_operators_equal_the_general_mfma_path(cuda):
+    """Every A/B switch of the engine (step-0 operators, single-K-block ConvA, one-block 2x2 pass, the two direct image-layer
+    kernels) turned off one at a time in a fresh process: all six PredNet frames of two small roll-outs are byte-identical."""
+    import subprocess
+    script = _FRAMES_SCRIPT % {"root": ROOT}
+
+    def run(extra_env):
+        env = dict(os.environ)
+        env.update(extra_env)
+        r = subprocess.run([sys.executable, "-c", script], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("FRAMES")]
+        assert line, r.stdout[-2000:]
+        return line[0]
+
+    base = run({})
+    for switch in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA"):
+        assert run({switch: "1"}) == base, switch
