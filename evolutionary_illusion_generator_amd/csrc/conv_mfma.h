@@ -682,6 +682,39 @@ conv3x3_mfma(const ConvArgs a)
             const size_t cbase = ((size_t)b * a.Cout + ch) * HW;
             const size_t pbase = (size_t)ch * HW;
             const size_t pstride = (size_t)a.Cout * HW;
+            if (VEC && EIG_ABLATE != 2 && gx0 + 1 < a.W) {
+                // W % 4 == 0 and gx0 even: the two pixels of a window row are one aligned 8-byte access -- half the memory
+                // instructions of the epilogue and whole 32-byte sectors per (channel, row) instead of half ones
+                typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int r2 = 0; r2 < 2; ++r2) {
+                    const int gy = gy0 + r2;
+                    if (gy >= a.H) continue;
+                    const int pix = gy * a.W + gx0;
+                    const f32x2 cold2 = *reinterpret_cast<const f32x2*>(a.c_state + cbase + pix);
+                    const f32x2 pi2 = *reinterpret_cast<const f32x2*>(a.peep + pbase + pix);
+                    const f32x2 pf2 = *reinterpret_cast<const f32x2*>(a.peep + pstride + pbase + pix);
+                    const f32x2 po2 = *reinterpret_cast<const f32x2*>(a.peep + 2 * pstride + pbase + pix);
+                    f32x2 cn2, hn2;
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int reg = r2 * 2 + e;
+                        const float cold = cold2[e];
+                        float zi = acc[mi][0][reg] + bi; zi = fmaf(pi2[e], cold, zi);
+                        float zf = acc[mi][1][reg] + bf; zf = fmaf(pf2[e], cold, zf);
+                        const float zc = acc[mi][2][reg] + bc;
+                        float zo = acc[mi][3][reg] + bo; zo = fmaf(po2[e], cold, zo);
+                        const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
+                        const float gi = gg * ii;
+                        const float cnew = fmaf(ff, cold, gi);
+                        cn2[e] = cnew;
+                        hn2[e] = oo * det_tanhf(cnew);
+                    }
+                    *reinterpret_cast<f32x2*>(a.c_state + cbase + pix) = cn2;
+                    *reinterpret_cast<f32x2*>(a.h_out + cbase + pix) = hn2;
+                }
+                continue;
+            }
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);
@@ -771,6 +804,17 @@ conv3x3_mfma(const ConvArgs a)
                 if (ch >= a.Cout) continue;
                 const float bb = a.bias[ch];
                 const size_t base = ((size_t)b * a.Cout + ch) * HW;
+                if (VEC && !a.frame && !a.E0 && gx0 + 1 < a.W) {  // layers > 0: P only, aligned 8-byte stores of the window rows
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int r2 = 0; r2 < 2; ++r2) {
+                        if (gy0 + r2 >= a.H) continue;
+                        float v0 = relu_f(acc[mi][ni][r2 * 2] + bb), v1 = relu_f(acc[mi][ni][r2 * 2 + 1] + bb);
+                        if (a.clip) { v0 = fminf(v0, 1.0f); v1 = fminf(v1, 1.0f); }
+                        *reinterpret_cast<f32x2*>(a.Pout + base + (gy0 + r2) * a.W + gx0) = (f32x2){v0, v1};
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int reg = 0; reg < 4; ++reg) {
                     const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);
