@@ -53,10 +53,10 @@ enum { EPI_RAW = 0, EPI_LSTM = 1, EPI_CONVA = 2, EPI_CONVP = 3, EPI_LSTM_PACKED 
 constexpr int epi_taps(int epi) { return (epi == EPI_UP4 || epi == EPI_UP4C) ? 4 : 9; }
 
 struct ConvSrc {
-    const float* ptr;  // [B][C][H>>up][W>>up]
+    const float* ptr;  // [B][Ct][H][W]
     int C;             // real channels
     int Cpad;          // padded to a multiple of 4
-    int up;            // 1: half resolution, nearest-unpooled x2 on the fly
+    int _reserved;     // (was: in-kernel x2 unpooling; unpooled sources are evaluated by an EPI_UP4 launch at their own resolution)
     int Ct;            // channels of the TENSOR (image stride); C < Ct reads only its first C channels (step-0 operators)
 };
 
@@ -148,9 +148,6 @@ template <int TW, bool VEC> struct TileGeom {
     static constexpr int XO = VEC ? 3 : 0;
     static constexpr int PH = TH + 2;
     static constexpr int PLANE = NIMG * PH * S;  // floats per channel in LDS
-    static constexpr int SU = TW / 2 + 8;        // unpooled source, VEC only
-    static constexpr int PHU = TH / 2 + 2;
-    static constexpr int PLANE_U = NIMG * PHU * SU;
 };
 
 #ifndef EIG_KC
@@ -197,7 +194,6 @@ conv3x3_mfma(const ConvArgs a)
 {
     using G = TileGeom<TW, VEC>;
     constexpr int TH = G::TH, NIMG = G::NIMG, S = G::S, XO = G::XO, PH = G::PH, PLANE = G::PLANE;
-    constexpr int SU = G::SU, PHU = G::PHU, PLANE_U = G::PLANE_U;
     constexpr int NB = NI * 16;
     // EPI_UP4: the 2x2 form of `unpool x2 -> conv3x3`.  The launch runs at the SOURCE resolution; a block
     // computes, for its parity class (py, px), the partial chains of the output pixels (2Y+py, 2X+px) of its tile:
@@ -244,11 +240,10 @@ conv3x3_mfma(const ConvArgs a)
     // ---- staging slots of this thread (K-block invariant): LDS slot tid + 256 r -> pixel offset in the source plane
     // (-1: zero fill) and image.  VEC: slots are the 16-B chunks of the whole K-block tile (the channel inside the
     // K-block is (tid + 256 r) / slots-per-channel); !VEC: slots are the floats of ONE channel plane.
-    constexpr int RC = S / 4, RCU = SU / 4;
-    constexpr int PER_C = VEC ? NIMG * PH * RC : PLANE, PER_CU = NIMG * PHU * RCU;
+    constexpr int RC = S / 4;
+    constexpr int PER_C = VEC ? NIMG * PH * RC : PLANE;
     constexpr int NR = VEC ? (KC * PER_C + 255) / 256 : (PLANE + 255) / 256;
-    constexpr int NRU = VEC ? (KC * PER_CU + 255) / 256 : 1;
-    int sl_off[NR], sl_img[NR], su_off[NRU], su_img[NRU];
+    int sl_off[NR], sl_img[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int p = tid + r * 256;
@@ -265,22 +260,6 @@ conv3x3_mfma(const ConvArgs a)
         sl_off[r] = ok ? (VEC ? ((p / PER_C) * a.H * a.W + gy * a.W + gx) * 4 : gy * a.W + gx) : -1;
         sl_img[r] = VEC ? img : b;
     }
-    if (VEC) {
-        const int Hs = a.H >> 1, Ws = a.W >> 1;
-#pragma unroll
-        for (int r = 0; r < NRU; ++r) {
-            const int p = tid + r * 256;
-            int rem = p % PER_CU;
-            const int img = rem / (PHU * RCU);
-            rem -= img * (PHU * RCU);
-            const int yy = rem / RCU, xx = rem - yy * RCU;
-            const int gy = (y0 >> 1) + yy - 1, gx = (x0 >> 1) - 4 + 4 * xx;
-            const int b = bgrp * NIMG + img;
-            const bool ok = p < KC * PER_CU && b < a.B && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
-            su_off[r] = ok ? ((p / PER_CU) * Hs * Ws + gy * Ws + gx) * 4 : -1;
-            su_img[r] = img;
-        }
-    }
 
     // ---- K loop: K-blocks of KC channels, enumerated across the sources, two LDS buffers.
     // Both operands go global -> LDS by DMA (global_load_lds: no staging registers, no ds_write pass; every lane
@@ -289,25 +268,19 @@ conv3x3_mfma(const ConvArgs a)
     // step): a DMA issued while the wave would anyway be waiting for the matrix pipe costs nothing, whereas a burst
     // of them ahead of the MFMAs measured ~0.7 % of the K-block time per instruction.  ONE barrier per K-block.
     constexpr int NWR = (KC * TAPS * (NB / 4) + 255) / 256;       // weight DMA rounds per K-block
-    constexpr int NIN = VEC ? (NR > NRU ? NR : NRU) : KC * NR;    // input DMA ops per K-block
+    constexpr int NIN = VEC ? NR : KC * NR;                       // input DMA ops per K-block
     constexpr int NOPS = NWR + NIN;
     constexpr int NSTEP = KC * TAPS / 4;                          // 18 (8 for the 2x2 form)
-    struct KB { int s, c0, kc, up; };
+    struct KB { int s, c0, kc; };
     // per-source scalars picked with selects (indexing a.src[] with a run-time index would put the argument struct in scratch
     // and turn everything derived from it -- descriptors, LDS-DMA bases -- into per-lane values)
     const int cpad0 = a.src[0].Cpad, cpad1 = a.src[1].Cpad, cpad2 = a.src[2].Cpad;
-    // (unpooled sources no longer reach this path: they are evaluated in their 2x2 form by an EPI_UP4 launch at the source
-    //  resolution; the in-kernel unpooling code below is kept, compiled out, for A/B measurements)
-    constexpr bool UPS = false;
-    const int up0 = (UPS && VEC) ? a.src[0].up : 0, up1 = (UPS && VEC) ? a.src[1].up : 0, up2 = (UPS && VEC) ? a.src[2].up : 0;
     auto cpad_of = [&](int si) __attribute__((always_inline)) { return si == 0 ? cpad0 : (si == 1 ? cpad1 : cpad2); };
-    auto up_of = [&](int si) __attribute__((always_inline)) { return si == 0 ? up0 : (si == 1 ? up1 : up2); };
-    auto kb_first = [&]() { KB k; k.s = 0; k.c0 = 0; k.kc = min(KC, cpad0); k.up = up0; return k; };
+    auto kb_first = [&]() { KB k; k.s = 0; k.c0 = 0; k.kc = min(KC, cpad0); return k; };
     auto kb_next = [&](KB k) __attribute__((always_inline)) {
         k.c0 += KC;
         if (k.c0 >= cpad_of(k.s)) { k.c0 = 0; ++k.s; }
-        if (k.s < a.nsrc) { k.kc = min(KC, cpad_of(k.s) - k.c0); k.up = up_of(k.s); }
-        else { k.kc = 0; k.up = 0; }
+        k.kc = (k.s < a.nsrc) ? min(KC, cpad_of(k.s) - k.c0) : 0;
         return k;
     };
     // Buffer descriptors (VEC path): one per source covering the NIMG images of this block, one for this N-block's
@@ -316,15 +289,15 @@ conv3x3_mfma(const ConvArgs a)
     // range of the descriptor, which the hardware turns into zeros.
     const int b0 = bgrp * NIMG;
     const int nimg_here = min(NIMG, a.B - b0);
-    auto make_rsrc = [&](const float* ptr, int C, int Ct, int up) {
-        const size_t plane = (size_t)((a.H >> up) * (a.W >> up));
+    auto make_rsrc = [&](const float* ptr, int C, int Ct) {
+        const size_t plane = (size_t)(a.H * a.W);
         return __builtin_amdgcn_make_buffer_rsrc((void*)(ptr + (size_t)b0 * Ct * plane), 0, (int)(((size_t)(nimg_here - 1) * Ct + C) * plane * 4), 0x00020000);
     };
     // (unused sources alias source 0: constant indices only, see cpad_of above)
     const bool has1 = a.nsrc > 1, has2 = a.nsrc > 2;
-    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, a.src[0].C, a.src[0].Ct, a.src[0].up);
-    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(has1 ? a.src[1].ptr : a.src[0].ptr, has1 ? a.src[1].C : a.src[0].C, has1 ? a.src[1].Ct : a.src[0].Ct, has1 ? a.src[1].up : a.src[0].up);
-    const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(has2 ? a.src[2].ptr : a.src[0].ptr, has2 ? a.src[2].C : a.src[0].C, has2 ? a.src[2].Ct : a.src[0].Ct, has2 ? a.src[2].up : a.src[0].up);
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(a.src[0].ptr, a.src[0].C, a.src[0].Ct);
+    const __amdgpu_buffer_rsrc_t rs1 = make_rsrc(has1 ? a.src[1].ptr : a.src[0].ptr, has1 ? a.src[1].C : a.src[0].C, has1 ? a.src[1].Ct : a.src[0].Ct);
+    const __amdgpu_buffer_rsrc_t rs2 = make_rsrc(has2 ? a.src[2].ptr : a.src[0].ptr, has2 ? a.src[2].C : a.src[0].C, has2 ? a.src[2].Ct : a.src[0].Ct);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + ((size_t)cls * a.n_nblk + nblk) * a.krows * NB), 0, a.krows * NB * 4, 0x00020000);
     auto buf_dma16 = [&](int si, float* lds_dst, int voff, int soff) {
         auto l = (__attribute__((address_space(3))) void*)lds_dst;
@@ -338,7 +311,6 @@ conv3x3_mfma(const ConvArgs a)
         src.ptr = k.s == 0 ? a.src[0].ptr : (k.s == 1 ? a.src[1].ptr : a.src[2].ptr);
         src.C = k.s == 0 ? a.src[0].C : (k.s == 1 ? a.src[1].C : a.src[2].C);
         src.Cpad = cpad_of(k.s);
-        src.up = k.s == 0 ? a.src[0].up : (k.s == 1 ? a.src[1].up : a.src[2].up);
         src.Ct = k.s == 0 ? a.src[0].Ct : (k.s == 1 ? a.src[1].Ct : a.src[2].Ct);
         if (j < NWR) {
             const int n16 = k.kc * TAPS * (NB / 4);
@@ -348,27 +320,17 @@ conv3x3_mfma(const ConvArgs a)
                                                          tid * 16, (wrow * NB + j * 1024) * 4, 0, 0);
             return;
         }
-        const int Hs = a.H >> src.up, Ws = a.W >> src.up;
-        const int chs = Hs * Ws;
+        const int chs = a.H * a.W;
         if (VEC) {
             const int r = j - NWR;
             const int p = tid + r * 256;
             const int soff = k.c0 * chs * 4;
             const bool tail = k.c0 + KC > src.C;  // padded channels present: mask them explicitly (rare, tiny layers)
-            if (!k.up) {
-                if (r < NR) {
-                    int vo = sl_off[r < NR ? r : 0];
-                    if (NIMG > 1) vo = vo < 0 ? vo : vo + sl_img[r < NR ? r : 0] * src.Ct * chs * 4;
-                    if (tail && k.c0 + p / PER_C >= src.C) vo = -1;
-                    if (p < k.kc * PER_C) buf_dma16(k.s, buf + (r * 256 + wv * 64) * 4, vo, soff);
-                }
-            } else {
-                if (r < NRU) {
-                    int vo = su_off[r < NRU ? r : 0];
-                    if (NIMG > 1) vo = vo < 0 ? vo : vo + su_img[r < NRU ? r : 0] * src.Ct * chs * 4;
-                    if (tail && k.c0 + p / PER_CU >= src.C) vo = -1;
-                    if (p < k.kc * PER_CU) buf_dma16(k.s, buf + (r * 256 + wv * 64) * 4, vo, soff);
-                }
+            if (r < NR) {
+                int vo = sl_off[r < NR ? r : 0];
+                if (NIMG > 1) vo = vo < 0 ? vo : vo + sl_img[r < NR ? r : 0] * src.Ct * chs * 4;
+                if (tail && k.c0 + p / PER_C >= src.C) vo = -1;
+                if (p < k.kc * PER_C) buf_dma16(k.s, buf + (r * 256 + wv * 64) * 4, vo, soff);
             }
         } else {
             const int c = (j - NWR) / NR, r = (j - NWR) % NR;
@@ -376,7 +338,7 @@ conv3x3_mfma(const ConvArgs a)
                 const bool pok = sl_off[r] >= 0;
                 const int gy = pok ? sl_off[r] / a.W : 0, gx = pok ? sl_off[r] - gy * a.W : 0;
                 const float* g = (pok && (k.c0 + c < src.C))
-                                     ? src.ptr + ((size_t)sl_img[r] * src.Ct + k.c0 + c) * chs + (gy >> src.up) * Ws + (gx >> src.up) : a.zeros;
+                                     ? src.ptr + ((size_t)sl_img[r] * src.Ct + k.c0 + c) * chs + gy * a.W + gx : a.zeros;
                 if (tid + r * 256 < PLANE)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                                      (__attribute__((address_space(3))) void*)(buf + c * PLANE + r * 256 + wv * 64), 4, 0, 0);
@@ -396,14 +358,14 @@ conv3x3_mfma(const ConvArgs a)
     const int aH = a.H, aW = a.W;
     // descriptor of the source a K-block reads, from SCALAR selects of base pointer and size (selecting between whole
     // descriptors ends in a scratch table + waterfall loop)
-    auto src_base = [&](const float* ptr, int Ct, int up) __attribute__((always_inline)) { return ptr + (size_t)b0 * Ct * ((a.H >> up) * (a.W >> up)); };
-    auto src_bytes = [&](int C, int Ct, int up) __attribute__((always_inline)) { return ((nimg_here - 1) * Ct + C) * ((a.H >> up) * (a.W >> up)) * 4; };
-    const float* const sp0 = src_base(a.src[0].ptr, a.src[0].Ct, a.src[0].up);
-    const float* const sp1 = has1 ? src_base(a.src[1].ptr, a.src[1].Ct, a.src[1].up) : sp0;
-    const float* const sp2 = has2 ? src_base(a.src[2].ptr, a.src[2].Ct, a.src[2].up) : sp0;
-    const int sn0 = src_bytes(a.src[0].C, a.src[0].Ct, a.src[0].up);
-    const int sn1 = has1 ? src_bytes(a.src[1].C, a.src[1].Ct, a.src[1].up) : sn0;
-    const int sn2 = has2 ? src_bytes(a.src[2].C, a.src[2].Ct, a.src[2].up) : sn0;
+    auto src_base = [&](const float* ptr, int Ct) __attribute__((always_inline)) { return ptr + (size_t)b0 * Ct * (a.H * a.W); };
+    auto src_bytes = [&](int C, int Ct) __attribute__((always_inline)) { return ((nimg_here - 1) * Ct + C) * (a.H * a.W) * 4; };
+    const float* const sp0 = src_base(a.src[0].ptr, a.src[0].Ct);
+    const float* const sp1 = has1 ? src_base(a.src[1].ptr, a.src[1].Ct) : sp0;
+    const float* const sp2 = has2 ? src_base(a.src[2].ptr, a.src[2].Ct) : sp0;
+    const int sn0 = src_bytes(a.src[0].C, a.src[0].Ct);
+    const int sn1 = has1 ? src_bytes(a.src[1].C, a.src[1].Ct) : sn0;
+    const int sn2 = has2 ? src_bytes(a.src[2].C, a.src[2].Ct) : sn0;
     const unsigned long long su0 = (unsigned long long)sp0, sd1 = (unsigned long long)sp1 - su0, sd2 = (unsigned long long)sp2 - (unsigned long long)sp1;
     auto rsrc_of = [=](int si) __attribute__((always_inline)) {
         // additive form + readfirstlane: plain 3-way selects were turned into a table in scratch memory indexed by si
@@ -424,7 +386,7 @@ conv3x3_mfma(const ConvArgs a)
         }
         const int r = j - NWR;
         const unsigned soff = soff_in;
-        const int slot = k.up ? (r < NRU ? su_off[r < NRU ? r : 0] : -1) : (r < NR ? sl_off[r < NR ? r : 0] : -1);
+        const int slot = r < NR ? sl_off[r < NR ? r : 0] : -1;
         const unsigned vo = __builtin_elementwise_add_sat((unsigned)slot, soff);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(buf + (r * 256 + wv * 64) * 4), 16, (int)vo, 0, 0, 0);
     };
@@ -443,21 +405,18 @@ conv3x3_mfma(const ConvArgs a)
 
     // ---- A-operand gather addresses: lane row r = lane&15 = 4*rq + rreg -> pixel (dy, dx); k-slot j = lane>>4.
     // k = 4*step + j, (channel, tap) = divmod(k, 9): period 9 steps = 4 channels -> nine address registers per layout.
-    int addrA[9], addrU[9];
+    int addrA[9];
     {
         const int r = col;
         const int dy = (r & 3) >> 1, dx = 2 * (r >> 2) + (r & 1);
         const int base = (TW == 16) ? (wv * 4 + dy) * S + dx + XO      // sub-tile mi adds (mi>>1)*2*S + (mi&1)*8
                                     : wv * PH * S + dy * S + dx + XO;  // one image per wave; sub-tile mi adds mi*2*S
-        const int baseU = (TW == 16) ? (wv * 2 + 1) * SU + 4           // sub-tile mi adds (mi>>1)*SU + (mi&1)*4
-                                     : (wv * PHU + 1) * SU + 4;        // sub-tile mi adds mi*SU
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             const int k = 4 * s + q;
             const int c = k / 9, tap = k - 9 * c;
             const int ky = tap / 3, kx = tap - 3 * ky;
             addrA[s] = base + c * PLANE + ky * S + kx;
-            addrU[s] = baseU + c * PLANE_U + ((dy + ky - 1) >> 1) * SU + ((dx + kx - 1) >> 1);
         }
     }
     // 2x2 form: k = 4*step + q -> channel = step, tap (a, b) = (q >> 1, q & 1): one address, the channel is an immediate
@@ -525,20 +484,18 @@ conv3x3_mfma(const ConvArgs a)
         const bool more_kb = (kb + 1 < nkb) && EIG_ABLATE != 1;
         const __amdgpu_buffer_rsrc_t rs_nxt = rsrc_of(nxt_kb.s);
         // byte offsets of the next K-block inside its source / the weight slab; 2^31 = `nothing to stage` (out of range)
-        const unsigned soff_in_nxt = more_kb ? (unsigned)(nxt_kb.c0 * ((aH >> nxt_kb.up) * (aW >> nxt_kb.up)) * 4) : 0x80000000u;
+        const unsigned soff_in_nxt = more_kb ? (unsigned)(nxt_kb.c0 * (aH * aW) * 4) : 0x80000000u;
         const unsigned soff_w_nxt = more_kb ? (unsigned)(wrow_nxt * NB * 4) : 0x80000000u;
 
-        // The two tile layouts (full resolution / unpooled source) differ only in the nine gather addresses, the four
-        // sub-tile offsets and the channel stride, all wave-uniform per K-block: ONE loop body.
-        // Two instantiations of the 18-step body (full-resolution tile / unpooled source) so that every LDS offset of
-        // the operand gather is an immediate: the four A reads of a step pair up into two ds_read2_b32, no address VALU.
+        // Every LDS offset of the operand gather is an immediate (nine address registers per period of 9 steps, sub-tile and
+        // channel-period offsets folded into the instruction): the four A reads of a step pair up into two ds_read2_b32, no
+        // address VALU.
         const float* const in_lds = cur;
         const float* const w_lds = cur + INF + boff;
-        auto body = [&](auto up_tag, auto first_tag) {
-            constexpr bool UP = decltype(up_tag)::value;
+        auto body = [&](auto first_tag) {
             constexpr bool FIRST = decltype(first_tag)::value;  // K-block 0 of an operator with an unpooled-source chain: issue its loads
-            constexpr int PL = UP ? PLANE_U : PLANE;
-            const int* const ad = UP ? addrU : addrA;
+            constexpr int PL = PLANE;
+            const int* const ad = addrA;
 #pragma unroll
             for (int st = 0; st < NSTEP; ++st) {
                 // second period only for a full K-block (wave-uniform).  FAST: always -- a 4-channel K-block's upper
@@ -550,8 +507,7 @@ conv3x3_mfma(const ConvArgs a)
                     float avc[4][3];  // EPI_UP4C: the gathers of classes 1..3
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) {
-                        const int moff = UP ? ((TW == 16) ? ((mi >> 1) * SU + (mi & 1) * 4) : (mi * SU))
-                                            : ((TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S));
+                        const int moff = (TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S);
                         av[mi] = (TAPS == 9) ? in_lds[ad[s9] + per * 4 * PL + moff] : in_lds[addr4 + st * PL + moff];
                         if constexpr (EPI == EPI_UP4C) {  // class c = (py, px) shifts the tap window by (py, px)
 #pragma unroll
@@ -596,8 +552,7 @@ conv3x3_mfma(const ConvArgs a)
                 }
             }
         };
-        if (VEC && cur_kb.up) body(std::true_type{}, std::false_type{});
-        else body(std::false_type{}, kfirst_tag);
+        body(kfirst_tag);
         wrow = wrow_nxt;
         cur_kb = nxt_kb;
         const unsigned long long tk1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;

@@ -43,7 +43,7 @@ struct ConvOp {
     int tl_seen = 0;  // EIG_TIMING builds: launches seen (timeline dump)
     int epi = 0, NI = 4, TW = 16, layer = 0;
     int nsrc = 0;
-    int src_C[3] = {0, 0, 0}, src_up[3] = {0, 0, 0};
+    int src_C[3] = {0, 0, 0};
     int src_Ct[3] = {0, 0, 0};  // channels of the source TENSOR when only its first src_C channels are read (0: = src_C)
     int H = 0, W = 0, Cout = 0, n_nblk = 0, krows = 0;
     float* d_wpk = nullptr;
@@ -368,12 +368,11 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     a.tilesY = (op.H + TH - 1) / TH;
     a.n_nblk = op.n_nblk; a.krows = op.krows; a.wpk = op.d_wpk; a.Cout = op.Cout; a.zeros = e->d_zeros;
     a.nsrc = op.nsrc;
-    for (int s = 0; s < op.nsrc; ++s) { a.src[s].C = op.src_C[s]; a.src[s].Cpad = pad4(op.src_C[s]); a.src[s].up = op.src_up[s]; a.src[s].Ct = op.src_Ct[s] ? op.src_Ct[s] : op.src_C[s]; }
+    for (int s = 0; s < op.nsrc; ++s) { a.src[s].C = op.src_C[s]; a.src[s].Cpad = pad4(op.src_C[s]); a.src[s]._reserved = 0; a.src[s].Ct = op.src_Ct[s] ? op.src_Ct[s] : op.src_C[s]; }
     const int ntile = ((batch + NIMG - 1) / NIMG) * a.tilesX * a.tilesY;
     const int grid = op.n_nblk * (op.epi == EPI_UP4 ? 4 : 1) * ((ntile + 7) / 8) * 8;  // XCD-aware tile map (conv_mfma.h): tiles padded to a multiple of 8
-    // 16-byte DMA staging needs chunk-aligned rows: W % 4 == 0, and W % 8 == 0 when a half-resolution source is read
-    bool vec = (op.W % 4) == 0;
-    for (int s = 0; s < op.nsrc; ++s) if (op.src_up[s] && ((op.W % 8) != 0 || (op.H % 2) != 0)) vec = false;
+    // 16-byte DMA staging needs chunk-aligned rows: W % 4 == 0
+    const bool vec = (op.W % 4) == 0;
 #if EIG_TIMING
     unsigned long long* tl_dbg = nullptr;
     if (getenv("EIGEN_TIMELINE") && (op.epi == EPI_LSTM || (op.epi == EPI_UP4 && op.NI == 4)) && ++op.tl_seen == 6) {  // a steady-state launch of every ConvLSTM op and 2x2-form pass
@@ -604,7 +603,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
         if (l > 0) {
             ConvOp& op = y.convA;
             { float *k0 = op.d_wpk, *k1 = op.d_wraw; op = ConvOp(); op.d_wpk = k0; op.d_wraw = k1; }  // keep the allocations: upload() frees them
-            op.epi = EPI_CONVA; op.layer = l; op.nsrc = 1; op.src_C[0] = 2 * e->layer[l - 1].C; op.src_up[0] = 0;
+            op.epi = EPI_CONVA; op.layer = l; op.nsrc = 1; op.src_C[0] = 2 * e->layer[l - 1].C;
             op.H = e->layer[l - 1].H; op.W = e->layer[l - 1].W; op.Cout = C;
             choose_ni(C, false, &op.NI, &op.n_nblk);
             op.TW = choose_tw(op.H, op.W);
@@ -687,7 +686,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
         {
             ConvOp& op = y.convP;
             { float *k0 = op.d_wpk, *k1 = op.d_wraw; op = ConvOp(); op.d_wpk = k0; op.d_wraw = k1; }  // keep the allocations: upload() frees them
-            op.epi = EPI_CONVP; op.layer = l; op.nsrc = 1; op.src_C[0] = C; op.src_up[0] = 0;
+            op.epi = EPI_CONVP; op.layer = l; op.nsrc = 1; op.src_C[0] = C;
             op.H = y.H; op.W = y.W; op.Cout = C;
             choose_ni(C, false, &op.NI, &op.n_nblk);
             op.TW = choose_tw(op.H, op.W);
