@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libeigen_hip.so")
+ABI_VERSION = 2  # include/eigen_engine.h: EIGEN_ABI_VERSION
 MAX_LAYERS = 8
 
 PAIR_POPULATION, PAIR_SINGLE = 0, 1
@@ -71,6 +72,8 @@ def load_library(path=None):
         lib.eigen_prednet_flops_per_step.argtypes = [ctypes.c_void_p]
         for name in EXPORTS:
             getattr(lib, name)  # AttributeError if the ABI drifted
+        if lib.eigen_abi_version() != ABI_VERSION:  # EigenConfig below mirrors eigen_config of exactly this version
+            raise EngineError("%s has ABI version %d, this package binds version %d: rebuild it" % (p, lib.eigen_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
 

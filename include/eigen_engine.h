@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define EIGEN_MAX_LAYERS 8
-#define EIGEN_ABI_VERSION 1
+#define EIGEN_ABI_VERSION 2 /* 2: eigen_config grew (flow_method, fb_*), eigen_debug_dense_flow, gradient = 2 */
 
 typedef enum {
     EIGEN_OK = 0,

@@ -22,7 +22,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libeigen_hip.so does not export %s" % name
     assert set(engine.EXPORTS) == set(declared)
-    assert lib.eigen_abi_version() == 1
+    assert lib.eigen_abi_version() == 2
     cfg = engine.EigenConfig()
     lib.eigen_config_defaults(ctypes.byref(cfg))
     assert (cfg.n_repeat, cfg.n_ext, cfg.lk_max_corners, cfg.lk_win, cfg.lk_max_level, cfg.lk_block_size) == (20, 2, 100, 15, 2, 7)
