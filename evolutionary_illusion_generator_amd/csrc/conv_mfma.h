@@ -587,6 +587,49 @@ conv3x3_mfma(const ConvArgs a)
             d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32); d[5] = t_mfma; d[6] = t_setup; d[7] = t_prewait; (void)t_mid; (void)t_bar;
         }
     };
+    if constexpr (EPI == EPI_CONVA && TW == 16 && VEC) {
+        // Tiles inside the image: sub-tiles 2mp and 2mp+1 of a wave hold the pooled pixels (row, q) and (row, 4 + q); one exchange
+        // between the lane pairs q ^ 1 gives every lane two NEIGHBOURING pooled pixels, so P is read and both halves of E are
+        // written as aligned 8-byte accesses (same values, half the memory instructions, whole sectors).
+        if (bgrp < a.B && y0 + 16 <= a.H && x0 + 16 <= a.W) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const int Ho = a.H >> 1, Wo = a.W >> 1;
+            const size_t plane = (size_t)Ho * Wo;
+#pragma unroll
+            for (int mp = 0; mp < 2; ++mp) {
+                const int yo = tyi * 8 + wv * 2 + mp;
+                const int xo = txi * 8 + ((q & 1) ? 3 + q : q);  // even: this lane's pair is (xo, xo + 1)
+                f32x2 pv[NI];
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int ch = nblk * NB + ni * 16 + col;
+                    pv[ni] = (ch < a.Cout) ? *reinterpret_cast<const f32x2*>(a.P + ((size_t)bgrp * a.Cout + ch) * plane + (size_t)yo * Wo + xo) : (f32x2){0.0f, 0.0f};
+                }
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int ch = nblk * NB + ni * 16 + col;
+                    const float bb = (ch < a.Cout) ? a.bias[ch] : 0.0f;
+                    float pooled[2];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const f32x4 c4 = acc[2 * mp + h][ni];
+                        const float v0 = relu_f(c4[0] + bb), v1 = relu_f(c4[1] + bb), v2 = relu_f(c4[2] + bb), v3 = relu_f(c4[3] + bb);
+                        pooled[h] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                    }
+                    const float recv = __shfl_xor((q & 1) ? pooled[0] : pooled[1], 16, 64);
+                    const f32x2 A2 = (q & 1) ? (f32x2){recv, pooled[1]} : (f32x2){pooled[0], recv};
+                    if (ch < a.Cout) {
+                        const f32x2 p2 = pv[ni];
+                        float* e = a.E + ((size_t)bgrp * 2 * a.Cout + ch) * plane + (size_t)yo * Wo + xo;
+                        *reinterpret_cast<f32x2*>(e) = (f32x2){relu_f(A2[0] - p2[0]), relu_f(A2[1] - p2[1])};
+                        *reinterpret_cast<f32x2*>(e + (size_t)a.Cout * plane) = (f32x2){relu_f(p2[0] - A2[0]), relu_f(p2[1] - A2[1])};
+                    }
+                }
+            }
+            timeline_record(0);
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         int img, py0, px0;
