@@ -87,16 +87,19 @@ def _flatten_lists(genome, config, n_leaves=2):
     leaf_of = {k: i for i, k in enumerate(in_keys)}
     required = _required_for_output(in_keys, out_keys, genome.connections)
     node_inputs = {o: [] for o in out_keys}
+    out_set = set(out_keys)
     for cg in genome.connections.values():
         if not cg.enabled:
             continue
         i, o = cg.key
-        if o not in required and i not in required:
+        if (o not in required and i not in required) or i in out_set:
             continue
-        if i in out_keys:
-            continue
-        node_inputs.setdefault(o, []).append((i, cg.weight))
-        node_inputs.setdefault(i, [])
+        lst = node_inputs.get(o)
+        if lst is None:
+            lst = node_inputs[o] = []
+        lst.append((i, cg.weight))
+        if i not in node_inputs:
+            node_inputs[i] = []
 
     # topological order by depth-first post-order from the outputs (feed_forward = True: acyclic)
     order, state = [], {}
@@ -136,7 +139,7 @@ def _flatten_lists(genome, config, n_leaves=2):
         if not conns:
             const32[n] = np.float32(node.bias)
             continue
-        if all(i in const32 for i, _ in conns):  # whole sub-graph is float32 constants: fold it
+        if const32 and all(i in const32 for i, _ in conns):  # whole sub-graph is float32 constants: fold it
             with np.errstate(all="ignore"):
                 pre = None
                 for i, w in conns:
@@ -150,8 +153,9 @@ def _flatten_lists(genome, config, n_leaves=2):
         # Python's sum() adds left to right: a LEADING run of float32 constants is accumulated in float32 before the
         # first float64 term promotes the running sum; later float32 terms are promoted one by one.
         lead = 0
-        while lead < len(conns) and conns[lead][0] in const32:
-            lead += 1
+        if const32:
+            while lead < len(conns) and conns[lead][0] in const32:
+                lead += 1
         if lead:
             with np.errstate(all="ignore"):
                 pre = None
@@ -159,9 +163,10 @@ def _flatten_lists(genome, config, n_leaves=2):
                     t = np.float32(w) * const32[i]
                     pre = t if pre is None else np.float32(pre + t)
             edge_src.append(ONE); edge_w.append(float(pre))
-        for i, w in conns[lead:]:
-            if i in leaf_of:
-                edge_src.append(-(leaf_of[i] + 1)); edge_w.append(float(w))
+        for i, w in (conns[lead:] if lead else conns):
+            li = leaf_of.get(i)
+            if li is not None:
+                edge_src.append(-(li + 1)); edge_w.append(float(w))
             elif i in const32:
                 with np.errstate(all="ignore"):
                     edge_src.append(ONE); edge_w.append(float(np.float32(w) * const32[i]))
