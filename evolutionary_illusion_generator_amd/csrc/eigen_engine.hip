@@ -9,6 +9,8 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "../../include/eigen_engine.h"
@@ -1192,6 +1194,157 @@ int eigen_time_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, c
 {
     if (iters < 1 || !h_ms) return fail(EIGEN_ERR_INVALID, "iters >= 1 and h_ms required");
     return test_conv_impl(e, n_src, d_src, cin, up, h_w, cout, H, W, batch, d_out, stream, iters, h_ms);
+}
+
+// Host-only: the graph part of genome flattening (genome.py: _flatten_lists is the specification, statement by statement).
+int eigen_flatten_genomes(int32_t G, int32_t n_in, const int32_t* in_keys, int32_t n_out, const int32_t* out_keys, const int32_t* conn_off,
+                          const int32_t* conn_in, const int32_t* conn_out, const double* conn_w, const uint8_t* conn_en, const int32_t* node_off,
+                          const int32_t* node_key, const uint8_t* node_act, const uint8_t* node_agg_sum, const double* node_bias,
+                          const double* node_resp, int32_t cap_nodes, int32_t cap_edges, int32_t* o_node_off, int32_t* o_edge_off, uint8_t* o_act,
+                          double* o_bias, double* o_resp, int32_t* o_edge_src, double* o_edge_w, int32_t* o_out_node, uint8_t* o_status)
+{
+    if (G < 0 || !in_keys || !out_keys || !conn_off || !node_off || !o_node_off || !o_edge_off || !o_status) return fail(EIGEN_ERR_INVALID, "null argument");
+    std::unordered_map<int, int> leaf_of;
+    for (int i = 0; i < n_in; ++i) leaf_of[in_keys[i]] = i;
+    std::unordered_set<int> out_set(out_keys, out_keys + n_out);
+    const int ONE = -(n_in + 1);
+    int nn = 0, ne = 0;  // nodes / edges emitted so far
+    o_node_off[0] = 0;
+    o_edge_off[0] = 0;
+    typedef std::vector<std::pair<int, double>> Conns;
+    for (int g = 0; g < G; ++g) {
+        const int c0 = conn_off[g], c1 = conn_off[g + 1], m0 = node_off[g], m1 = node_off[g + 1];
+        const int nn0 = nn, ne0 = ne;
+        uint8_t status = 0;
+        // required_for_output over ALL connection keys, layer by layer
+        std::unordered_map<int, std::vector<int>> incoming;
+        for (int c = c0; c < c1; ++c) incoming[conn_out[c]].push_back(conn_in[c]);
+        std::unordered_set<int> required(out_keys, out_keys + n_out), seen(out_keys, out_keys + n_out);
+        std::vector<int> last(out_keys, out_keys + n_out);
+        for (;;) {
+            std::unordered_set<int> t;
+            for (int b : last) {
+                auto it = incoming.find(b);
+                if (it == incoming.end()) continue;
+                for (int a : it->second) if (!seen.count(a)) t.insert(a);
+            }
+            if (t.empty()) break;
+            std::vector<int> layer;
+            for (int x : t) if (!leaf_of.count(x)) layer.push_back(x);
+            if (layer.empty()) break;
+            for (int x : layer) required.insert(x);
+            for (int x : t) seen.insert(x);
+            last.assign(t.begin(), t.end());
+        }
+        // expressed connections, in genome.connections order
+        std::unordered_map<int, Conns> node_inputs;
+        for (int k = 0; k < n_out; ++k) node_inputs[out_keys[k]];
+        for (int c = c0; c < c1; ++c) {
+            if (!conn_en[c]) continue;
+            const int i = conn_in[c], o = conn_out[c];
+            if ((!required.count(o) && !required.count(i)) || out_set.count(i)) continue;
+            node_inputs[o].emplace_back(i, conn_w[c]);
+            node_inputs[i];
+        }
+        // node table of this genome
+        std::unordered_map<int, int> node_at;
+        for (int m = m0; m < m1; ++m) node_at[node_key[m]] = m;
+        // depth-first post-order from the outputs
+        std::vector<int> order;
+        std::unordered_map<int, int> state;
+        for (int k = 0; k < n_out && !status; ++k) {
+            std::vector<std::pair<int, int>> stack{{out_keys[k], 0}};
+            while (!stack.empty() && !status) {
+                const int n = stack.back().first, ci = stack.back().second;
+                stack.pop_back();
+                auto st = state.find(n);
+                if (leaf_of.count(n) || (st != state.end() && st->second == 2)) continue;
+                const Conns& conns = node_inputs[n];
+                if (ci == 0) {
+                    if (st != state.end() && st->second == 1) { status = 2; break; }  // cycle
+                    state[n] = 1;
+                }
+                if (ci < (int)conns.size()) {
+                    stack.emplace_back(n, ci + 1);
+                    const int child = conns[ci].first;
+                    auto sc = state.find(child);
+                    const int cs = sc == state.end() ? 0 : sc->second;
+                    if (!leaf_of.count(child) && cs != 2) {
+                        if (cs == 1) { status = 2; break; }  // cycle
+                        stack.emplace_back(child, 0);
+                    }
+                } else {
+                    state[n] = 2;
+                    order.push_back(n);
+                }
+            }
+        }
+        std::unordered_map<int, float> const32;
+        std::unordered_map<int, int> index;
+        auto emit_node = [&](uint8_t act, double bias, double resp) -> bool {
+            if (nn >= cap_nodes) return false;
+            o_act[nn] = act; o_bias[nn] = bias; o_resp[nn] = resp;
+            return true;
+        };
+        auto emit_edge = [&](int src, double w) -> bool {
+            if (ne >= cap_edges) return false;
+            o_edge_src[ne] = src; o_edge_w[ne] = w; ++ne;
+            return true;
+        };
+        bool full = false;
+        for (size_t oi = 0; oi < order.size() && !status && !full; ++oi) {
+            const int n = order[oi];
+            auto at = node_at.find(n);
+            if (at == node_at.end()) { status = 2; break; }
+            const int m = at->second;
+            const Conns& conns = node_inputs[n];
+            if ((!node_agg_sum[m] && !conns.empty()) || node_act[m] == 255) { status = 2; break; }
+            if (conns.empty()) { const32[n] = (float)node_bias[m]; continue; }
+            bool all_const = !const32.empty();
+            if (all_const) for (const auto& cw : conns) if (!const32.count(cw.first)) { all_const = false; break; }
+            if (all_const) { status = 1; break; }  // numpy float32 activation of a constant sub-graph: the caller's job
+            index[n] = nn - nn0;
+            if (!emit_node(node_act[m], node_bias[m], node_resp[m])) { full = true; break; }
+            size_t lead = 0;
+            if (!const32.empty()) while (lead < conns.size() && const32.count(conns[lead].first)) ++lead;
+            if (lead) {  // Python's sum(): the leading run of float32 constants accumulates in float32
+                float pre = 0.0f;
+                for (size_t j = 0; j < lead; ++j) {
+                    const float t = (float)conns[j].second * const32[conns[j].first];
+                    pre = j == 0 ? t : (float)(pre + t);
+                }
+                if (!emit_edge(ONE, (double)pre)) { full = true; break; }
+            }
+            for (size_t j = lead; j < conns.size() && !full; ++j) {
+                const int i = conns[j].first;
+                auto lf = leaf_of.find(i);
+                if (lf != leaf_of.end()) full = !emit_edge(-(lf->second + 1), conns[j].second);
+                else if (const32.count(i)) full = !emit_edge(ONE, (double)((float)conns[j].second * const32[i]));
+                else full = !emit_edge(index[i], conns[j].second);
+            }
+            if (full) break;
+            ++nn;
+            o_edge_off[nn] = ne;
+        }
+        for (int k = 0; k < n_out && !status && !full; ++k) {
+            const int o = out_keys[k];
+            auto cc = const32.find(o);
+            if (cc != const32.end()) {  // constant output plane: identity(1 * (k * 1.0) + 0) == k
+                index[o] = nn - nn0;
+                if (!emit_node(EIGEN_ACT_IDENTITY, 0.0, 1.0) || !emit_edge(ONE, (double)cc->second)) { full = true; break; }
+                ++nn;
+                o_edge_off[nn] = ne;
+            }
+            auto ix = index.find(o);
+            if (ix == index.end()) { status = 2; break; }
+            o_out_node[(size_t)g * n_out + k] = ix->second;
+        }
+        if (full) return fail(EIGEN_ERR_CAPACITY, "eigen_flatten_genomes: output capacity (%d nodes, %d edges) exceeded at genome %d", cap_nodes, cap_edges, g);
+        if (status) { nn = nn0; ne = ne0; }  // empty segment: the caller handles this genome
+        o_status[g] = status;
+        o_node_off[g + 1] = nn;
+    }
+    return EIGEN_OK;
 }
 
 int eigen_test_det_math(eigen_engine* e, const float* d_x, int32_t n, float* d_exp, float* d_sig, float* d_tanh, void* stream)

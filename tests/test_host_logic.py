@@ -111,6 +111,56 @@ def test_genome_flattening_rejects_what_pytorch_neat_rejects():
         genome.GenomeBatch([g], cfg, 3)  # 1 output, 3 channels asked
 
 
+def test_native_flattening_is_the_python_specification():
+    """eigen_flatten_genomes (host-side C in libeigen_hip.so) against genome._flatten_lists: identical arrays on random genomes with
+    disabled connections, constant nodes (float32 products and leading-run sums), constant outputs and constant sub-graphs
+    (declined to the Python path), 4-input configs; invalid genomes raise the same exceptions."""
+    from evolutionary_illusion_generator_amd import genome, synth
+    fields = ("node_off", "edge_off", "node_act", "node_bias", "node_resp", "edge_src", "edge_w", "out_node")
+    n_checked = 0
+    for seed, n_in, n_hidden, n_out, c_out in [(0, 2, 20, 3, 3), (1, 2, 8, 6, 3), (2, 2, 20, 1, 1), (3, 2, 0, 3, 3), (7, 2, 30, 3, 1), (5, 4, 12, 6, 3)]:
+        cfg = synth.make_config(n_in, n_out)
+        gs = [g for _, g in synth.make_population(120, cfg, seed=seed, num_hidden=n_hidden)]
+        rng = np.random.default_rng(seed)
+        for gi, g in enumerate(gs):
+            if gi % 2 == 0:
+                for c in g.connections.values():
+                    if rng.random() < 0.3:
+                        c.enabled = False
+            if gi % 9 == 0:  # an output without inputs: constant output plane
+                for key, c in g.connections.items():
+                    if key[1] == 0:
+                        c.enabled = False
+        a = genome.GenomeBatch(gs, cfg, c_out, n_leaves=n_in, native=True)
+        b = genome.GenomeBatch(gs, cfg, c_out, n_leaves=n_in, native=False)
+        for k in fields:
+            x, y = getattr(a, k), getattr(b, k)
+            assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y), (seed, k)
+        n_checked += len(gs)
+    assert n_checked == 720
+    cfg = synth.make_config(2, 1)
+    bad = synth.make_genome(1, cfg, 0)
+    bad.nodes[0].activation = "cube"
+    good = synth.make_genome(2, cfg, 1)
+    for native in (True, False):
+        with pytest.raises(ValueError, match="str_to_activation"):
+            genome.GenomeBatch([good, bad], cfg, 1, native=native)
+    cyc = synth.make_genome(3, cfg, 2)
+    hidden = [k for k in cyc.nodes if k >= 1][:2]
+    if len(hidden) == 2:
+        import copy
+        some = next(iter(cyc.connections.values()))
+        for key in ((hidden[0], hidden[1]), (hidden[1], hidden[0])):
+            c = copy.copy(some); c.key = key; c.enabled = True; c.weight = 0.5
+            cyc.connections[key] = c
+        for key in ((hidden[0], 0),):
+            c = copy.copy(some); c.key = key; c.enabled = True; c.weight = 0.5
+            cyc.connections[key] = c
+        for native in (True, False):
+            with pytest.raises(ValueError, match="cycle"):
+                genome.GenomeBatch([cyc], cfg, 1, native=native)
+
+
 def test_weights_tables(tmp_path):
     from evolutionary_illusion_generator_amd import weights
     import oracle
