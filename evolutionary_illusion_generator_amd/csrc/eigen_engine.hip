@@ -982,11 +982,20 @@ int eigen_score(eigen_engine* e, int32_t structure, int32_t width, int32_t heigh
                 double* d_fitness, void* stream)
 {
     if (!e || !d_vectors || !d_counts || !d_fitness) return fail(EIGEN_ERR_INVALID, "null argument");
-    if (structure < 0 || structure > 3) return fail(EIGEN_ERR_INVALID, "unknown structure %d (the reference raises NameError, generate_illusion.py:606-607)", structure);
+    if (structure < 0 || structure > EIGEN_SCORE_INSIDE_OUTSIDE)
+        return fail(EIGEN_ERR_INVALID, "unknown structure %d (the reference raises NameError, generate_illusion.py:606-607)", structure);
     if (batch < 1) return fail(EIGEN_ERR_INVALID, "batch < 1");
     HIPCHK(hipSetDevice(e->cfg.device));
     ScoreArgs a;
     a.vectors = d_vectors; a.counts = d_counts; a.K = e->K; a.structure = structure; a.w = width > 0 ? width : e->W; a.h = height > 0 ? height : e->H; a.fitness = d_fitness;
+    if (structure == EIGEN_SCORE_INSIDE_OUTSIDE) {
+        const double step = (double)a.w / 5.0;
+        const long cells = ((long)((double)a.w / step) + 1) * ((long)((double)a.h / step) + 1);
+        if (cells > IO_MAX_CELLS) return fail(EIGEN_ERR_CAPACITY, "inside_outside_score: %ld cells of %dx%d exceed %d", cells, a.w, a.h, IO_MAX_CELLS);
+        hipLaunchKernelGGL(inside_outside_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, a);
+        HIPCHK(hipGetLastError());
+        return EIGEN_OK;
+    }
     hipLaunchKernelGGL(score_kernel, dim3(batch), dim3(SCORE_T), 0, (hipStream_t)stream, a);
     HIPCHK(hipGetLastError());
     return EIGEN_OK;
@@ -1197,6 +1206,59 @@ int eigen_time_conv(eigen_engine* e, int32_t n_src, const float* const* d_src, c
 }
 
 // Host-only: the graph part of genome flattening (genome.py: _flatten_lists is the specification, statement by statement).
+// Keys are mapped to dense local ids once per genome (sorted key table + binary search), after which every set / map of the
+// specification is a flat array indexed by id and reused from genome to genome: ~3 us per genome instead of ~20 us with
+// node-based hash containers (256 genomes: 5.3 -> 0.8 ms, scripts/host_overhead.py).
+namespace {
+struct FlattenScratch {
+    std::vector<int> keys;                    // sorted unique keys of this genome (fallback when the key range is huge)
+    std::vector<int> dmap, dstamp;            // direct table key - kmin -> id, valid where dstamp == epoch
+    int epoch = 0, kmin = 0, n_ids = 0;
+    bool direct = false;
+    std::vector<int> leaf, is_out, required, seen, node_at, state, index, has_c32;
+    std::vector<float> c32;
+    std::vector<int> ci, co;                  // connection ends as ids
+    std::vector<int> in_off, in_src;          // incoming (ALL connections), CSR by out id
+    std::vector<int> ex_off, ex_src, ex_fill; // expressed connections, CSR by out id, genome.connections order kept
+    std::vector<double> ex_w;
+    std::vector<int> last, next, order;
+    std::vector<std::pair<int, int>> stack;
+    int id_of(int key)
+    {
+        if (!direct) return (int)(std::lower_bound(keys.begin(), keys.end(), key) - keys.begin());
+        const int at = key - kmin;
+        if (dstamp[at] != epoch) { dstamp[at] = epoch; dmap[at] = n_ids++; }
+        return dmap[at];
+    }
+    // ids for one genome's keys: NEAT keys are small integers (inputs -1..-n, nodes 0..), so a direct table serves; a
+    // sorted table + binary search is the fallback for pathological ranges
+    int begin(const int32_t* in_keys, int n_in, const int32_t* out_keys, int n_out, const int32_t* nk, int n_nodes,
+              const int32_t* ci_, const int32_t* co_, int nc)
+    {
+        int lo = 0, hi = 0;
+        bool first = true;
+        auto span = [&](const int32_t* p, int n) { for (int i = 0; i < n; ++i) { if (first) { lo = hi = p[i]; first = false; } lo = std::min(lo, (int)p[i]); hi = std::max(hi, (int)p[i]); } };
+        span(in_keys, n_in); span(out_keys, n_out); span(nk, n_nodes); span(ci_, nc); span(co_, nc);
+        const long range = (long)hi - lo + 1;
+        direct = range <= (1L << 22);
+        if (direct) {
+            kmin = lo; n_ids = 0;
+            if ((long)dstamp.size() < range) { dstamp.assign(range, 0); dmap.resize(range); epoch = 0; }
+            if (++epoch == 0x7fffffff) { std::fill(dstamp.begin(), dstamp.end(), 0); epoch = 1; }
+            auto reg = [&](const int32_t* p, int n) { for (int i = 0; i < n; ++i) id_of(p[i]); };
+            reg(in_keys, n_in); reg(out_keys, n_out); reg(nk, n_nodes); reg(ci_, nc); reg(co_, nc);
+            return n_ids;
+        }
+        keys.clear();
+        keys.insert(keys.end(), in_keys, in_keys + n_in); keys.insert(keys.end(), out_keys, out_keys + n_out);
+        keys.insert(keys.end(), nk, nk + n_nodes); keys.insert(keys.end(), ci_, ci_ + nc); keys.insert(keys.end(), co_, co_ + nc);
+        std::sort(keys.begin(), keys.end());
+        keys.erase(std::unique(keys.begin(), keys.end()), keys.end());
+        return (int)keys.size();
+    }
+};
+}  // namespace
+
 int eigen_flatten_genomes(int32_t G, int32_t n_in, const int32_t* in_keys, int32_t n_out, const int32_t* out_keys, const int32_t* conn_off,
                           const int32_t* conn_in, const int32_t* conn_out, const double* conn_w, const uint8_t* conn_en, const int32_t* node_off,
                           const int32_t* node_key, const uint8_t* node_act, const uint8_t* node_agg_sum, const double* node_bias,
@@ -1204,83 +1266,99 @@ int eigen_flatten_genomes(int32_t G, int32_t n_in, const int32_t* in_keys, int32
                           double* o_bias, double* o_resp, int32_t* o_edge_src, double* o_edge_w, int32_t* o_out_node, uint8_t* o_status)
 {
     if (G < 0 || !in_keys || !out_keys || !conn_off || !node_off || !o_node_off || !o_edge_off || !o_status) return fail(EIGEN_ERR_INVALID, "null argument");
-    std::unordered_map<int, int> leaf_of;
-    for (int i = 0; i < n_in; ++i) leaf_of[in_keys[i]] = i;
-    std::unordered_set<int> out_set(out_keys, out_keys + n_out);
+    static thread_local FlattenScratch S;
     const int ONE = -(n_in + 1);
     int nn = 0, ne = 0;  // nodes / edges emitted so far
     o_node_off[0] = 0;
     o_edge_off[0] = 0;
-    typedef std::vector<std::pair<int, double>> Conns;
     for (int g = 0; g < G; ++g) {
         const int c0 = conn_off[g], c1 = conn_off[g + 1], m0 = node_off[g], m1 = node_off[g + 1];
+        const int nc = c1 - c0;
         const int nn0 = nn, ne0 = ne;
         uint8_t status = 0;
-        // required_for_output over ALL connection keys, layer by layer
-        std::unordered_map<int, std::vector<int>> incoming;
-        for (int c = c0; c < c1; ++c) incoming[conn_out[c]].push_back(conn_in[c]);
-        std::unordered_set<int> required(out_keys, out_keys + n_out), seen(out_keys, out_keys + n_out);
-        std::vector<int> last(out_keys, out_keys + n_out);
+        // dense ids
+        const int N = S.begin(in_keys, n_in, out_keys, n_out, node_key + m0, m1 - m0, conn_in + c0, conn_out + c0, nc);
+        S.leaf.assign(N, -1); S.is_out.assign(N, 0); S.required.assign(N, 0); S.seen.assign(N, 0); S.node_at.assign(N, -1);
+        S.state.assign(N, 0); S.index.assign(N, -1); S.has_c32.assign(N, 0); S.c32.assign(N, 0.0f);
+        for (int i = 0; i < n_in; ++i) S.leaf[S.id_of(in_keys[i])] = i;
+        for (int m = m0; m < m1; ++m) S.node_at[S.id_of(node_key[m])] = m;   // a later duplicate key wins, as in a dict
+        S.ci.resize(nc); S.co.resize(nc);
+        for (int c = 0; c < nc; ++c) { S.ci[c] = S.id_of(conn_in[c0 + c]); S.co[c] = S.id_of(conn_out[c0 + c]); }
+        // incoming lists over ALL connection keys
+        S.in_off.assign(N + 1, 0);
+        for (int c = 0; c < nc; ++c) ++S.in_off[S.co[c] + 1];
+        for (int i = 0; i < N; ++i) S.in_off[i + 1] += S.in_off[i];
+        S.in_src.resize(nc);
+        S.ex_fill.assign(S.in_off.begin(), S.in_off.end() - 1);
+        for (int c = 0; c < nc; ++c) S.in_src[S.ex_fill[S.co[c]]++] = S.ci[c];
+        // required_for_output, layer by layer
+        S.last.clear();
+        for (int k = 0; k < n_out; ++k) {
+            const int o = S.id_of(out_keys[k]);
+            S.is_out[o] = 1;
+            if (!S.seen[o]) { S.seen[o] = 1; S.required[o] = 1; S.last.push_back(o); }
+        }
         for (;;) {
-            std::unordered_set<int> t;
-            for (int b : last) {
-                auto it = incoming.find(b);
-                if (it == incoming.end()) continue;
-                for (int a : it->second) if (!seen.count(a)) t.insert(a);
-            }
-            if (t.empty()) break;
-            std::vector<int> layer;
-            for (int x : t) if (!leaf_of.count(x)) layer.push_back(x);
-            if (layer.empty()) break;
-            for (int x : layer) required.insert(x);
-            for (int x : t) seen.insert(x);
-            last.assign(t.begin(), t.end());
-        }
-        // expressed connections, in genome.connections order
-        std::unordered_map<int, Conns> node_inputs;
-        for (int k = 0; k < n_out; ++k) node_inputs[out_keys[k]];
-        for (int c = c0; c < c1; ++c) {
-            if (!conn_en[c]) continue;
-            const int i = conn_in[c], o = conn_out[c];
-            if ((!required.count(o) && !required.count(i)) || out_set.count(i)) continue;
-            node_inputs[o].emplace_back(i, conn_w[c]);
-            node_inputs[i];
-        }
-        // node table of this genome
-        std::unordered_map<int, int> node_at;
-        for (int m = m0; m < m1; ++m) node_at[node_key[m]] = m;
-        // depth-first post-order from the outputs
-        std::vector<int> order;
-        std::unordered_map<int, int> state;
-        for (int k = 0; k < n_out && !status; ++k) {
-            std::vector<std::pair<int, int>> stack{{out_keys[k], 0}};
-            while (!stack.empty() && !status) {
-                const int n = stack.back().first, ci = stack.back().second;
-                stack.pop_back();
-                auto st = state.find(n);
-                if (leaf_of.count(n) || (st != state.end() && st->second == 2)) continue;
-                const Conns& conns = node_inputs[n];
-                if (ci == 0) {
-                    if (st != state.end() && st->second == 1) { status = 2; break; }  // cycle
-                    state[n] = 1;
+            S.next.clear();   // t: sources of connections into the layer added last that were not seen before
+            for (int b : S.last)
+                for (int j = S.in_off[b]; j < S.in_off[b + 1]; ++j) {
+                    const int a = S.in_src[j];
+                    if (!S.seen[a] && S.state[a] == 0) { S.state[a] = 1; S.next.push_back(a); }   // state doubles as "in t" here
                 }
-                if (ci < (int)conns.size()) {
-                    stack.emplace_back(n, ci + 1);
-                    const int child = conns[ci].first;
-                    auto sc = state.find(child);
-                    const int cs = sc == state.end() ? 0 : sc->second;
-                    if (!leaf_of.count(child) && cs != 2) {
-                        if (cs == 1) { status = 2; break; }  // cycle
-                        stack.emplace_back(child, 0);
+            if (S.next.empty()) break;
+            bool any_layer = false;
+            for (int x : S.next) if (S.leaf[x] < 0) any_layer = true;
+            for (int x : S.next) S.state[x] = 0;
+            if (!any_layer) break;
+            for (int x : S.next) { if (S.leaf[x] < 0) S.required[x] = 1; S.seen[x] = 1; }
+            S.last.swap(S.next);
+        }
+        // expressed connections, per destination, in genome.connections order
+        S.ex_off.assign(N + 1, 0);
+        for (int c = 0; c < nc; ++c) {
+            if (!conn_en[c0 + c]) continue;
+            const int i = S.ci[c], o = S.co[c];
+            if ((!S.required[o] && !S.required[i]) || S.is_out[i]) continue;
+            ++S.ex_off[o + 1];
+        }
+        for (int i = 0; i < N; ++i) S.ex_off[i + 1] += S.ex_off[i];
+        const int nex = S.ex_off[N];
+        S.ex_src.resize(nex); S.ex_w.resize(nex);
+        S.ex_fill.assign(S.ex_off.begin(), S.ex_off.end() - 1);
+        for (int c = 0; c < nc; ++c) {
+            if (!conn_en[c0 + c]) continue;
+            const int i = S.ci[c], o = S.co[c];
+            if ((!S.required[o] && !S.required[i]) || S.is_out[i]) continue;
+            const int at = S.ex_fill[o]++;
+            S.ex_src[at] = i; S.ex_w[at] = conn_w[c0 + c];
+        }
+        // depth-first post-order from the outputs
+        S.order.clear();
+        for (int k = 0; k < n_out && !status; ++k) {
+            S.stack.clear();
+            S.stack.emplace_back(S.id_of(out_keys[k]), 0);
+            while (!S.stack.empty() && !status) {
+                const int n = S.stack.back().first, ci = S.stack.back().second;
+                S.stack.pop_back();
+                if (S.leaf[n] >= 0 || S.state[n] == 2) continue;
+                const int cn = S.ex_off[n + 1] - S.ex_off[n];
+                if (ci == 0) {
+                    if (S.state[n] == 1) { status = 2; break; }  // cycle
+                    S.state[n] = 1;
+                }
+                if (ci < cn) {
+                    S.stack.emplace_back(n, ci + 1);
+                    const int child = S.ex_src[S.ex_off[n] + ci];
+                    if (S.leaf[child] < 0 && S.state[child] != 2) {
+                        if (S.state[child] == 1) { status = 2; break; }  // cycle
+                        S.stack.emplace_back(child, 0);
                     }
                 } else {
-                    state[n] = 2;
-                    order.push_back(n);
+                    S.state[n] = 2;
+                    S.order.push_back(n);
                 }
             }
         }
-        std::unordered_map<int, float> const32;
-        std::unordered_map<int, int> index;
         auto emit_node = [&](uint8_t act, double bias, double resp) -> bool {
             if (nn >= cap_nodes) return false;
             o_act[nn] = act; o_bias[nn] = bias; o_resp[nn] = resp;
@@ -1291,53 +1369,49 @@ int eigen_flatten_genomes(int32_t G, int32_t n_in, const int32_t* in_keys, int32
             o_edge_src[ne] = src; o_edge_w[ne] = w; ++ne;
             return true;
         };
-        bool full = false;
-        for (size_t oi = 0; oi < order.size() && !status && !full; ++oi) {
-            const int n = order[oi];
-            auto at = node_at.find(n);
-            if (at == node_at.end()) { status = 2; break; }
-            const int m = at->second;
-            const Conns& conns = node_inputs[n];
-            if ((!node_agg_sum[m] && !conns.empty()) || node_act[m] == 255) { status = 2; break; }
-            if (conns.empty()) { const32[n] = (float)node_bias[m]; continue; }
-            bool all_const = !const32.empty();
-            if (all_const) for (const auto& cw : conns) if (!const32.count(cw.first)) { all_const = false; break; }
+        bool full = false, any_c32 = false;
+        for (size_t oi = 0; oi < S.order.size() && !status && !full; ++oi) {
+            const int n = S.order[oi];
+            const int m = S.node_at[n];
+            if (m < 0) { status = 2; break; }
+            const int e0 = S.ex_off[n], e1 = S.ex_off[n + 1];
+            if ((!node_agg_sum[m] && e1 > e0) || node_act[m] == 255) { status = 2; break; }
+            if (e1 == e0) { S.has_c32[n] = 1; S.c32[n] = (float)node_bias[m]; any_c32 = true; continue; }
+            bool all_const = any_c32;
+            if (all_const) for (int j = e0; j < e1; ++j) if (!S.has_c32[S.ex_src[j]]) { all_const = false; break; }
             if (all_const) { status = 1; break; }  // numpy float32 activation of a constant sub-graph: the caller's job
-            index[n] = nn - nn0;
+            S.index[n] = nn - nn0;
             if (!emit_node(node_act[m], node_bias[m], node_resp[m])) { full = true; break; }
-            size_t lead = 0;
-            if (!const32.empty()) while (lead < conns.size() && const32.count(conns[lead].first)) ++lead;
-            if (lead) {  // Python's sum(): the leading run of float32 constants accumulates in float32
+            int lead = e0;
+            if (any_c32) while (lead < e1 && S.has_c32[S.ex_src[lead]]) ++lead;
+            if (lead > e0) {  // Python's sum(): the leading run of float32 constants accumulates in float32
                 float pre = 0.0f;
-                for (size_t j = 0; j < lead; ++j) {
-                    const float t = (float)conns[j].second * const32[conns[j].first];
-                    pre = j == 0 ? t : (float)(pre + t);
+                for (int j = e0; j < lead; ++j) {
+                    const float t = (float)S.ex_w[j] * S.c32[S.ex_src[j]];
+                    pre = j == e0 ? t : (float)(pre + t);
                 }
                 if (!emit_edge(ONE, (double)pre)) { full = true; break; }
             }
-            for (size_t j = lead; j < conns.size() && !full; ++j) {
-                const int i = conns[j].first;
-                auto lf = leaf_of.find(i);
-                if (lf != leaf_of.end()) full = !emit_edge(-(lf->second + 1), conns[j].second);
-                else if (const32.count(i)) full = !emit_edge(ONE, (double)((float)conns[j].second * const32[i]));
-                else full = !emit_edge(index[i], conns[j].second);
+            for (int j = lead; j < e1 && !full; ++j) {
+                const int i = S.ex_src[j];
+                if (S.leaf[i] >= 0) full = !emit_edge(-(S.leaf[i] + 1), S.ex_w[j]);
+                else if (S.has_c32[i]) full = !emit_edge(ONE, (double)((float)S.ex_w[j] * S.c32[i]));
+                else full = !emit_edge(S.index[i], S.ex_w[j]);
             }
             if (full) break;
             ++nn;
             o_edge_off[nn] = ne;
         }
         for (int k = 0; k < n_out && !status && !full; ++k) {
-            const int o = out_keys[k];
-            auto cc = const32.find(o);
-            if (cc != const32.end()) {  // constant output plane: identity(1 * (k * 1.0) + 0) == k
-                index[o] = nn - nn0;
-                if (!emit_node(EIGEN_ACT_IDENTITY, 0.0, 1.0) || !emit_edge(ONE, (double)cc->second)) { full = true; break; }
+            const int o = S.id_of(out_keys[k]);
+            if (S.has_c32[o]) {  // constant output plane: identity(1 * (k * 1.0) + 0) == k
+                S.index[o] = nn - nn0;
+                if (!emit_node(EIGEN_ACT_IDENTITY, 0.0, 1.0) || !emit_edge(ONE, (double)S.c32[o])) { full = true; break; }
                 ++nn;
                 o_edge_off[nn] = ne;
             }
-            auto ix = index.find(o);
-            if (ix == index.end()) { status = 2; break; }
-            o_out_node[(size_t)g * n_out + k] = ix->second;
+            if (S.index[o] < 0) { status = 2; break; }
+            o_out_node[(size_t)g * n_out + k] = S.index[o];
         }
         if (full) return fail(EIGEN_ERR_CAPACITY, "eigen_flatten_genomes: output capacity (%d nodes, %d edges) exceeded at genome %d", cap_nodes, cap_edges, g);
         if (status) { nn = nn0; ne = ne0; }  // empty segment: the caller handles this genome

@@ -19,7 +19,7 @@ struct ScoreArgs {
     const float* vectors;  // [B][K][4]
     const int* counts;     // [B]
     int K;
-    int structure;         // 0 Bands, 1 Circles, 2 Free, 3 CirclesFree
+    int structure;         // 0 Bands, 1 Circles, 2 Free, 3 CirclesFree (score_kernel); 4 inside_outside_score (inside_outside_kernel)
     int w, h;
     double* fitness;       // [B]
 };
@@ -197,6 +197,84 @@ __global__ void __launch_bounds__(SCORE_T) score_kernel(const ScoreArgs a)
         }
     }
     if (t == 0) a.fitness[b] = score;
+}
+
+// inside_outside_score (fitness_calculator.py:219-304; a12): agreement of the vectors inside 5 x n cells plus disagreement
+// with the neighbouring cells.  Unreachable at the reference's call sites (the else branch of the scoring block names an
+// undefined `good_vectors`, generate_illusion.py:606-607), so it is a scorer of its own (eigen_score structure 4): ALL the
+// given vectors, no plausibility filter, no sentinel.  Quirks kept: counts start at 1, neighbourhood x in [i-1, i],
+// y in [j-1, min(h, i+1)) (`i + 1` for `j + 1`, :272), the cell itself excluded.  Vector sums run sequentially in vector
+// order like the reference's loops; the two np.mean reductions are sequential here (pairwise in numpy: ~1e-16 relative).
+constexpr int IO_MAX_CELLS = 6 * 64;
+
+__global__ void __launch_bounds__(64) inside_outside_kernel(const ScoreArgs a)
+{
+    __shared__ double fx[IO_MAX_CELLS], fy[IO_MAX_CELLS], cnt[IO_MAX_CELLS], ax[IO_MAX_CELLS], ay[IO_MAX_CELLS], ns[IO_MAX_CELLS];
+    __shared__ double sd[IO_MAX_CELLS];
+    const int b = blockIdx.x, t = threadIdx.x;
+    int n = a.counts[b];
+    if (n > a.K) n = a.K;
+    const float* v = a.vectors + (size_t)b * a.K * 4;
+    const double step = (double)a.w / 5.0;
+    const int w = (int)((double)a.w / step) + 1, h = (int)((double)a.h / step) + 1;
+    const int cells = w * h;  // <= IO_MAX_CELLS, checked by the host
+    for (int c = t; c < cells; c += 64) { fx[c] = 0; fy[c] = 0; cnt[c] = 1; ax[c] = 0; ay[c] = 0; ns[c] = 0; }
+    __syncthreads();
+    auto cell = [&](int k) {
+        int i = (int)((double)v[k * 4] / step), j = (int)((double)v[k * 4 + 1] / step);
+        i = i < 0 ? 0 : (i >= w ? w - 1 : i);  // positions are inside the image; the reference would wrap / raise otherwise
+        j = j < 0 ? 0 : (j >= h ? h - 1 : j);
+        return i * h + j;
+    };
+    if (t == 0) {
+        for (int k = 0; k < n; ++k) {
+            const int c = cell(k);
+            const double dx = (double)v[k * 4 + 2], dy = (double)v[k * 4 + 3];
+            fx[c] += dx; fy[c] += dy; cnt[c] += 1;
+            ns[c] += sqrt(dx * dx + dy * dy);
+        }
+        for (int c = 0; c < cells; ++c) { fx[c] = fx[c] / cnt[c]; fy[c] = fy[c] / cnt[c]; ns[c] = ns[c] / cnt[c]; }
+        for (int k = 0; k < n; ++k) {
+            const int c = cell(k);
+            const double dx = (double)v[k * 4 + 2], dy = (double)v[k * 4 + 3];
+            ax[c] += (fx[c] - dx) * (fx[c] - dx);
+            ay[c] += (fy[c] - dy) * (fy[c] - dy);
+        }
+        for (int c = 0; c < cells; ++c) { ax[c] = ax[c] / cnt[c]; ay[c] = ay[c] / cnt[c]; }
+    }
+    __syncthreads();
+    for (int c = t; c < cells; c += 64) {
+        const int i = c / h, j = c % h;
+        double vx = fx[c], vy = fy[c];
+        if (vx != 0 || vy != 0) { const double nv = sqrt(vx * vx + vy * vy); vx = vx / nv; vy = vy / nv; }
+        const int min_i = i - 1 < 0 ? 0 : i - 1, max_i = i + 1 < w ? i + 1 : w;
+        const int min_j = j - 1 < 0 ? 0 : j - 1, max_j = i + 1 < h ? i + 1 : h;
+        int plus = 0, minus = 0;
+        for (int x = min_i; x < max_i; ++x)
+            for (int y = min_j; y < max_j; ++y) {
+                if (x == i && y == j) continue;
+                double wx = fx[x * h + y], wy = fy[x * h + y];
+                if (wx != 0 || wy != 0) {
+                    const double nw = sqrt(wx * wx + wy * wy);
+                    wx = wx / nw; wy = wy / nw;
+                    if (vx * wx + vy * wy > 0) ++plus; else ++minus;
+                }
+            }
+        sd[c] = (double)((plus < 2 ? plus : 2) + (minus < 2 ? minus : 2)) / 4.0;
+    }
+    __syncthreads();
+    if (t == 0) {
+        double sa = 0, sn = 0, sum_d = 0;
+        for (int c = 0; c < cells; ++c) { sa += ax[c]; sa += ay[c]; }   // np.mean over [w][h][2]: (x, y) interleaved
+        for (int c = 0; c < cells; ++c) sn += ns[c];
+        for (int c = 0; c < cells; ++c) sum_d += sd[c];
+        const double mean_a = sa / (double)(2 * cells), mean_n = sn / (double)cells;
+        const double score_agreement = -(mean_a < 10.0 ? mean_a : 10.0);
+        const double score_size = (10.0 < mean_n) ? 10.0 : mean_n;   // Python min(10, x)
+        sum_d = sum_d / (double)cells;
+        sum_d = sum_d * 10;
+        a.fitness[b] = (score_agreement + score_size + sum_d) / 30;
+    }
 }
 
 }  // namespace eig

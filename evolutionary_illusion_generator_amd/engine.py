@@ -174,7 +174,17 @@ class Engine:
         s = self._genome_struct(gb)
         _check(self.lib.eigen_eval_cppn_nodes(self._h, ctypes.byref(s), _ptr(d_nodes), _stream_arg(stream)))
 
+    def _check_images(self, d_images, batch):
+        """The C side reads batch * C0 * H * W bytes from the raw pointer: refuse anything smaller."""
+        need = int(batch) * self.c_dim * self.height * self.width
+        have = getattr(d_images, "numel", None)
+        have = have() if callable(have) else getattr(d_images, "size", None)
+        if isinstance(have, int) and have < need:
+            raise ValueError("image buffer holds %d bytes, %d images of (%d, %d, %d) need %d"
+                             % (have, batch, self.c_dim, self.height, self.width, need))
+
     def prednet_rollout(self, d_images, batch, n_steps, first_out_step, d_frames, stream=None):
+        self._check_images(d_images, batch)
         _check(self.lib.eigen_prednet_rollout(self._h, _ptr(d_images), ctypes.c_int32(batch), ctypes.c_int32(n_steps),
                                               ctypes.c_int32(first_out_step), _ptr(d_frames), _stream_arg(stream)))
 
@@ -194,6 +204,7 @@ class Engine:
         return fit
 
     def eval_images(self, d_images, batch, structure, pairing=PAIR_SINGLE, stream=None):
+        self._check_images(d_images, batch)
         fit = np.zeros(batch, dtype=np.float64)
         vec = np.zeros((batch, self.K, 4), dtype=np.float32)
         cnt = np.zeros(batch, dtype=np.int32)

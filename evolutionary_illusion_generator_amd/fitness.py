@@ -35,14 +35,24 @@ DEFAULT_MAX_BATCH = 256
 _engines = {}
 
 
-def _resolve_weights(model_name, channels, w, h):
+def _weights_key(model_name):
+    """Cache key of a weight source WITHOUT reading it: get_fitnesses_neat resolves its engine several times per
+    generation, and a 33 MB npz (0.2 s) or a synthetic set (0.6 s) must only be materialised on a cache miss."""
     if isinstance(model_name, dict):
-        return model_name, ("dict", id(model_name))
+        return ("dict", id(model_name))
     name = str(model_name)
     if name.startswith("synthetic"):
-        seed = int(name.split(":")[1]) if ":" in name else 0
-        return synthetic_prednet_weights(channels, w, h, seed=seed), ("synthetic", seed)
-    return load_chainer_npz(name, channels, w, h), ("file", os.path.abspath(name), os.path.getmtime(name))
+        return ("synthetic", int(name.split(":")[1]) if ":" in name else 0)
+    return ("file", os.path.abspath(name), os.path.getmtime(name))
+
+
+def _resolve_weights(model_name, channels, w, h):
+    if isinstance(model_name, dict):
+        return model_name
+    name = str(model_name)
+    if name.startswith("synthetic"):
+        return synthetic_prednet_weights(channels, w, h, seed=int(name.split(":")[1]) if ":" in name else 0)
+    return load_chainer_npz(name, channels, w, h)
 
 
 def _local_device():
@@ -56,14 +66,14 @@ def get_engine(model_name, w, h, channels, max_batch=None, **kw):
     """Engine handles are cached per (device, size, channels, weights): workspaces and packed weights stay in HBM
     across generations."""
     channels = [int(c) for c in channels]
-    weights, wkey = _resolve_weights(model_name, channels, w, h)
     dev = _local_device()
     mb = int(max_batch or int(os.environ.get("EIGEN_MAX_BATCH", DEFAULT_MAX_BATCH)))
-    key = (dev, w, h, tuple(channels), wkey, mb, tuple(sorted(kw.items())))
+    key = (dev, w, h, tuple(channels), _weights_key(model_name), mb, tuple(sorted(kw.items())))
     eng = _engines.get(key)
     if eng is None:
         eng = Engine(w, h, channels, mb, device=dev, **kw)
-        eng.set_weights(weights)
+        eng.set_weights(_resolve_weights(model_name, channels, w, h))
+        eng._weights_ref = model_name  # a dict is keyed by id(): keep it alive so the id cannot be reused
         eng._grid_key = None
         _engines[key] = eng
     return eng
@@ -112,30 +122,51 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
 
 
-def sharded_map(n_items, evaluate, group=None):
+def sharded_map(n_items, evaluate, group=None, extra=None):
     """Evaluate items [lo, hi) of this rank with ``evaluate(lo, hi) -> float64 array`` and all-gather the
-    scalars so that every rank returns the full float64 vector.  One collective per call; no data-path exchange."""
+    scalars so that every rank returns the full float64 vector.  One collective per call; no data-path exchange.
+    ``extra``: one float64 per rank that rides in the same collective (a digest, a timing); when given the result
+    is ``(vector, extras[R])``."""
     dist = _dist()
     if dist is None:
-        return np.asarray(evaluate(0, n_items), dtype=np.float64)
+        res = np.asarray(evaluate(0, n_items), dtype=np.float64)
+        return res if extra is None else (res, np.asarray([extra], dtype=np.float64))
     import torch
     R, r = dist.get_world_size(group), dist.get_rank(group)
     lo, hi, per = shard_bounds(n_items, R, r)
-    local = np.zeros(per, dtype=np.float64)
+    slot = per + (1 if extra is not None else 0)
+    local = np.zeros(slot, dtype=np.float64)
     if hi > lo:
         local[:hi - lo] = evaluate(lo, hi)
-    on_gpu = dist.get_backend(group) == "nccl"
+    if extra is not None:
+        local[per] = extra
     t = torch.from_numpy(local)
-    if on_gpu:
+    if dist.get_backend(group) == "nccl":
         t = t.cuda()
-    out = torch.empty(per * R, dtype=torch.float64, device=t.device)
+    out = torch.empty(slot * R, dtype=torch.float64, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
-    full = out.cpu().numpy().reshape(R, per)
+    full = out.cpu().numpy().reshape(R, slot)
     res = np.zeros(n_items, dtype=np.float64)
     for k in range(R):
         a, b, _ = shard_bounds(n_items, R, k)
         res[a:b] = full[k, :b - a]
-    return res
+    return res if extra is None else (res, full[:, per].copy())
+
+
+def _broadcast_bytes(payload, src=0, group=None):
+    """bytes of rank ``src`` -> every rank (two broadcasts: length, then the buffer; device tensors under nccl = RCCL)."""
+    import torch
+    dist = _dist()
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    me = dist.get_rank(group)
+    n = torch.tensor([len(payload) if me == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src, group=group)
+    if me == src:
+        buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
+    else:
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    dist.broadcast(buf, src, group=group)
+    return payload if me == src else buf.cpu().numpy().tobytes()
 
 
 # ----------------------------------------------------------------------------------------------- the API
@@ -144,24 +175,88 @@ def sharded_map(n_items, evaluate, group=None):
 # so the choice is a module setting; evaluate_population also takes it as an argument.
 FLOW_METHOD = "lk"
 
+# Where a multi-rank run takes its genomes from (one rank per GPU, torch.distributed initialised):
+#   "rank0"      rank 0 flattens ITS population once and broadcasts the ~1 KB/genome wire arrays; every rank evaluates its
+#                contiguous slice of THAT batch.  Rank 0 is authoritative (north_star: "all-gather ... back to the rank-0
+#                reproduction step"), so the result is right even when the ranks' own NEAT runs were never seeded alike
+#                (the reference and neat-python never seed `random`).
+#   "replicated" every rank flattens only its own slice of its own copy of the population (no broadcast); a digest of the
+#                population rides in the fitness all-gather and a mismatch raises -- the ranks MUST run identically seeded.
+GENOME_SOURCE = os.environ.get("EIGEN_GENOME_SOURCE", "rank0")
+
+
+def _engine_for(model_name, w, h, channels, max_batch, flow):
+    flow = flow or FLOW_METHOD
+    return get_engine(model_name, w, h, channels, max_batch=max_batch, **({} if flow == "lk" else {"flow": flow}))
+
+
+def evaluate_batch(structure, gb, n_in, model_name, w, h, channels, c_dim=3, gradient=1, bg=1,
+                   pairing=PAIR_POPULATION, max_batch=None, flow=None):
+    """Fitness (float64 array) of an already flattened genome batch on the local GPU, in chunks of max_batch."""
+    channels = [int(c) for c in channels]
+    if channels[0] != c_dim:
+        raise ValueError("channels[0]=%d but c_dim=%d: PredNet's input channels are the image channels" % (channels[0], c_dim))
+    eng = _engine_for(model_name, w, h, channels, max_batch, flow)
+    _set_grid(eng, structure, w, h, n_in)
+    out = np.zeros(gb.n_genomes, dtype=np.float64)
+    for i in range(0, gb.n_genomes, eng.max_batch):
+        j = min(gb.n_genomes, i + eng.max_batch)
+        out[i:j] = eng.eval_population(gb.slice(i, j), int(structure), bg=bg, gradient=gradient, pairing=pairing)
+    return out
+
 
 def evaluate_population(structure, genomes, model_name, config, w, h, channels, c_dim=3, gradient=1, bg=1,
                         pairing=PAIR_POPULATION, max_batch=None, flow=None):
     """Fitness (float64 array) of a list of genome objects on the local GPU, in chunks of max_batch."""
-    channels = [int(c) for c in channels]
-    if channels[0] != c_dim:
-        raise ValueError("channels[0]=%d but c_dim=%d: PredNet's input channels are the image channels" % (channels[0], c_dim))
-    flow = flow or FLOW_METHOD
-    eng = get_engine(model_name, w, h, channels, max_batch=max_batch, **({} if flow == "lk" else {"flow": flow}))
     n_in = len(config.genome_config.input_keys)
-    _set_grid(eng, structure, w, h, n_in)
     c_out = c_dim if gradient == 1 else 1
-    out = np.zeros(len(genomes), dtype=np.float64)
-    for i in range(0, len(genomes), eng.max_batch):
-        chunk = genomes[i:i + eng.max_batch]
-        gb = GenomeBatch(chunk, config, c_out, n_leaves=n_in)  # Q6: the first c_dim outputs are rendered
-        out[i:i + len(chunk)] = eng.eval_population(gb, int(structure), bg=bg, gradient=gradient, pairing=pairing)
-    return out
+    gb = GenomeBatch(genomes, config, c_out, n_leaves=n_in)  # Q6: the first c_dim outputs are rendered
+    return evaluate_batch(structure, gb, n_in, model_name, w, h, channels, c_dim=c_dim, gradient=gradient, bg=bg,
+                          pairing=pairing, max_batch=max_batch, flow=flow)
+
+
+def population_digest(genomes):
+    """Cheap fingerprint of a population (keys, sizes and one weight / bias per genome; < 0.2 ms for 256 genomes): two
+    NEAT runs that were not seeded alike differ in it from the first generation on."""
+    import zlib
+    parts = []
+    for g in genomes:
+        c = next(iter(g.connections.values()), None)
+        n = next(iter(g.nodes.values()), None)
+        parts.append((getattr(g, "key", None), len(g.nodes), len(g.connections),
+                      None if c is None else (c.weight, c.enabled), None if n is None else n.bias))
+    return float(zlib.crc32(repr(parts).encode()))
+
+
+def population_fitness(structure, genomes, model_name, config, w, h, channels, c_dim=3, gradient=1, max_batch=None,
+                       flow=None, source=None):
+    """Fitness of the WHOLE population list on every rank: the population is sharded over the ranks (contiguous slices in
+    list order), every rank evaluates its slice on its GPU, ONE all-gather of float64 scalars returns the full vector
+    (SURVEY 8(e)).  Single process: plain evaluate_population."""
+    dist = _dist()
+    kw = dict(c_dim=c_dim, gradient=gradient, max_batch=max_batch, flow=flow)
+    if dist is None:
+        return evaluate_population(structure, genomes, model_name, config, w, h, channels, **kw)
+    source = source or GENOME_SOURCE
+    if source == "replicated":
+        scores, digests = sharded_map(len(genomes), lambda lo, hi: evaluate_population(
+            structure, genomes[lo:hi], model_name, config, w, h, channels, **kw), extra=population_digest(genomes))
+        if not np.all(digests == digests[0]):
+            raise EngineError("the ranks hold different populations (digests %s): with EIGEN_GENOME_SOURCE=replicated every "
+                              "rank must run the same seeded NEAT (random.seed(<const>) before neat.Population); or use the "
+                              "default source 'rank0'" % digests.tolist())
+        return scores
+    if source != "rank0":
+        raise ValueError("GENOME_SOURCE must be 'rank0' or 'replicated', got %r" % (source,))
+    n_in = len(config.genome_config.input_keys)
+    payload = b""
+    if dist.get_rank() == 0:
+        payload = GenomeBatch(genomes, config, c_dim if gradient == 1 else 1, n_leaves=n_in).to_bytes()
+    gb = GenomeBatch.from_bytes(_broadcast_bytes(payload))
+    return sharded_map(gb.n_genomes, lambda lo, hi: evaluate_batch(structure, gb.slice(lo, hi), n_in, model_name, w, h, channels, **kw))
+
+
+_warned_diverged = [False]
 
 
 def get_fitnesses_neat(structure, population, model_name, config, w, h, channels,
@@ -169,11 +264,13 @@ def get_fitnesses_neat(structure, population, model_name, config, w, h, channels
     """Drop-in for generate_illusion.get_fitnesses_neat: sets ``genome.fitness`` for every (id, genome) pair."""
     print("Calculating fitnesses of populations: ", len(population))
     genomes = [g for _, g in population]
-
-    def evaluate(lo, hi):
-        return evaluate_population(structure, genomes[lo:hi], model_name, config, w, h, channels, c_dim=c_dim, gradient=gradient)
-
-    scores = sharded_map(len(genomes), evaluate)
+    scores = population_fitness(structure, genomes, model_name, config, w, h, channels, c_dim=c_dim, gradient=gradient)
+    if len(scores) != len(population):  # source "rank0" on a rank whose own NEAT run diverged from rank 0's
+        if not _warned_diverged[0]:
+            print("eigen: this rank's population (%d genomes) is not rank 0's (%d): rank 0 is authoritative; seed `random` "
+                  "identically on every rank to keep the replicas in step" % (len(population), len(scores)))
+            _warned_diverged[0] = True
+        scores = np.resize(scores, len(population)) if len(scores) else np.zeros(len(population))
     best_score, best_illusion, best_genome = 0, 0, None
     for i, (_, genome) in enumerate(population):
         genome.fitness = float(scores[i])
@@ -189,10 +286,10 @@ def get_fitnesses_neat(structure, population, model_name, config, w, h, channels
     return scores
 
 
-def render_images(structure, genomes, model_name, config, w, h, channels, c_dim=3, gradient=1, bg=1):
+def render_images(structure, genomes, model_name, config, w, h, channels, c_dim=3, gradient=1, bg=1, max_batch=None):
     """uint8 [n, C, H, W] images of get_image_from_cppn (generate_illusion.py:372-460) for a list of genomes."""
     import torch
-    eng = get_engine(model_name, w, h, channels)
+    eng = _engine_for(model_name, w, h, [int(c) for c in channels], max_batch, None)  # the engine the fitness path uses
     n_in = len(config.genome_config.input_keys)
     _set_grid(eng, structure, w, h, n_in)
     out = []
@@ -229,18 +326,20 @@ def save_best_artifacts(structure, genome, model_name, config, w, h, channels, c
     to_pil(white).save(os.path.join(best_dir, "best.png"), "PNG")
     black = render_images(structure, [genome], model_name, config, w, h, channels, c_dim, gradient, 0)[0]
     to_pil(black).save(os.path.join(best_dir, "best_black_bg.png"), "PNG")
-    # flow overlay: population pairing (prediction@20 -> first extension), as the fitness used
-    eng = get_engine(model_name, w, h, channels)
-    d = torch.from_numpy(white[None]).cuda()
+    # flow overlay: population pairing (prediction@20 -> first extension) and flow method, as the fitness used
+    eng = _engine_for(model_name, w, h, [int(c) for c in channels], None, None)
+    d = torch.from_numpy(np.ascontiguousarray(white[None])).cuda()
     _, vecs = eng.eval_images(d, 1, int(structure), pairing=PAIR_POPULATION)
+    np.save(os.path.join(best_dir, "best_flow_vectors.npy"), np.asarray(vecs[0], dtype=np.float32).reshape(-1, 4))
     flow = to_pil(white).convert("RGB")
     draw = ImageDraw.Draw(flow)
     for x, y, dx, dy in vecs[0]:
         draw.line([(x, y), (x + flow_scale * dx, y + flow_scale * dy)], fill=(255, 0, 0), width=1)
         draw.ellipse([x - 1, y - 1, x + 1, y + 1], fill=(255, 255, 0))
     flow.save(os.path.join(best_dir, "best_flow.png"), "PNG")
-    # enhanced image: 3x3 + 2x2 circles on a render-only engine (one PredNet layer keeps its workspaces tiny)
-    if enhanced_size and int(structure) in (int(StructureType.Circles), int(StructureType.CirclesFree)):
+    # enhanced image: 3x3 + 2x2 circles on a render-only engine (one PredNet layer keeps its workspaces tiny); written for
+    # every structure, as the reference does (generate_illusion.py:665-671; Bands / Free get ring coordinates with theta 0)
+    if enhanced_size:
         e = enhanced_size
         key = ("render", _local_device(), e, c_dim)
         reng = _engines.get(key)
@@ -283,7 +382,12 @@ def get_vectors(image_path, model_name, channels, w, h):
     c_dim = channels[0]
     if isinstance(image_path, np.ndarray):
         a = image_path if image_path.ndim == 3 else image_path[:, :, None]
-        img = np.ascontiguousarray(a.transpose(2, 0, 1).astype(np.uint8))
+        if a.ndim != 3 or a.shape[2] != c_dim:
+            raise ValueError("image array must be (H, W) or (H, W, %d) uint8, got shape %s" % (c_dim, image_path.shape))
+        top, left = (a.shape[0] - h) // 2, (a.shape[1] - w) // 2  # centre crop, as for files
+        if top < 0 or left < 0:
+            raise ValueError("image array is %dx%d, smaller than the requested %dx%d" % (a.shape[1], a.shape[0], w, h))
+        img = np.ascontiguousarray(a[top:top + h, left:left + w].transpose(2, 0, 1).astype(np.uint8))
     else:
         img = _read_image_chw(image_path, c_dim, w, h)
     eng = get_engine(model_name, w, h, channels)
@@ -298,6 +402,11 @@ def calculate_fitness(structure, vectors, image_path, w, h):
     import torch
     if int(structure) not in (0, 1, 2, 3):
         raise NameError("name 'good_vectors' is not defined")  # what the reference does for an unknown structure
+    return _device_score(structure, vectors, w, h)
+
+
+def _device_score(structure, vectors, w, h):
+    import torch
     v = np.asarray(vectors, dtype=np.float64).reshape(-1, 4) if (len(vectors) and vectors[0] is not None) else np.zeros((0, 4))
     eng = _score_engine(w, h, max(len(v), 1))
     K = eng.K
@@ -311,6 +420,12 @@ def calculate_fitness(structure, vectors, image_path, w, h):
     eng.score(int(structure), dv, dc, 1, df, width=int(w), height=int(h))
     torch.cuda.synchronize()
     return float(df.cpu().numpy()[0])
+
+
+def inside_outside_score(vectors, width, height):
+    """fitness_calculator.inside_outside_score (:219-304) on the device scorer.  The reference only reaches it through an
+    else branch that raises NameError, so it is offered under its own name rather than through calculate_fitness."""
+    return _device_score(4, vectors, width, height)
 
 
 def _score_engine(w, h, n):
@@ -357,6 +472,8 @@ def prednet_predictions(images, model_name, channels, w, h, n_repeat=20, n_ext=2
     import torch
     channels = [int(c) for c in channels]
     images = np.ascontiguousarray(images, dtype=np.uint8)
+    if images.ndim != 4 or images.shape[1:] != (channels[0], h, w):
+        raise ValueError("images must be uint8 [n, %d, %d, %d] (n, C, H, W), got %s" % (channels[0], h, w, images.shape))
     n_steps = n_repeat + n_ext
     eng = get_engine(model_name, w, h, channels, n_repeat=n_repeat, n_ext=n_ext)
     out = np.empty((len(images), n_steps) + images.shape[1:], dtype=np.uint8)
@@ -375,7 +492,7 @@ def flow_vectors(img0, img1, method="lk"):
     (Optical_Flow_Analyzer lucas_kanade; generate_illusion.py:549-550, fitness_calculator.py:498); "farneback": dense
     Farneback flow sampled on a grid."""
     import torch
-    a, b = np.ascontiguousarray(img0, dtype=np.uint8), np.ascontiguousarray(img1, dtype=np.uint8)
+    a, b = np.array(img0, dtype=np.uint8, order="C"), np.array(img1, dtype=np.uint8, order="C")  # writable copies for torch
     if a.shape != b.shape or a.ndim != 3:
         raise ValueError("flow_vectors needs two CHW uint8 images of the same shape, got %s and %s" % (a.shape, b.shape))
     c, h, w = a.shape

@@ -183,6 +183,52 @@ def _flatten_lists(genome, config, n_leaves=2):
     return act, bias, resp, edge_off, edge_src, edge_w, out_node
 
 
+def _marshal_python(genomes):
+    """The genome objects as plain arrays (input of eigen_flatten_genomes) -- the specification of csrc/genome_walk.c."""
+    conn_off, node_off = [0], [0]
+    cin, cout, cw, cen, nkey, nact, nagg, nbias, nresp = [], [], [], [], [], [], [], [], []
+    act_ids = ACT_IDS
+    for g in genomes:
+        cv = list(g.connections.values())
+        keys = [c.key for c in cv]
+        cin += [k[0] for k in keys]; cout += [k[1] for k in keys]
+        cw += [c.weight for c in cv]; cen += [c.enabled for c in cv]
+        conn_off.append(len(cin))
+        nv = list(g.nodes.values())
+        nkey += list(g.nodes.keys())
+        nact += [act_ids.get(n.activation, 255) for n in nv]
+        nagg += [n.aggregation == "sum" for n in nv]
+        nbias += [n.bias for n in nv]; nresp += [n.response for n in nv]
+        node_off.append(len(nkey))
+    a_i32 = lambda x: np.asarray(x, np.int32)
+    return (a_i32(conn_off), a_i32(cin), a_i32(cout), np.asarray(cw, np.float64), np.asarray(cen, np.uint8), a_i32(node_off),
+            a_i32(nkey), np.asarray(nact, np.uint8), np.asarray(nagg, np.uint8), np.asarray(nbias, np.float64), np.asarray(nresp, np.float64))
+
+
+_walker = [None]
+
+
+def _marshal(genomes):
+    """_marshal_python's arrays through the C walker (csrc/genome_walk.c, built by __graft_entry__.build()) when it is there:
+    one call instead of ~28 K Python-level attribute reads per 256 genomes."""
+    if _walker[0] is None:
+        try:
+            from . import _genome_walk
+            _walker[0] = _genome_walk.walk
+        except ImportError:
+            _walker[0] = False
+    if not _walker[0]:
+        return _marshal_python(genomes)
+    G = len(genomes)
+    nc = sum(len(g.connections) for g in genomes)
+    nn = sum(len(g.nodes) for g in genomes)
+    out = (np.empty(G + 1, np.int32), np.empty(nc, np.int32), np.empty(nc, np.int32), np.empty(nc, np.float64), np.empty(nc, np.uint8),
+           np.empty(G + 1, np.int32), np.empty(nn, np.int32), np.empty(nn, np.uint8), np.empty(nn, np.uint8), np.empty(nn, np.float64),
+           np.empty(nn, np.float64))
+    _walker[0](genomes, ACT_IDS, *out)
+    return out
+
+
 class GenomeBatch:
     """Concatenation of flattened genomes = the arrays behind ``eigen_genome_batch``."""
 
@@ -193,6 +239,55 @@ class GenomeBatch:
         if native is not False and genomes and self._init_native(genomes, config, c_out, n_leaves, required=bool(native)):
             return
         self._init_python(genomes, config, c_out, n_leaves)
+
+    _FIELDS = (("node_off", np.int32), ("edge_off", np.int32), ("node_act", np.uint8), ("node_bias", np.float64),
+               ("node_resp", np.float64), ("edge_src", np.int32), ("edge_w", np.float64), ("out_node", np.int32))
+
+    @classmethod
+    def _from_arrays(cls, n_genomes, c_out, arrays):
+        gb = cls.__new__(cls)
+        gb.n_genomes, gb.c_out = int(n_genomes), int(c_out)
+        for (name, dt), a in zip(cls._FIELDS, arrays):
+            setattr(gb, name, np.ascontiguousarray(a, dtype=dt))
+        return gb
+
+    def slice(self, lo, hi):
+        """Genomes [lo, hi) as a batch of their own (offsets rebased): what one rank evaluates of a population that was
+        flattened once (fitness.population_fitness, source "rank0")."""
+        lo, hi = max(0, int(lo)), min(self.n_genomes, int(hi))
+        if lo == 0 and hi == self.n_genomes:
+            return self
+        n0, n1 = int(self.node_off[lo]), int(self.node_off[hi])
+        e0, e1 = int(self.edge_off[n0]), int(self.edge_off[n1])
+        return self._from_arrays(hi - lo, self.c_out, (
+            self.node_off[lo:hi + 1] - n0, self.edge_off[n0:n1 + 1] - e0, self.node_act[n0:n1], self.node_bias[n0:n1],
+            self.node_resp[n0:n1], self.edge_src[e0:e1], self.edge_w[e0:e1], self.out_node[lo * self.c_out:hi * self.c_out]))
+
+    def to_bytes(self):
+        """One flat buffer (int64 header + the eight arrays, each padded to 8 bytes) for the rank-0 -> all broadcast."""
+        arrs = [np.ascontiguousarray(getattr(self, n), dtype=dt) for n, dt in self._FIELDS]
+        head = np.asarray([self.n_genomes, self.c_out] + [a.size for a in arrs], np.int64)
+        parts = [head.tobytes()]
+        for a in arrs:
+            b = a.tobytes()
+            parts.append(b + b"\0" * (-len(b) % 8))
+        return b"".join(parts)
+
+    @classmethod
+    def from_bytes(cls, buf):
+        buf = memoryview(buf).cast("B")
+        nf = len(cls._FIELDS)
+        head = np.frombuffer(buf[:8 * (2 + nf)], np.int64)
+        off, arrs = 8 * (2 + nf), []
+        for (name, dt), n in zip(cls._FIELDS, head[2:]):
+            nb = int(n) * np.dtype(dt).itemsize
+            arrs.append(np.frombuffer(buf[off:off + nb], dt).copy())
+            off += nb + (-nb % 8)
+        return cls._from_arrays(head[0], head[1], arrs)
+
+    def digest(self):
+        import zlib
+        return zlib.crc32(self.to_bytes())
 
     def _init_python(self, genomes, config, c_out, n_leaves):
         node_off, act, bias, resp, edge_off, edge_src, edge_w, out_node = [0], [], [], [], [0], [], [], []
@@ -231,26 +326,8 @@ class GenomeBatch:
         if len(out_keys) < c_out:
             raise ValueError("genome %r has %d outputs, %d are rendered" % (getattr(genomes[0], "key", None), len(out_keys), c_out))
         G, n_out = len(genomes), len(out_keys)
-        conn_off, node_off = [0], [0]
-        cin, cout, cw, cen, nkey, nact, nagg, nbias, nresp = [], [], [], [], [], [], [], [], []
-        act_ids = ACT_IDS
-        for g in genomes:
-            cv = list(g.connections.values())
-            keys = [c.key for c in cv]
-            cin += [k[0] for k in keys]; cout += [k[1] for k in keys]
-            cw += [c.weight for c in cv]; cen += [c.enabled for c in cv]
-            conn_off.append(len(cin))
-            nv = list(g.nodes.values())
-            nkey += list(g.nodes.keys())
-            nact += [act_ids.get(n.activation, 255) for n in nv]
-            nagg += [n.aggregation == "sum" for n in nv]
-            nbias += [n.bias for n in nv]; nresp += [n.response for n in nv]
-            node_off.append(len(nkey))
+        conn_off, cin, cout, cw, cen, node_off, nkey, nact, nagg, nbias, nresp = _marshal(genomes)
         a_i32 = lambda x: np.asarray(x, np.int32)
-        conn_off, node_off = a_i32(conn_off), a_i32(node_off)
-        cin, cout, nkey = a_i32(cin), a_i32(cout), a_i32(nkey)
-        cw, nbias, nresp = np.asarray(cw, np.float64), np.asarray(nbias, np.float64), np.asarray(nresp, np.float64)
-        cen, nact, nagg = np.asarray(cen, np.uint8), np.asarray(nact, np.uint8), np.asarray(nagg, np.uint8)
         ik, ok = a_i32(in_keys), a_i32(out_keys)
         cap_nodes, cap_edges = len(nkey) + G * n_out + 1, len(cin) + len(nkey) + G * n_out + 1
         o_node_off, o_edge_off = np.zeros(G + 1, np.int32), np.zeros(cap_nodes + 1, np.int32)
@@ -272,32 +349,35 @@ class GenomeBatch:
             self.edge_src, self.edge_w = o_src[:ne].copy(), o_w[:ne].copy()
             self.out_node = np.ascontiguousarray(o_out[:, :c_out]).reshape(-1)
             return True
-        # splice: declined genomes come from the Python specification (which also raises for invalid ones)
-        node_off2, act, bias, resp, edge_off2, esrc, ew, outn = [0], [], [], [], [0], [], [], []
+        # splice: declined genomes come from the Python specification (which also raises for invalid ones); runs of
+        # consecutive genomes the library did flatten are copied as one block each
+        act, bias, resp, esrc, ew, eoff, outn, noff = [], [], [], [], [], [np.zeros(1, np.int32)], [], [np.zeros(1, np.int32)]
         n_tot = e_tot = 0
-        for gi, g in enumerate(genomes):
-            if o_status[gi]:
-                a, b, r, eo, es, w_, on = _flatten_lists(g, config, n_leaves)
-                if len(on) < c_out:
-                    raise ValueError("genome %r has %d outputs, %d are rendered" % (getattr(g, "key", None), len(on), c_out))
-                a, b, r = np.asarray(a, np.uint8), np.asarray(b, np.float64), np.asarray(r, np.float64)
-                es, w_ = np.asarray(es, np.int32), np.asarray(w_, np.float64)
-                eo = np.asarray(eo[1:], np.int32)
-                on = np.asarray(on[:c_out], np.int32)
-            else:
-                n0, n1 = int(o_node_off[gi]), int(o_node_off[gi + 1])
+        gi = 0
+        bad = np.flatnonzero(o_status).tolist() + [G]
+        for nxt in bad:
+            if nxt > gi:  # block of genomes gi..nxt-1 straight from the library's arrays
+                n0, n1 = int(o_node_off[gi]), int(o_node_off[nxt])
                 e0, e1 = int(o_edge_off[n0]), int(o_edge_off[n1])
-                a, b, r, es, w_ = o_act[n0:n1], o_bias[n0:n1], o_resp[n0:n1], o_src[e0:e1], o_w[e0:e1]
-                eo = o_edge_off[n0 + 1:n1 + 1] - e0
-                on = o_out[gi, :c_out]
-            act.append(a); bias.append(b); resp.append(r); esrc.append(es); ew.append(w_)
-            edge_off2.append(eo + e_tot)
-            outn.append(on)
-            n_tot += len(a); e_tot += len(es)
-            node_off2.append(n_tot)
+                act.append(o_act[n0:n1]); bias.append(o_bias[n0:n1]); resp.append(o_resp[n0:n1])
+                esrc.append(o_src[e0:e1]); ew.append(o_w[e0:e1])
+                eoff.append(o_edge_off[n0 + 1:n1 + 1] - e0 + e_tot)
+                noff.append(o_node_off[gi + 1:nxt + 1] - n0 + n_tot)
+                outn.append(o_out[gi:nxt, :c_out].reshape(-1))
+                n_tot += n1 - n0; e_tot += e1 - e0
+            if nxt < G:
+                a_, b_, r_, eo, es, w_, on = _flatten_lists(genomes[nxt], config, n_leaves)
+                if len(on) < c_out:
+                    raise ValueError("genome %r has %d outputs, %d are rendered" % (getattr(genomes[nxt], "key", None), len(on), c_out))
+                act.append(np.asarray(a_, np.uint8)); bias.append(np.asarray(b_, np.float64)); resp.append(np.asarray(r_, np.float64))
+                esrc.append(np.asarray(es, np.int32)); ew.append(np.asarray(w_, np.float64))
+                eoff.append(np.asarray(eo[1:], np.int32) + e_tot)
+                outn.append(np.asarray(on[:c_out], np.int32))
+                n_tot += len(a_); e_tot += len(es)
+                noff.append(np.asarray([n_tot], np.int32))
+            gi = nxt + 1
         cat = lambda xs, dt: np.ascontiguousarray(np.concatenate(xs).astype(dt, copy=False)) if xs else np.zeros(0, dt)
-        self.node_off = np.asarray(node_off2, np.int32)
-        self.edge_off = cat([np.zeros(1, np.int32)] + edge_off2[1:], np.int32)
+        self.node_off, self.edge_off = cat(noff, np.int32), cat(eoff, np.int32)
         self.node_act, self.node_bias, self.node_resp = cat(act, np.uint8), cat(bias, np.float64), cat(resp, np.float64)
         self.edge_src, self.edge_w = cat(esrc, np.int32), cat(ew, np.float64)
         self.out_node = cat(outn, np.int32)

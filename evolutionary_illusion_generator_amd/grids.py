@@ -3,7 +3,7 @@
 Product-side counterpart of ``create_grid`` / ``fill_circle`` (/root/reference/generate_illusion.py:196-317, 38-117).
 The grid is shared by every genome of every generation (generate_illusion.py:501), so it is not on the per-genome
 critical path; it is built with numpy in the same float64 operation order as the reference's scalar loops, which
-makes it bit-identical to them (tests/test_grids.py checks against fixtures produced by the reference itself).
+makes it bit-identical to them (tests/test_oracle_golden.py checks against fixtures produced by the reference itself).
 
 Deviations: Bands planes are returned as (H, W) -- the reference returns (1, H*W, 1)
 arrays that its own renderer cannot index -- and sizes with W % 10 != 0 or H % 4 != 0, where the reference
@@ -36,8 +36,10 @@ def _polar(x, y):
     return np.where(x < 0, theta + math.pi, theta)
 
 
-def ring_grid(x, y, max_radius, direction=1, circles_free=False):
-    """Vectorised fill_circle: x, y are float64 arrays of offsets from the circle centre -> (r, theta)."""
+def ring_grid(x, y, max_radius, direction=1, circles_free=False, no_theta=False):
+    """Vectorised fill_circle: x, y are float64 arrays of offsets from the circle centre -> (r, theta).
+    no_theta: fill_circle called with a structure that is neither Circles nor CirclesFree (generate_illusion.py:69-105 has no
+    branch for Bands / Free, so theta keeps its initial 0 while r is still the ring coordinate)."""
     edges = _ring_edges()
     r_total = np.sqrt(x * x + y * y)
     inside = r_total <= max_radius / 2
@@ -60,6 +62,8 @@ def ring_grid(x, y, max_radius, direction=1, circles_free=False):
     if direction < 0:
         theta = (math.pi / 6.0) - theta
     blank = (r > 0.9) | (r < 0.1) | (~inside)
+    if no_theta:
+        return np.where(blank, -1.0, r / 0.8), np.zeros(x.shape)
     return np.where(blank, -1.0, r / 0.8), np.where(blank, 0.0, theta)
 
 
@@ -109,6 +113,7 @@ def create_grid(structure, x_res=32, y_res=32, scaling=1.0):
 def enhanced_image_grid(x_res, y_res, structure):
     """3x3 circles plus 2x2 overlaid circles with alternating direction (generate_illusion.py:121-193)."""
     free = int(structure) == StructureType.CirclesFree
+    flat = int(structure) not in (StructureType.Circles, StructureType.CirclesFree)  # Bands / Free: theta stays 0
     y_step, x_step = int(y_res / 3), int(x_res / 3)
     x_mat = np.ones((y_res, x_res)) * -1
     y_mat = np.ones((y_res, x_res)) * -1
@@ -121,7 +126,7 @@ def enhanced_image_grid(x_res, y_res, structure):
             rx = col * x_step + np.arange(x_step)
             ry = row * y_step + np.arange(y_step)
             gx, gy = np.meshgrid(rx, ry)
-            r, t = ring_grid(gx - centers[index][0], gy - centers[index][1], y_step, direction, free)
+            r, t = ring_grid(gx - centers[index][0], gy - centers[index][1], y_step, direction, free, flat)
             x_mat[np.ix_(ry, rx)] = r
             y_mat[np.ix_(ry, rx)] = t
     for row in range(2):
@@ -132,7 +137,7 @@ def enhanced_image_grid(x_res, y_res, structure):
             ry = row * y_step + np.arange(y_step) + int(y_step / 2)
             gx, gy = np.meshgrid(rx, ry)
             x, y = gx - centers[index][0], gy - centers[index][1]
-            r, t = ring_grid(x, y, y_step, direction, free)
+            r, t = ring_grid(x, y, y_step, direction, free, flat)
             m = np.sqrt(x * x + y * y) < x_step / 2
             sub_x, sub_y = x_mat[np.ix_(ry, rx)], y_mat[np.ix_(ry, rx)]
             x_mat[np.ix_(ry, rx)] = np.where(m, r, sub_x)

@@ -298,13 +298,17 @@ class Population:
         self._next_genome, self._next_species = 1, 1
         self.species = {}
         self.best_genome = None
+        self._fresh_population()
+        self._speciate()
+
+    def _fresh_population(self):
+        """pop_size new genomes from the population's OWN random stream (also the restart after a complete extinction)."""
         self.population = {}
-        for _ in range(config.pop_size):
-            g = config.genome_type(self._next_genome)
-            g.configure_new(config.genome_config, self.rng)
+        for _ in range(self.config.pop_size):
+            g = self.config.genome_type(self._next_genome)
+            g.configure_new(self.config.genome_config, self.rng)
             self.population[g.key] = g
             self._next_genome += 1
-        self._speciate()
 
     def add_reporter(self, r):
         self.reporters.append(r)
@@ -389,6 +393,10 @@ class Population:
             for g in self.population.values():
                 if g.fitness is None:
                     raise RuntimeError("Fitness not assigned to genome %d" % g.key)
+                if g.fitness != g.fitness or g.fitness in (float("inf"), float("-inf")):
+                    # the reference's scorers return NaN for zero-length vectors; NaN makes max()/sorted()
+                    # order-dependent, so rank such genomes below everything finite
+                    g.fitness = -1e300 if g.fitness != float("inf") else 1e300
             best = max(self.population.values(), key=lambda g: g.fitness)
             if self.best_genome is None or best.fitness > self.best_genome.fitness:
                 self.best_genome = best
@@ -402,7 +410,10 @@ class Population:
             if not self.species:
                 if not self.config.reset_on_extinction:
                     raise RuntimeError("complete extinction")
-                self.__init__(self.config)
+                # neat-python's reset_on_extinction: a new random population; reporters, generation counter, best genome and
+                # the seeded random stream are kept (re-running __init__ dropped the reporters and reseeded from the clock)
+                self.species = {}
+                self._fresh_population()
             self._speciate()
             for r in self.reporters:
                 r.end_generation(self.config, self.population, self.species, self.generation, self)

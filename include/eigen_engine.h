@@ -39,6 +39,10 @@ typedef enum {
 
 /* StructureType of the reference (generate_illusion.py:25-29, fitness_calculator.py:10-14) */
 typedef enum { EIGEN_BANDS = 0, EIGEN_CIRCLES = 1, EIGEN_FREE = 2, EIGEN_CIRCLES_FREE = 3 } eigen_structure;
+/* eigen_score only: inside_outside_score(vectors, width, height) (fitness_calculator.py:219-304) on ALL the given vectors.
+ * The reference reaches it only through an else branch that raises NameError (generate_illusion.py:606-607,
+ * fitness_calculator.py:545-546), so no structure selects it on the population path. */
+#define EIGEN_SCORE_INSIDE_OUTSIDE 4
 
 /* Which two frames Lucas-Kanade compares:
  *   POPULATION: prediction after step n_repeat -> first extension frame   (generate_illusion.py:543-550)
@@ -162,7 +166,8 @@ int eigen_flow(eigen_engine* e, const uint8_t* d_img0, int64_t stride0, const ui
 
 /* Replaces the scoring block of get_fitnesses_neat (generate_illusion.py:559-616; scorers
  * fitness_calculator.py:18-215).  count == 0 -> the sentinel [[0,0,-1000,0]] -> fitness 0.
- * width/height: the image size the scorers are given (w, h); 0 = the engine's own size. */
+ * width/height: the image size the scorers are given (w, h); 0 = the engine's own size.
+ * structure EIGEN_SCORE_INSIDE_OUTSIDE: inside_outside_score of the raw vectors (no filter, no sentinel). */
 int eigen_score(eigen_engine* e, int32_t structure, int32_t width, int32_t height, const float* d_vectors,
                 const int32_t* d_counts, int32_t batch, double* d_fitness, void* stream);
 

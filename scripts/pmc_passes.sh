@@ -17,4 +17,5 @@ run sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_AN
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM TCC_HIT_sum TCC_MISS_sum
-ls -R $OUT | head -30
+python $R/scripts/summarize_pmc.py $OUT $OUT/pmc_summary.json $POP > $OUT/summary.txt 2>&1
+tail -12 $OUT/summary.txt

@@ -7,7 +7,10 @@ loads are all 16 B/lane DMA, so the read side is doubled; WRITE_SIZE is used as 
 import collections
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def main(d, out, pop):
@@ -24,7 +27,10 @@ def main(d, out, pop):
     for r in csv.DictReader(open("%s/sq/sq_kernel_trace.csv" % d)):
         calls[r["Kernel_Name"]] += 1
         dur[r["Kernel_Name"]] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6
-    res = {"pop": pop, "kernels": {}}
+    # stamp: bench.py reports `roofline.traffic` from this file only when the kernel sources are the ones it runs on
+    import bench
+    res = {"pop": pop, "kernel_sources_sha": bench.kernel_sources_sha(),
+           "commit": os.environ.get("EIGEN_COMMIT") or bench.git_head(), "kernels": {}}
     for k in sorted(agg, key=lambda x: -dur[x])[:8]:
         v = agg[k]
         n = max(calls[k], 1)

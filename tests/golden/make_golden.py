@@ -209,7 +209,7 @@ def main():
     print("golden fixtures written to", OUT)
 
 
-if __name__ == "__main__" and "--e2e" not in sys.argv:
+if __name__ == "__main__" and "--e2e" not in sys.argv and "--round2" not in sys.argv:
     main()
 
 
@@ -331,3 +331,50 @@ def make_e2e():
 
 if __name__ == "__main__" and "--e2e" in sys.argv:
     make_e2e()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# Round-2 additions, in files of their own so that the fixtures above keep their bytes (separate random stream):
+#   grids at 256x256 (SURVEY 8(c) lists "64^2, 160x120, 256^2"), enhanced_image_grid for structures without a theta branch,
+#   inside_outside_score (fitness_calculator.py:219-304, a12).
+def make_round2():
+    state = {}
+    install_stubs(state)
+    sys.path.insert(0, REF)
+    import fitness_calculator as fc
+    import generate_illusion as gi
+    rng = np.random.default_rng(20260929)
+    import hashlib
+    grids, grid_sha = {}, {}
+    # full-size grids: the SHA-256 of the float64 bytes pins every value; every 16th row is kept for diagnosis (the full
+    # 256x256 ring planes are ~1 MB of incompressible doubles)
+    for name, st, w, h in [("circles_256x256", gi.StructureType.Circles, 256, 256), ("free_256x256", gi.StructureType.Free, 256, 256),
+                           ("circlesfree_256x256", gi.StructureType.CirclesFree, 256, 256), ("free_512x512", gi.StructureType.Free, 512, 512)]:
+        g = gi.create_grid(st, w, h, 10)
+        for ax in ("x", "y"):
+            a = np.ascontiguousarray(np.asarray(g[ax + "_mat"], dtype=np.float64).reshape(h, w))
+            grid_sha[name + "_" + ax] = hashlib.sha256(a.tobytes()).hexdigest()
+            grids[name + "_" + ax + "_rows16"] = a[::16]
+    for name, st in [("bands", gi.StructureType.Bands), ("free", gi.StructureType.Free), ("circlesfree", gi.StructureType.CirclesFree)]:
+        eg = gi.enhanced_image_grid(120, 120, st)
+        grids["enhanced_%s_120x120_x" % name] = eg["x_mat"]
+        grids["enhanced_%s_120x120_y" % name] = eg["y_mat"]
+    np.savez_compressed(os.path.join(OUT, "grids_round2.npz"), **grids)
+    cases = []
+    for (w, h), n, mag in [((160, 120), 40, 0.1), ((160, 120), 3, 0.2), ((256, 256), 100, 0.15), ((256, 256), 60, 0.3), ((512, 512), 75, 0.05),
+                           ((96, 64), 12, 0.4), ((160, 120), 0, 0.1), ((64, 64), 25, 1.5)]:
+        v = vec_set(rng, n, w, h, mag) if n else np.zeros((0, 4))
+        if n > 5:
+            v[3, 2:] = 0.0                      # a zero-length vector
+            v[4, :2] = v[5, :2]                 # two vectors in the same cell, same position
+        cases.append({"w": w, "h": h, "vectors": v.tolist(), "score": float(fc.inside_outside_score(v, w, h))})
+    ang = np.linspace(0, 2 * np.pi, 48, endpoint=False)
+    rot = np.stack([128 + 100 * np.cos(ang), 128 + 100 * np.sin(ang), -0.2 * np.sin(ang), 0.2 * np.cos(ang)], 1)
+    cases.append({"w": 256, "h": 256, "vectors": rot.tolist(), "score": float(fc.inside_outside_score(rot, 256, 256))})
+    with open(os.path.join(OUT, "round2.json"), "w") as f:
+        json.dump({"inside_outside": cases, "grid_sha256": grid_sha}, f)
+    print("round-2 fixtures written:", [round(c["score"], 6) for c in cases])
+
+
+if __name__ == "__main__" and "--round2" in sys.argv:
+    make_round2()

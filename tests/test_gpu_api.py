@@ -14,8 +14,8 @@ from evolutionary_illusion_generator_amd import fitness, grids, synth, weights
 
 
 def _oracle_fitness(pop, cfg, wts, ch, w, h, structure, pairing=0):
-    from oracle import pipeline
-    grid = grids.create_grid(structure, w, h, 10)
+    from oracle import grids as ogrids, pipeline
+    grid = ogrids.create_grid(structure, w, h, 10)  # the ORACLE's grid: the two sides share no code
     return np.array([pipeline.genome_fitness(g, cfg, grid, wts, ch, w, h, structure, pairing=pairing) for _, g in pop])
 
 
@@ -36,7 +36,8 @@ def test_get_fitnesses_neat_drop_in(cuda, oracle_lib, tmp_path, structure, w, h,
     from PIL import Image
     from oracle import pipeline
     best = max(range(len(pop)), key=lambda i: (got[i], i))
-    grid = grids.create_grid(structure, w, h, 10)
+    from oracle import grids as ogrids
+    grid = ogrids.create_grid(structure, w, h, 10)
     for name, bg in (("best.png", 1), ("best_black_bg.png", 0)):
         img = np.asarray(Image.open(tmp_path / name))
         exp = pipeline.render_chw(pop[best][1], cfg, grid, c_dim, w, h, bg=bg)
@@ -69,7 +70,8 @@ def test_get_vectors_and_calculate_fitness_single_image_api(cuda, oracle_lib, tm
     cfg = synth.make_config(2, 3)
     pop = synth.make_population(3, cfg, seed=8)
     wts = weights.synthetic_prednet_weights(ch, w, h, seed=4)
-    grid = grids.create_grid(structure, w, h, 10)
+    from oracle import grids as ogrids
+    grid = ogrids.create_grid(structure, w, h, 10)
     for i, (_, g) in enumerate(pop):
         img = pipeline.render_chw(g, cfg, grid, 3, w, h)
         path = str(tmp_path / ("img%d.png" % i))

@@ -1,0 +1,288 @@
+"""GPU (round 2): the north-star parity claim on the box, BASELINE.json configs[3] / configs[4] end to end, a12, RCCL.
+
+* HIP fitness against an INDEPENDENTLY ORDERED fp32 PredNet (torch-CPU / oneDNN, oracle/prednet_torch.py: library
+  convolutions, library sigmoid/tanh, plain unpool -> 9-tap conv) within north_star's 1e-4 relative, with the uint8
+  frame flip rate printed.  The bit-exact tests elsewhere prove "kernel == the build's canonical arithmetic"; this one
+  bounds what the choice of that arithmetic is worth.
+* configs[3]: neat_configs/bands.txt (num_hidden 8, num_outputs 6 -> first 3; bands.txt:48-51), Bands grid at 256x256
+  colour (build-defined generalisation), horizontal_symmetry_score.
+* configs[4]: neat_configs/free.txt (num_hidden 20, num_outputs 6; free.txt:48-50), 512x512 colour, Free grid
+  (generate_illusion.py:308-315), full 21-step roll-out + LK + swarm_score.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from evolutionary_illusion_generator_amd import fitness, genome as genome_mod, synth, weights
+from evolutionary_illusion_generator_amd.engine import Engine
+
+
+def _independent_order_check(cuda, w, h, ch, structure, n_pop, seed, want_nonzero, extra_zero=1):
+    """-> (rel errors of the non-zero genomes, flip rate of the two frames LK reads)."""
+    import torch
+    import oracle
+    from oracle import grids as ogrids, pipeline, scores
+    from oracle.prednet_torch import PredNetTorch
+    c_dim = ch[0]
+    cfg = synth.make_config(2, 3 if c_dim == 3 else 1)
+    pop = synth.make_population(n_pop, cfg, seed=seed)
+    genomes = [g for _, g in pop]
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=0)
+    grid = ogrids.create_grid(structure, w, h, 10)
+    e = Engine(w, h, ch, n_pop)
+    e.set_weights(wts)
+    e.set_grid([grid["x_mat"], grid["y_mat"]])
+    gb = genome_mod.GenomeBatch(genomes, cfg, c_dim)
+    hip = e.eval_population(gb, structure)
+    d_img = torch.zeros((n_pop, c_dim, h, w), dtype=torch.uint8, device=cuda)
+    e.render_cppn(gb, d_img)
+    d_fr = torch.zeros((n_pop, 2, c_dim, h, w), dtype=torch.uint8, device=cuda)
+    e.prednet_rollout(d_img, n_pop, 21, 19, d_fr)
+    torch.cuda.synchronize()
+    imgs, frames = d_img.cpu().numpy(), d_fr.cpu().numpy()
+    nz = [i for i in range(n_pop) if hip[i] != 0][:want_nonzero]
+    zero = [i for i in range(n_pop) if hip[i] == 0][:extra_zero]
+    assert len(nz) >= want_nonzero, "only %d non-zero genomes of %d: vacuous" % (len(nz), n_pop)
+    net = PredNetTorch(wts, ch, w, h)
+    rels, flips, nbytes = [], 0, 0
+    for i in nz + zero:
+        assert np.array_equal(imgs[i], pipeline.render_chw(genomes[i], cfg, grid, c_dim, w, h))  # same stimulus on both sides
+        fr, _ = net.rollout(imgs[i][None], n_repeat=20, n_ext=1)
+        flips += int((fr[0, 19] != frames[i, 0]).sum() + (fr[0, 20] != frames[i, 1]).sum())
+        nbytes += 2 * frames[i, 0].size
+        assert np.abs(fr[0, 19].astype(int) - frames[i, 0]).max() <= 1 and np.abs(fr[0, 20].astype(int) - frames[i, 1]).max() <= 1
+        v = oracle.lucas_kanade(fr[0, 19], fr[0, 20])
+        ref = scores.fitness_from_vectors(structure, v.astype(np.float64), w, h)
+        if hip[i] == 0 or ref == 0:
+            assert hip[i] == ref, (i, hip[i], ref)
+        else:
+            rels.append(abs(hip[i] - ref) / abs(ref))
+    return np.asarray(rels), flips / float(nbytes), torch.get_num_threads()
+
+
+def test_hip_fitness_vs_independently_ordered_prednet_c2(cuda, oracle_lib):
+    """BASELINE.json configs[1]: circles_bw, 160x120 gray, channels 1,16,32,64 -- >= 8 non-zero genomes within 1e-4."""
+    rels, flip, thr = _independent_order_check(cuda, 160, 120, [1, 16, 32, 64], 1, n_pop=40, seed=0, want_nonzero=8, extra_zero=2)
+    print("\nC2 160x120 gray: %d non-zero genomes, max rel %.3g, median %.3g; uint8 frame flip rate %.3g (torch-CPU %d threads)"
+          % (len(rels), rels.max(), np.median(rels), flip, thr))
+    assert len(rels) >= 8
+    assert rels.max() <= 1e-4, rels  # north_star: "within 1e-4 relative"
+    assert flip < 1e-3
+
+
+def test_hip_fitness_vs_independently_ordered_prednet_c3(cuda, oracle_lib):
+    """BASELINE.json configs[2], the headline shape: circles.txt colour, 256x256, channels 3,48,96,192 -- >= 4 non-zero genomes."""
+    rels, flip, thr = _independent_order_check(cuda, 256, 256, [3, 48, 96, 192], 1, n_pop=12, seed=0, want_nonzero=4, extra_zero=1)
+    print("\nC3 256x256 colour: %d non-zero genomes, max rel %.3g, median %.3g; uint8 frame flip rate %.3g (torch-CPU %d threads)"
+          % (len(rels), rels.max(), np.median(rels), flip, thr))
+    assert len(rels) >= 4
+    assert rels.max() <= 1e-4, rels
+    assert flip < 1e-3
+
+
+def test_config3_bands_256_colour_end_to_end(cuda, oracle_lib):
+    """configs[3]: bands.txt genomes (8 hidden, 6 outputs -> the first 3 are rendered) on the Bands grid at 256x256
+    (the reference raises there: build-defined generalisation, restated independently in oracle/grids.py), PredNet
+    3,48,96,192, horizontal_symmetry_score.  Two genomes against the bit-exact C oracle (~20 s each); 64 through the
+    size-independent properties."""
+    import torch
+    from oracle import grids as ogrids, pipeline
+    w, h, ch, structure = 256, 256, [3, 48, 96, 192], 0
+    cfg = synth.make_config(2, 6)
+    pop = synth.make_population(64, cfg, seed=3, num_hidden=8)
+    genomes = [g for _, g in pop]
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=0)
+    grid = ogrids.create_grid(structure, w, h, 10, generalised=True)
+    got = fitness.evaluate_population(structure, genomes, wts, cfg, w, h, ch, c_dim=3, gradient=1, max_batch=64)
+    assert np.isfinite(got).all() and (got != 0).sum() >= 8, got
+    # batch-size / batch-position invariance and determinism: reversed order in smaller device batches, bit for bit
+    rev = fitness.evaluate_population(structure, genomes[::-1], wts, cfg, w, h, ch, c_dim=3, gradient=1, max_batch=24)
+    assert np.array_equal(rev[::-1], got)
+    # renders of all 64 byte-exact vs the oracle (6-output genomes: first three outputs)
+    imgs = fitness.render_images(structure, genomes, wts, cfg, w, h, ch, c_dim=3, gradient=1, max_batch=64)
+    ref_imgs = np.stack([pipeline.render_chw(g, cfg, grid, 3, w, h) for g in genomes])
+    assert np.array_equal(imgs, ref_imgs)
+    nz = [i for i in range(64) if got[i] != 0]
+    for i in nz[:2]:
+        ref = pipeline.image_fitness(ref_imgs[i], wts, ch, w, h, structure)
+        assert ref != 0 and got[i] == pytest.approx(ref, rel=1e-9, abs=1e-12), (i, got[i], ref)
+
+
+def test_config4_free_512_colour_end_to_end(cuda, oracle_lib):
+    """configs[4]: free.txt genomes (20 hidden, 6 outputs -> first 3) on the Free grid at 512x512 colour: HIP render
+    byte-exact, FULL 21-step roll-out + Lucas-Kanade + swarm_score of one genome against the C oracle (~1.5 min of CPU),
+    properties for the rest."""
+    import torch
+    from oracle import grids as ogrids, pipeline
+    w, h, ch, structure = 512, 512, [3, 48, 96, 192], 2
+    cfg = synth.make_config(2, 6)
+    pop = synth.make_population(6, cfg, seed=4, num_hidden=20)
+    genomes = [g for _, g in pop]
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=1)
+    grid = ogrids.create_grid(structure, w, h, 10)
+    batch = genomes + [genomes[1], genomes[0]]
+    got = fitness.evaluate_population(structure, batch, wts, cfg, w, h, ch, c_dim=3, gradient=1, max_batch=8)
+    assert got[6] == got[1] and got[7] == got[0] and np.isfinite(got).all()
+    again = fitness.evaluate_population(structure, genomes[:3], wts, cfg, w, h, ch, c_dim=3, gradient=1, max_batch=8)
+    assert np.array_equal(again, got[:3])
+    imgs = fitness.render_images(structure, genomes, wts, cfg, w, h, ch, c_dim=3, gradient=1, max_batch=8)
+    ref_imgs = np.stack([pipeline.render_chw(g, cfg, grid, 3, w, h) for g in genomes])
+    assert np.array_equal(imgs, ref_imgs)
+    nz = [i for i in range(6) if got[i] != 0]
+    assert nz, "all six genomes scored 0: vacuous"
+    i = nz[0]
+    ref = pipeline.image_fitness(ref_imgs[i], wts, ch, w, h, structure)
+    assert ref != 0 and got[i] == pytest.approx(ref, rel=1e-9, abs=1e-12), (i, got[i], ref)
+
+
+def test_inside_outside_score_on_the_device(cuda):
+    """a12: fitness_calculator.inside_outside_score (:219-304) -- device scorer against the reference-generated fixture
+    (vectors rounded to the float32 the flow stage produces, re-scored by the oracle's restatement) and raw against it."""
+    import json
+    from oracle import scores
+    cases = json.load(open(os.path.join(ROOT, "tests", "golden", "round2.json")))["inside_outside"]
+    nz = 0
+    for c in cases:
+        v = np.asarray(c["vectors"], dtype=np.float64).reshape(-1, 4)
+        v32 = v.astype(np.float32).astype(np.float64)
+        got = fitness.inside_outside_score(v32, c["w"], c["h"])
+        ref = float(scores.inside_outside_score(v32, c["w"], c["h"]))
+        assert got == pytest.approx(ref, rel=1e-9, abs=1e-12), (c["w"], c["h"], len(v), got, ref)
+        assert got == pytest.approx(c["score"], rel=1e-5, abs=1e-7)  # float32 rounding of dx, dy only
+        nz += got != 0
+    assert nz >= 7
+    with pytest.raises(NameError):   # the reference's own behaviour for an unknown structure is kept
+        fitness.calculate_fitness(4, np.zeros((3, 4)), "x.png", 160, 120)
+
+
+def test_best_flow_vectors_are_the_oracles(cuda, oracle_lib, tmp_path):
+    """best_flow.png is an overlay of the flow the fitness used (generate_illusion.py:655-657 copies the LK visualisation):
+    the vectors behind it (saved next to it) are the oracle's, bit for bit, and the overlay marks every one of them."""
+    from PIL import Image
+    from oracle import grids as ogrids, pipeline
+    w, h, ch, structure = 96, 64, [3, 12, 24, 48], 1
+    cfg = synth.make_config(2, 3)
+    pop = synth.make_population(9, cfg, seed=31)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=2)
+    fitness.get_fitnesses_neat(structure, pop, wts, cfg, w, h, ch, c_dim=3, best_dir=str(tmp_path), gradient=1)
+    got = np.array([g.fitness for _, g in pop])
+    best = max(range(len(pop)), key=lambda i: (got[i], i))
+    grid = ogrids.create_grid(structure, w, h, 10)
+    img = pipeline.render_chw(pop[best][1], cfg, grid, 3, w, h)
+    ref_v = pipeline.image_vectors(img, wts, ch, w, h)
+    v = np.load(tmp_path / "best_flow_vectors.npy")
+    assert v.shape == ref_v.shape and np.array_equal(v, ref_v) and len(v) > 0
+    overlay = np.asarray(Image.open(tmp_path / "best_flow.png").convert("RGB")).astype(int)
+    base = img.transpose(1, 2, 0).astype(int)
+    for x, y, dx, dy in v:   # a yellow dot at every tracked corner
+        px = overlay[int(round(y)), int(round(x))]
+        assert tuple(px) == (255, 255, 0), (x, y, px)
+    assert (overlay != base).any(axis=2).sum() >= len(v)
+    # enhanced.png is written for every structure (generate_illusion.py:665-671)
+    for st in (0, 2):
+        sub = tmp_path / ("s%d" % st)
+        fitness.get_fitnesses_neat(st, pop, wts, cfg, w, h, ch, c_dim=3, best_dir=str(sub), gradient=1)
+        assert Image.open(sub / "enhanced.png").size == (800, 800)
+
+
+def test_engine_cache_does_not_reload_weights(cuda, tmp_path, monkeypatch):
+    """get_engine resolved (re-read / re-generated) the weight set on every call, even on a cache hit."""
+    calls = []
+    real = fitness.synthetic_prednet_weights
+    monkeypatch.setattr(fitness, "synthetic_prednet_weights", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    fitness.clear_engines()
+    cfg = synth.make_config(2, 1)
+    pop = synth.make_population(3, cfg, seed=1)
+    for _ in range(3):
+        fitness.get_fitnesses_neat(2, pop, "synthetic:5", cfg, 64, 64, [1, 4, 8], c_dim=1, best_dir=str(tmp_path))
+    assert len(calls) == 1
+    with pytest.raises(ValueError):
+        fitness.get_vectors(np.zeros((20, 20), np.uint8), "synthetic:5", [1, 4, 8], 64, 64)   # smaller than the engine: refused on the host
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _nccl_worker(rank, world, port, q, source):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from evolutionary_illusion_generator_amd import fitness as F, synth as S, weights as W
+    F.GENOME_SOURCE = source
+    w, h, ch = 64, 64, [1, 8, 16]
+    cfg = S.make_config(2, 1)
+    pop = S.make_population(7, cfg, seed=12)
+    wts = W.synthetic_prednet_weights(ch, w, h, seed=6)
+    F.get_fitnesses_neat(2, pop, wts, cfg, w, h, ch, c_dim=1, best_dir=None)
+    q.put((rank, [g.fitness for _, g in pop], dist.get_backend()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("source", ["rank0", "replicated"])
+def test_two_ranks_over_rccl(cuda, oracle_lib, source):
+    """One rank per GPU on the `nccl` (= RCCL) backend: broadcast of the genome wire arrays + all-gather of the fitness
+    scalars on device tensors.  Needs two GPUs; the single-GPU boxes of the test tier skip it (the gloo twin runs there)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (have %d)" % torch.cuda.device_count())
+    import torch.multiprocessing as mp
+    from oracle import grids as ogrids, pipeline
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nccl_worker, args=(r, 2, port, q, source)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r: (f, b) for r, f, b in (q.get(timeout=600) for _ in procs)}
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    w, h, ch = 64, 64, [1, 8, 16]
+    cfg = synth.make_config(2, 1)
+    pop = synth.make_population(7, cfg, seed=12)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=6)
+    grid = ogrids.create_grid(2, w, h, 10)
+    ref = np.array([pipeline.genome_fitness(g, cfg, grid, wts, ch, w, h, 2) for _, g in pop])
+    assert res[0][1] == res[1][1] == "nccl"
+    assert res[0][0] == res[1][0]
+    assert np.allclose(res[0][0], ref, rtol=1e-9, atol=1e-12)
+
+
+def test_bench_gpus_flag_launches_ranks(cuda):
+    """`python bench.py --gpus N` must BE N ranks (the flag was parsed and dropped).  On a 1-GPU box: N = 1 prints
+    n_gpus 1 and N = 2 refuses loudly instead of silently running one rank."""
+    import json
+    import subprocess
+    import torch
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    small = ["--shape", "c2", "--pop", "8", "--steps", "1", "--warmup", "1", "--no-roofline", "--no-cpu-baseline"]
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["config"]["global_pop"] == 8 and line["scaling"] == "strong" and line["value"] > 0
+    n = 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + small, env=env, capture_output=True, text=True, timeout=900)
+    if torch.cuda.device_count() >= n:
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        assert line["n_gpus"] == n and line["config"]["genomes_per_gpu"] == 4 and "RCCL" in line["config"]["parallelism"]
+    else:
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
+    # joined under a launcher with the wrong world size: refuse
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, env=env2, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

@@ -161,6 +161,66 @@ def test_native_flattening_is_the_python_specification():
                 genome.GenomeBatch([cyc], cfg, 1, native=native)
 
 
+def test_c_genome_walker_is_the_python_marshalling():
+    """csrc/genome_walk.c (CPython extension) against genome._marshal_python: identical arrays for the synthetic duck-typed
+    genomes, neat_lite genomes after a few generations of mutation, gene classes with __slots__ / properties (the generic
+    attribute protocol), large keys, and the exceptions of malformed genomes."""
+    import __graft_entry__ as ge
+    ge.build()
+    from evolutionary_illusion_generator_amd import _genome_walk, genome, synth  # noqa: F401  (must be built)
+    genome._walker[0] = None
+
+    def same(gs):
+        a, b = genome._marshal_python(gs), genome._marshal(gs)
+        assert genome._walker[0] is _genome_walk.walk
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y)
+
+    cfg = synth.make_config(2, 3)
+    same([g for _, g in synth.make_population(64, cfg, seed=11, num_hidden=20)])
+    same([])
+    from evolutionary_illusion_generator_amd import neat_lite
+    ncfg = neat_lite.Config(neat_lite.DefaultGenome, neat_lite.DefaultReproduction, neat_lite.DefaultSpeciesSet, neat_lite.DefaultStagnation,
+                            os.path.join(ROOT, "examples", "circles_neat.cfg"))
+    p = neat_lite.Population(ncfg, seed=3)
+
+    def fake_fitness(genomes, config):
+        for i, (_, g) in enumerate(genomes):
+            g.fitness = (i * 37 % 11) / 11.0
+    p.run(fake_fitness, 4)
+    same(list(p.population.values()))
+
+    class SlotConn:
+        __slots__ = ("key", "weight", "enabled")
+
+        def __init__(self, key, weight, enabled):
+            self.key, self.weight, self.enabled = key, weight, enabled
+
+    class PropNode:
+        def __init__(self, b):
+            self._b = b
+            self.response, self.activation, self.aggregation = 1.5, "gauss", "product"
+
+        @property
+        def bias(self):
+            return self._b
+
+    g = synth.Genome(1)
+    g.connections = {(-1, 5 + (1 << 21)): SlotConn((-1, 5 + (1 << 21)), 0.25, True), (5 + (1 << 21), 0): SlotConn((5 + (1 << 21), 0), -1, 0)}
+    g.nodes = {0: PropNode(0.5), 5 + (1 << 21): PropNode(-2)}
+    same([g])
+    arrays = genome._marshal([g])
+    assert arrays[3].tolist() == [0.25, -1.0] and arrays[4].tolist() == [1, 0] and arrays[8].tolist() == [0, 0] and arrays[7].tolist() == [3, 3]
+    bad = synth.Genome(2)
+    bad.connections = {(-1, 0): SlotConn((-1, 0), "heavy", True)}
+    bad.nodes = {}
+    with pytest.raises(TypeError):
+        genome._marshal([bad])
+    del bad.connections
+    with pytest.raises(AttributeError):
+        genome._marshal([bad])
+
+
 def test_weights_tables(tmp_path):
     from evolutionary_illusion_generator_amd import weights
     import oracle
@@ -194,51 +254,113 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _gloo_worker(rank, world, port, q):
+def _fake_fitness_of_batch(gb):
+    """Stand-in for the device pass: a deterministic function of each flattened genome (sum of its edge weights)."""
+    out = np.zeros(gb.n_genomes)
+    for g in range(gb.n_genomes):
+        e0, e1 = gb.edge_off[gb.node_off[g]], gb.edge_off[gb.node_off[g + 1]]
+        out[g] = float(np.sum(gb.edge_w[e0:e1]))
+    return out
+
+
+def _gloo_worker(rank, world, port, q, source, diverged):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from evolutionary_illusion_generator_amd import fitness, synth
+    from evolutionary_illusion_generator_amd import fitness, genome, synth
+    fitness.GENOME_SOURCE = source
     calls = []
 
-    def fake_eval(structure, genomes, *a, **k):  # stands in for the device pass: fitness = f(genome key)
-        calls.append([g.key for g in genomes])
-        return np.array([g.key * 0.125 for g in genomes])
+    def fake_batch(structure, gb, n_in, *a, **k):  # what evaluate_batch would run on the device
+        calls.append(gb.n_genomes)
+        return _fake_fitness_of_batch(gb)
 
+    def fake_eval(structure, genomes, model, config, *a, **k):
+        return fake_batch(structure, genome.GenomeBatch(genomes, config, 1, n_leaves=2, native=False), 2)
+
+    fitness.evaluate_batch = fake_batch
     fitness.evaluate_population = fake_eval
     fitness.save_best_artifacts = lambda *a, **k: None
     cfg = synth.make_config(2, 1)
-    out = {}
-    for P in (7, 8, 1):
-        pop = synth.make_population(P, cfg, seed=3)
-        scores = fitness.get_fitnesses_neat(1, pop, "synthetic", cfg, 64, 64, [1, 4, 8], c_dim=1, best_dir=None)
-        out[P] = ([g.fitness for _, g in pop], scores.tolist(), calls[-1] if calls else None)
-    full = fitness.sharded_map(5, lambda lo, hi: np.arange(lo, hi) * 2.0)
-    q.put((rank, out, full.tolist(), calls))
+    out, err = {}, None
+    try:
+        for P in (7, 8, 1):
+            # `diverged`: rank 1's NEAT run was never seeded like rank 0's (the reference never seeds `random`)
+            pop = synth.make_population(P, cfg, seed=3 if not (diverged and rank == 1) else 99)
+            scores = fitness.get_fitnesses_neat(1, pop, "synthetic", cfg, 64, 64, [1, 4, 8], c_dim=1, best_dir=None)
+            out[P] = ([g.fitness for _, g in pop], scores.tolist())
+        full = fitness.sharded_map(5, lambda lo, hi: np.arange(lo, hi) * 2.0).tolist()
+        v, extras = fitness.sharded_map(3, lambda lo, hi: np.arange(lo, hi) + 0.5, extra=10.0 + rank)
+        full = (full, v.tolist(), extras.tolist())
+    except Exception as e:  # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    q.put((rank, out, None if err else full, calls, err))
     dist.destroy_process_group()
 
 
-def test_population_sharding_and_all_gather_gloo_world2():
+def _run_gloo(source, diverged):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q, source, diverged)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, out0, full0, calls0), (r1, out1, full1, calls1) = res
-    assert full0 == full1 == [0.0, 2.0, 4.0, 6.0, 8.0]
+    return res
+
+
+def _expected(P, seed=3):
+    from evolutionary_illusion_generator_amd import genome, synth
+    cfg = synth.make_config(2, 1)
+    pop = synth.make_population(P, cfg, seed=seed)
+    return _fake_fitness_of_batch(genome.GenomeBatch([g for _, g in pop], cfg, 1, n_leaves=2, native=False)).tolist()
+
+
+@pytest.mark.parametrize("source", ["rank0", "replicated"])
+def test_population_sharding_and_all_gather_gloo_world2(source):
+    (r0, out0, full0, calls0, e0), (r1, out1, full1, calls1, e1) = _run_gloo(source, diverged=False)
+    assert e0 is None and e1 is None, (e0, e1)
+    assert full0 == full1 == ([0.0, 2.0, 4.0, 6.0, 8.0], [0.5, 1.5, 2.5], [10.0, 11.0])  # `extra` rides in the same all-gather
     for P in (7, 8, 1):
-        want = [(i + 1) * 0.125 for i in range(P)]
+        want = _expected(P)
         assert out0[P][0] == want and out1[P][0] == want  # every rank ends with the full fitness list
-    assert calls0[0] == [1, 2, 3, 4] and calls1[0] == [5, 6, 7]   # contiguous shards in population order
-    assert calls0[1] == [1, 2, 3, 4] and calls1[1] == [5, 6, 7, 8]
-    assert calls0[2] == [1] and len(calls1) == 2                    # rank 1 owns nothing of a population of 1
+        assert out0[P][1] == want
+    assert calls0 == [4, 4, 1] and calls1 == [3, 4]   # contiguous shards in population order; rank 1 owns nothing of a population of 1
+
+
+def test_rank0_is_authoritative_when_the_ranks_populations_diverge():
+    """the reference never seeds `random`, so N unchanged copies of generate_illusion.py under torchrun evolve N
+    different populations.  Source 'rank0' broadcasts rank 0's flattened genomes: rank 0's fitness list is the right one."""
+    (r0, out0, full0, calls0, e0), (r1, out1, full1, calls1, e1) = _run_gloo("rank0", diverged=True)
+    assert e0 is None and e1 is None, (e0, e1)
+    for P in (7, 8, 1):
+        assert out0[P][0] == _expected(P)          # rank 0: fitness of ITS genomes, evaluated partly by rank 1
+        assert out1[P][1] == _expected(P)          # rank 1 returns the same vector (of rank 0's genomes)
+
+
+def test_replicated_source_refuses_diverged_populations():
+    (r0, out0, full0, calls0, e0), (r1, out1, full1, calls1, e1) = _run_gloo("replicated", diverged=True)
+    assert e0 and e1 and "different populations" in e0 and "EngineError" in e0
+
+
+def test_genome_batch_slice_and_wire_round_trip():
+    from evolutionary_illusion_generator_amd import genome, synth
+    cfg = synth.make_config(2, 3)
+    gs = [g for _, g in synth.make_population(9, cfg, seed=4)]
+    gb = genome.GenomeBatch(gs, cfg, 3, native=False)
+    rt = genome.GenomeBatch.from_bytes(gb.to_bytes())
+    for name, _ in genome.GenomeBatch._FIELDS:
+        assert np.array_equal(getattr(rt, name), getattr(gb, name)) and getattr(rt, name).dtype == getattr(gb, name).dtype, name
+    assert (rt.n_genomes, rt.c_out) == (9, 3)
+    for lo, hi in ((0, 9), (0, 4), (4, 9), (3, 4), (9, 9)):
+        part, want = gb.slice(lo, hi), genome.GenomeBatch(gs[lo:hi], cfg, 3, native=False)
+        for name, _ in genome.GenomeBatch._FIELDS:
+            assert np.array_equal(getattr(part, name), getattr(want, name)), (lo, hi, name)
 
 
 def test_get_fitnesses_neat_contract_single_process(monkeypatch):

@@ -33,6 +33,43 @@ def test_enhanced_grid_bit_exact():
     assert np.array_equal(e["y_mat"], g["enhanced_circles_120x120_y"])
 
 
+@pytest.mark.parametrize("name,structure,w,h", [("circles_256x256", 1, 256, 256), ("free_256x256", 2, 256, 256),
+                                                 ("circlesfree_256x256", 3, 256, 256), ("free_512x512", 2, 512, 512)])
+def test_full_size_grids_bit_exact(name, structure, w, h):
+    """The benchmark sizes ('grids at 64^2, 160x120, 256^2'): SHA-256 of the reference's float64 planes."""
+    import hashlib
+    from evolutionary_illusion_generator_amd import grids as product_grids
+    from oracle import grids as oracle_grids
+    sha = json.load(open(os.path.join(GOLD, "round2.json")))["grid_sha256"]
+    rows = np.load(os.path.join(GOLD, "grids_round2.npz"))
+    for impl in (product_grids,) + ((oracle_grids,) if w <= 256 else ()):   # the oracle's scalar loops take ~1 s per 256^2 grid
+        o = impl.create_grid(structure, w, h, 10)
+        for ax in ("x", "y"):
+            a = np.ascontiguousarray(o[ax + "_mat"], dtype=np.float64).reshape(h, w)
+            assert np.array_equal(a[::16], rows[name + "_" + ax + "_rows16"]), (impl.__name__, ax)
+            assert hashlib.sha256(a.tobytes()).hexdigest() == sha[name + "_" + ax], (impl.__name__, ax)
+
+
+@pytest.mark.parametrize("name,structure", [("bands", 0), ("free", 2), ("circlesfree", 3)])
+def test_enhanced_grid_for_every_structure(name, structure):
+    """generate_illusion.py:665-671 builds the enhanced grid for EVERY structure; fill_circle has no theta branch for Bands / Free."""
+    from evolutionary_illusion_generator_amd import grids
+    g = np.load(os.path.join(GOLD, "grids_round2.npz"))
+    e = grids.enhanced_image_grid(120, 120, structure)
+    assert np.array_equal(e["x_mat"], g["enhanced_%s_120x120_x" % name])
+    assert np.array_equal(e["y_mat"], g["enhanced_%s_120x120_y" % name])
+
+
+def test_inside_outside_score_matches_the_reference():
+    """a12 (fitness_calculator.py:219-304): the oracle's restatement against values computed by the imported function."""
+    from oracle import scores as S
+    cases = json.load(open(os.path.join(GOLD, "round2.json")))["inside_outside"]
+    assert len(cases) >= 9 and sum(1 for c in cases if c["score"] != 0) >= 7
+    for c in cases:
+        got = S.inside_outside_score(np.asarray(c["vectors"]).reshape(-1, 4), c["w"], c["h"])
+        assert float(got) == c["score"], (c["w"], c["h"], len(c["vectors"]))
+
+
 def test_bands_generalisation_for_sizes_the_reference_rejects():
     from evolutionary_illusion_generator_amd import grids
     o = grids.create_grid(0, 256, 256, 10)  # reference: ValueError (256 % 10 != 0), SURVEY Q5
@@ -40,6 +77,13 @@ def test_bands_generalisation_for_sizes_the_reference_rejects():
     from oracle import grids as og
     with pytest.raises(ValueError):
         og.create_grid(0, 256, 256, 10)
+    # the oracle states the build-defined generalisation independently (scalar loops); where the reference's grid exists
+    # the two coincide with it
+    for w, h in ((256, 256), (100, 70), (64, 64), (160, 120)):
+        a, b = og.create_grid(0, w, h, 10, generalised=True), grids.create_grid(0, w, h, 10)
+        assert np.array_equal(a["x_mat"], b["x_mat"]) and np.array_equal(a["y_mat"], b["y_mat"]), (w, h)
+    s, g_ = og.create_grid(0, 160, 120, 10), og.create_grid(0, 160, 120, 10, generalised=True)
+    assert np.array_equal(s["x_mat"], g_["x_mat"]) and np.array_equal(s["y_mat"], g_["y_mat"])
 
 
 def test_postprocess_matches_reference_bytes():
