@@ -32,9 +32,17 @@
 // everything that must not be read (padded channels, rows past the slab, `no next K-block`) is pushed out of the
 // descriptor's range by a saturating add -- every non-MFMA instruction in the loop costs matrix-pipe time.
 //
-// Row <-> pixel map of a 16-row MFMA sub-tile: 2 image rows x 8 columns; row r = 4q + reg covers
-// (dy, dx) = (reg >> 1, 2q + (reg & 1)), so the four accumulator registers of a lane are one 2x2 pooling window
-// (max-pool and the 2x2 patch stores of the epilogues stay inside the lane).
+// Row <-> pixel map ("class-major"): the four 16-row MFMA sub-tiles of a wave are the four PARITY CLASSES (y & 1, x & 1) of the
+// wave's 64 pixels, sub-tile mi = class (mi >> 1, mi & 1).  16-wide tiles: the wave owns rows 4 wv .. 4 wv + 3 of the 16 x 16
+// tile = 2 x 8 pooling windows; MFMA row r = 4 q + reg <-> window (wy, wx) = (reg >> 1, 2 q + (reg & 1)), pixel
+// (4 wv + 2 wy + py, 2 wx + px).  8-wide tiles: the wave owns one 8 x 8 image tile, row r <-> window (q, reg).  Consequences:
+//   - the four classes of a pooling window are the SAME register of the four sub-tile accumulators of one lane (max-pool in-lane);
+//   - a lane owns 4 (2) image rows x 4 (8) CONTIGUOUS columns: every epilogue access is a 16-byte access of 4 pixels;
+//   - the 16 pixels of one A-operand read sit on 16 distinct even (odd) LDS banks and the neighbouring tap kx + 1 of the other
+//     half of the lane group on the odd (even) ones: the gather of two adjacent taps is conflict-free (it was 2-way with the
+//     2-rows-x-8-columns sub-tiles of round 1: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.34);
+//   - all 16 rows of an MFMA share their class, so the class-dependent 2x2-form weights of an unpooled source are an ordinary
+//     B operand per sub-tile (what lets that chain run inside the ConvLSTM kernel).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -144,7 +152,10 @@ __device__ __forceinline__ float relu_f(float v) { return v > 0.0f ? v : 0.0f; }
 template <int TW, bool VEC> struct TileGeom {
     static constexpr int TH = (TW == 16) ? 16 : 8;
     static constexpr int NIMG = 256 / (TH * TW);
-    static constexpr int S = VEC ? TW + 8 : TW + 2;
+    // row stride in floats.  VEC: the aligned chunks x0-4 .. x0+TW+3 (TW + 8 floats); 8-wide tiles carry one more chunk so
+    // that 2 S = 8 (mod 32): the four window rows of a class sub-tile then start 8 banks apart (conflict-free gather; with
+    // S = 16 they would all start on the same bank).  16-wide: S = 24, 2 S = 16 (mod 32), two window rows x 8 even columns.
+    static constexpr int S = VEC ? (TW == 16 ? TW + 8 : TW + 12) : TW + 2;
     static constexpr int XO = VEC ? 3 : 0;
     static constexpr int PH = TH + 2;
     static constexpr int PLANE = NIMG * PH * S;  // floats per channel in LDS
@@ -406,23 +417,22 @@ conv3x3_mfma(const ConvArgs a)
     // ---- A-operand gather addresses: lane row r = lane&15 = 4*rq + rreg -> pixel (dy, dx); k-slot j = lane>>4.
     // k = 4*step + j, (channel, tap) = divmod(k, 9): period 9 steps = 4 channels -> nine address registers per layout.
     int addrA[9];
+    // class-major map: MFMA row r of sub-tile (py, px) is pixel (2 wy + py, 2 wx + px) of the wave's region
+    const int g_wy = (TW == 16) ? (col & 3) >> 1 : col >> 2;
+    const int g_wx = (TW == 16) ? 2 * (col >> 2) + (col & 1) : col & 3;
+    const int g_base = (TW == 16) ? (wv * 4 + 2 * g_wy) * S + 2 * g_wx + XO      // sub-tile mi adds (mi >> 1) * S + (mi & 1)
+                                  : wv * PH * S + 2 * g_wy * S + 2 * g_wx + XO;  // one image per wave
     {
-        const int r = col;
-        const int dy = (r & 3) >> 1, dx = 2 * (r >> 2) + (r & 1);
-        const int base = (TW == 16) ? (wv * 4 + dy) * S + dx + XO      // sub-tile mi adds (mi>>1)*2*S + (mi&1)*8
-                                    : wv * PH * S + dy * S + dx + XO;  // one image per wave; sub-tile mi adds mi*2*S
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
             const int k = 4 * s + q;
             const int c = k / 9, tap = k - 9 * c;
             const int ky = tap / 3, kx = tap - 3 * ky;
-            addrA[s] = base + c * PLANE + ky * S + kx;
+            addrA[s] = g_base + c * PLANE + ky * S + kx;
         }
     }
     // 2x2 form: k = 4*step + q -> channel = step, tap (a, b) = (q >> 1, q & 1): one address, the channel is an immediate
-    const int addr4 = ((TW == 16) ? (wv * 4 + ((col & 3) >> 1)) * S + 2 * (col >> 2) + (col & 1) + XO
-                                  : wv * PH * S + ((col & 3) >> 1) * S + 2 * (col >> 2) + (col & 1) + XO) +
-                      ((q >> 1) + (cls >> 1)) * S + (q & 1) + (cls & 1);
+    const int addr4 = g_base + ((q >> 1) + (cls >> 1)) * S + (q & 1) + (cls & 1);
     const int boff = q * NB + col * NI;  // weight slab row k = [16 channels][NI tiles]: a lane's NI values are contiguous
 
     f32x4 acc[4][NI];
@@ -436,43 +446,49 @@ conv3x3_mfma(const ConvArgs a)
     __syncthreads();
 
     // The chain of the unpooled source (an EPI_UP4 launch at half this resolution wrote it) is added to this launch's chain with
-    // one fp32 addition after the K loop.  Register `reg` of a lane is parity class `reg` of source pixel (gy0/2, gx0/2): four
-    // 4-byte loads per accumulator tile at the same offset of the four class planes, 16 cache lines per instruction.  Issued in
-    // one burst they saturate the wave's 63 outstanding vector-memory operations and the CU's address path (measured: 21K
-    // cycles in front of the first MFMA, scripts/timeline.py), so they are SPREAD over the MFMA steps of K-block 0, three or four
-    // per step, and land long before the K loop ends.
+    // one fp32 addition after the K loop.  Sub-tile mi of a lane is parity class mi and its registers 0..3 are the source pixels
+    // (wy, wx) of the lane's windows: per (class, N-tile) two 8-byte loads (16-wide tiles: rows wy = 0, 1, columns 2q, 2q + 1) or
+    // one 16-byte load (8-wide tiles: row q, columns 0..3) from plane `class` of the chain tensor.  Issued in one burst they
+    // saturate the wave's outstanding vector-memory operations and the CU's address path in front of the first MFMA (round 1:
+    // 21K cycles, scripts/timeline.py), so they are SPREAD over the MFMA steps of K-block 0 and land long before the K loop ends.
     constexpr bool HAS_UP = (EPI == EPI_LSTM || EPI == EPI_LSTM_PACKED || EPI == EPI_RAW);  // operators that can have an unpooled source
-    constexpr int NUPL = HAS_UP ? 16 * NI : 0;  // loads per lane
+    constexpr int UPV = (TW == 16) ? 2 : 1;             // loads per (class, N-tile)
+    constexpr int NUPL = HAS_UP ? 4 * NI * UPV : 0;     // loads per lane
     f32x4 upc[4][HAS_UP ? NI : 1];
     const bool has_up = HAS_UP && a.acc_init != nullptr;
-    int up_off[4];
+    int up_off[UPV];
     const float* up_base = a.acc_init;
     int up_hw = 0, up_cstride = 0;
     if (has_up) {
         const int Hs = a.H >> 1, Ws = a.W >> 1;
         up_hw = Hs * Ws;
         up_cstride = a.n_nblk * NB * up_hw;
+        const int b = bgrp * NIMG + (TW == 16 ? 0 : wv);
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            int img, py0, px0;
-            if (TW == 16) {
-                const int sidx = wv * 4 + mi;
-                img = 0; py0 = 2 * (sidx >> 1); px0 = 8 * (sidx & 1) + 2 * q;
-            } else {
-                img = wv; py0 = 2 * mi; px0 = 2 * q;
-            }
-            const int b = bgrp * NIMG + img;
-            const int gy0 = tyi * TH + py0, gx0 = txi * TW + px0;
+        for (int v = 0; v < UPV; ++v) {
+            // window row / first window column of this load, in pixels of THIS launch's resolution
+            const int gy0 = (TW == 16) ? y0 + 4 * wv + 2 * v : tyi * TH + 2 * q;
+            const int gx0 = (TW == 16) ? x0 + 4 * q : txi * TW;
             // element offset inside this wave's image block [4][n_nblk*NB][Hs][Ws] (the image is wave-uniform); windows outside
             // the image read element 0 instead -- their accumulators are never stored
-            up_off[mi] = (b < a.B && gy0 < a.H && gx0 < a.W) ? ((nblk * NB + col) * up_hw + (gy0 >> 1) * Ws + (gx0 >> 1)) * 4 : 0;
+            up_off[v] = (b < a.B && gy0 < a.H && gx0 < a.W) ? ((nblk * NB + col) * up_hw + (gy0 >> 1) * Ws + (gx0 >> 1)) * 4 : 0;
         }
-        const int bw = __builtin_amdgcn_readfirstlane(bgrp * NIMG + (TW == 16 ? 0 : wv));
+        const int bw = __builtin_amdgcn_readfirstlane(b);
         up_base = a.acc_init + (size_t)(bw < a.B ? bw : 0) * 4 * up_cstride;
     }
-    // buffer loads: the lane part of the address is one of FOUR byte offsets (up_off), the (tile, class) part a scalar -- with flat
-    // addresses the compiler hoists 64 loop-invariant 64-bit pointers out of the K loop (128 VGPRs, spilled)
+    // buffer loads: the lane part of the address is one of UPV byte offsets (up_off), the (N-tile, class) part a scalar -- with flat
+    // addresses the compiler hoists the loop-invariant 64-bit pointers out of the K loop (128 VGPRs, spilled)
     const __amdgpu_buffer_rsrc_t rs_up = __builtin_amdgcn_make_buffer_rsrc((void*)up_base, 0, has_up ? 4 * up_cstride * 4 : 0, 0x00020000);
+    auto up_load = [&](int mi, int ni, int v) __attribute__((always_inline)) {
+        const int soff = (ni * 16 * up_hw + mi * up_cstride) * 4;
+        if constexpr (TW == 16) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_up, up_off[v], soff, 0));
+            upc[mi][ni][2 * v] = t[0]; upc[mi][ni][2 * v + 1] = t[1];
+        } else {
+            upc[mi][ni] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_up, up_off[0], soff, 0));
+        }
+    };
 
     unsigned long long t_mfma = 0, t_wait = 0, t_bar = 0, t_all0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     auto kiter = [&](const int kb, auto kfirst_tag) __attribute__((always_inline)) {
@@ -507,7 +523,7 @@ conv3x3_mfma(const ConvArgs a)
                     float avc[4][3];  // EPI_UP4C: the gathers of classes 1..3
 #pragma unroll
                     for (int mi = 0; mi < 4; ++mi) {
-                        const int moff = (TW == 16) ? ((mi >> 1) * 2 * S + (mi & 1) * 8) : (mi * 2 * S);
+                        const int moff = (mi >> 1) * S + (mi & 1);  // parity class (py, px) of sub-tile mi
                         av[mi] = (TAPS == 9) ? in_lds[ad[s9] + per * 4 * PL + moff] : in_lds[addr4 + st * PL + moff];
                         if constexpr (EPI == EPI_UP4C) {  // class c = (py, px) shifts the tap window by (py, px)
 #pragma unroll
@@ -545,9 +561,8 @@ conv3x3_mfma(const ConvArgs a)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-                            for (int reg = 0; reg < 4; ++reg)
-                                if (((mi * NI + ni) * 4 + reg) * NSTEP / NUPL == st)
-                                    upc[mi][ni][reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_up, up_off[mi], (ni * 16 * up_hw + reg * up_cstride) * 4, 0));
+                            for (int v = 0; v < UPV; ++v)
+                                if (((mi * NI + ni) * UPV + v) * NSTEP / NUPL == st) up_load(mi, ni, v);
                     __builtin_amdgcn_sched_barrier(0);  // keep them in their step: left alone the scheduler sinks all of them to the end of the K-block
                 }
             }
@@ -587,163 +602,112 @@ conv3x3_mfma(const ConvArgs a)
             d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32); d[5] = t_mfma; d[6] = t_setup; d[7] = t_prewait; (void)t_mid; (void)t_bar;
         }
     };
-    if constexpr (EPI == EPI_CONVA && TW == 16 && VEC) {
-        // Tiles inside the image: sub-tiles 2mp and 2mp+1 of a wave hold the pooled pixels (row, q) and (row, 4 + q); one exchange
-        // between the lane pairs q ^ 1 gives every lane two NEIGHBOURING pooled pixels, so P is read and both halves of E are
-        // written as aligned 8-byte accesses (same values, half the memory instructions, whole sectors).
-        if (bgrp < a.B && y0 + 16 <= a.H && x0 + 16 <= a.W) {
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            const int Ho = a.H >> 1, Wo = a.W >> 1;
-            const size_t plane = (size_t)Ho * Wo;
-#pragma unroll
-            for (int mp = 0; mp < 2; ++mp) {
-                const int yo = tyi * 8 + wv * 2 + mp;
-                const int xo = txi * 8 + ((q & 1) ? 3 + q : q);  // even: this lane's pair is (xo, xo + 1)
-                f32x2 pv[NI];
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int ch = nblk * NB + ni * 16 + col;
-                    pv[ni] = (ch < a.Cout) ? *reinterpret_cast<const f32x2*>(a.P + ((size_t)bgrp * a.Cout + ch) * plane + (size_t)yo * Wo + xo) : (f32x2){0.0f, 0.0f};
-                }
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    const int ch = nblk * NB + ni * 16 + col;
-                    const float bb = (ch < a.Cout) ? a.bias[ch] : 0.0f;
-                    float pooled[2];
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        const f32x4 c4 = acc[2 * mp + h][ni];
-                        const float v0 = relu_f(c4[0] + bb), v1 = relu_f(c4[1] + bb), v2 = relu_f(c4[2] + bb), v3 = relu_f(c4[3] + bb);
-                        pooled[h] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-                    }
-                    const float recv = __shfl_xor((q & 1) ? pooled[0] : pooled[1], 16, 64);
-                    const f32x2 A2 = (q & 1) ? (f32x2){recv, pooled[1]} : (f32x2){pooled[0], recv};
-                    if (ch < a.Cout) {
-                        const f32x2 p2 = pv[ni];
-                        float* e = a.E + ((size_t)bgrp * 2 * a.Cout + ch) * plane + (size_t)yo * Wo + xo;
-                        *reinterpret_cast<f32x2*>(e) = (f32x2){relu_f(A2[0] - p2[0]), relu_f(A2[1] - p2[1])};
-                        *reinterpret_cast<f32x2*>(e + (size_t)a.Cout * plane) = (f32x2){relu_f(p2[0] - A2[0]), relu_f(p2[1] - A2[1])};
-                    }
-                }
-            }
-            timeline_record(0);
-            return;
-        }
-    }
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-        int img, py0, px0;
-        if (TW == 16) {
-            const int sidx = wv * 4 + mi;
-            img = 0; py0 = 2 * (sidx >> 1); px0 = 8 * (sidx & 1) + 2 * q;
-        } else {
-            img = wv; py0 = 2 * mi; px0 = 2 * q;
-        }
-        const int b = bgrp * NIMG + img;
-        const int gy0 = tyi * TH + py0, gx0 = txi * TW + px0;
-        if (b >= a.B || gy0 >= a.H || gx0 >= a.W) continue;
+    // ---- what a lane owns (class-major map): 4 SEGMENTS of 4 horizontally contiguous pixels; element j of segment s is the
+    // accumulator register seg_reg(s, j) of sub-tile (class) seg_mi(s, j).  16-wide tiles: segment s = row 4 wv + s, columns
+    // 4 q .. 4 q + 3; 8-wide tiles: segment s = row 2 q + (s >> 1), columns 4 (s & 1) .. + 3 of the wave's image.
+    // Pooled / half-resolution view: register reg of every sub-tile is window (wy, wx): 16-wide (reg >> 1, 2 q + (reg & 1)) of the
+    // wave's 2 x 8 windows, 8-wide (q, reg).
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const int eb = bgrp * NIMG + (TW == 16 ? 0 : wv);          // image of this wave
+    const int ey0 = (TW == 16) ? y0 + 4 * wv : tyi * TH;       // first row / column of the wave's region
+    const int ex0 = (TW == 16) ? x0 : txi * TW;
+    auto seg_row = [&](int sgi) __attribute__((always_inline)) { return ey0 + ((TW == 16) ? sgi : 2 * q + (sgi >> 1)); };
+    auto seg_col = [&](int sgi) __attribute__((always_inline)) { return ex0 + ((TW == 16) ? 4 * q : 4 * (sgi & 1)); };
+#define EIG_SEG_MI(sgi, j) ((TW == 16) ? 2 * ((sgi) & 1) + ((j) & 1) : 2 * ((sgi) >> 1) + ((j) & 1))
+#define EIG_SEG_REG(sgi, j) ((TW == 16) ? 2 * ((sgi) >> 1) + ((j) >> 1) : 2 * ((sgi) & 1) + ((j) >> 1))
+    if (eb >= a.B) { timeline_record(0); return; }
 
-        if (EPI == EPI_RAW) {
+    if constexpr (EPI == EPI_RAW || EPI == EPI_UP4 || EPI == EPI_UP4C) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
+            float* dst;
+            if (EPI == EPI_UP4C) dst = a.raw + (((size_t)eb * 4 + ni) * a.n_nblk * 16 + nblk * 16 + col) * HW;  // N-tile ni is class ni of the 16 output columns
+            else if (EPI == EPI_UP4) dst = a.raw + (((size_t)eb * 4 + cls) * a.n_nblk * NB + nblk * NB + ni * 16 + col) * HW;
+            else {
                 const int o = nblk * NB + ni * 16 + col;
                 if (o >= a.Cout) continue;
-                float* dst = a.raw + ((size_t)b * a.Cout + o) * HW;
-#pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);
-                    if (gy < a.H && gx < a.W) dst[gy * a.W + gx] = acc[mi][ni][reg];
-                }
+                dst = a.raw + ((size_t)eb * a.Cout + o) * HW;
             }
-        } else if (EPI == EPI_UP4 || EPI == EPI_UP4C) {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                // EPI_UP4C: N-tile ni is class ni of the 16 output columns of this N-block
-                float* dst = (EPI == EPI_UP4C) ? a.raw + (((size_t)b * 4 + ni) * a.n_nblk * 16 + nblk * 16 + col) * HW
-                                               : a.raw + (((size_t)b * 4 + cls) * a.n_nblk * NB + nblk * NB + ni * 16 + col) * HW;
-                if (VEC && gx0 + 1 < a.W) {  // W % 4 == 0, gx0 even: the two pixels of a window row are one aligned 8-byte store
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-                    *reinterpret_cast<f32x2*>(dst + gy0 * a.W + gx0) = (f32x2){acc[mi][ni][0], acc[mi][ni][1]};
-                    if (gy0 + 1 < a.H) *reinterpret_cast<f32x2*>(dst + (gy0 + 1) * a.W + gx0) = (f32x2){acc[mi][ni][2], acc[mi][ni][3]};
+            for (int sgi = 0; sgi < 4; ++sgi) {
+                const int gy = seg_row(sgi), gx = seg_col(sgi);
+                if (gy >= a.H || gx >= a.W) continue;
+                if (VEC) {  // W % 4 == 0: the whole segment is inside, one aligned 16-byte store
+                    *reinterpret_cast<f32x4*>(dst + gy * a.W + gx) = (f32x4){acc[EIG_SEG_MI(sgi, 0)][ni][EIG_SEG_REG(sgi, 0)], acc[EIG_SEG_MI(sgi, 1)][ni][EIG_SEG_REG(sgi, 1)],
+                                                                              acc[EIG_SEG_MI(sgi, 2)][ni][EIG_SEG_REG(sgi, 2)], acc[EIG_SEG_MI(sgi, 3)][ni][EIG_SEG_REG(sgi, 3)]};
                     continue;
                 }
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);
-                    if (gy < a.H && gx < a.W) dst[gy * a.W + gx] = acc[mi][ni][reg];
-                }
+                for (int j = 0; j < 4; ++j)
+                    if (gx + j < a.W) dst[gy * a.W + gx + j] = acc[EIG_SEG_MI(sgi, j)][ni][EIG_SEG_REG(sgi, j)];
             }
-        } else if (EPI == EPI_LSTM) {
-            const int ch = nblk * 16 + col;
-            if (ch >= a.Cout) continue;
+        }
+    } else if constexpr (EPI == EPI_LSTM) {
+        const int ch = nblk * 16 + col;
+        if (ch < a.Cout) {
             const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
-            const size_t cbase = ((size_t)b * a.Cout + ch) * HW;
+            const size_t cbase = ((size_t)eb * a.Cout + ch) * HW;
             const size_t pbase = (size_t)ch * HW;
             const size_t pstride = (size_t)a.Cout * HW;
-            if (VEC && EIG_ABLATE != 2 && gx0 + 1 < a.W) {
-                // W % 4 == 0 and gx0 even: the two pixels of a window row are one aligned 8-byte access -- half the memory
-                // instructions of the epilogue and whole 32-byte sectors per (channel, row) instead of half ones
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int r2 = 0; r2 < 2; ++r2) {
-                    const int gy = gy0 + r2;
-                    if (gy >= a.H) continue;
-                    const int pix = gy * a.W + gx0;
-                    const f32x2 cold2 = *reinterpret_cast<const f32x2*>(a.c_state + cbase + pix);
-                    const f32x2 pi2 = *reinterpret_cast<const f32x2*>(a.peep + pbase + pix);
-                    const f32x2 pf2 = *reinterpret_cast<const f32x2*>(a.peep + pstride + pbase + pix);
-                    const f32x2 po2 = *reinterpret_cast<const f32x2*>(a.peep + 2 * pstride + pbase + pix);
-                    f32x2 cn2, hn2;
-#pragma unroll
-                    for (int e = 0; e < 2; ++e) {
-                        const int reg = r2 * 2 + e;
-                        const float cold = cold2[e];
-                        float zi = acc[mi][0][reg] + bi; zi = fmaf(pi2[e], cold, zi);
-                        float zf = acc[mi][1][reg] + bf; zf = fmaf(pf2[e], cold, zf);
-                        const float zc = acc[mi][2][reg] + bc;
-                        float zo = acc[mi][3][reg] + bo; zo = fmaf(po2[e], cold, zo);
-                        const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
-                        const float gi = gg * ii;
-                        const float cnew = fmaf(ff, cold, gi);
-                        cn2[e] = cnew;
-                        hn2[e] = oo * det_tanhf(cnew);
-                    }
-                    *reinterpret_cast<f32x2*>(a.c_state + cbase + pix) = cn2;
-                    *reinterpret_cast<f32x2*>(a.h_out + cbase + pix) = hn2;
-                }
-                continue;
-            }
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);
-                if (gy >= a.H || gx >= a.W) continue;
-                const int pix = gy * a.W + gx;
-                const float cold = a.c_state[cbase + pix];
-                float zi = acc[mi][0][reg] + bi; zi = fmaf(a.peep[pbase + pix], cold, zi);
-                float zf = acc[mi][1][reg] + bf; zf = fmaf(a.peep[pstride + pbase + pix], cold, zf);
-                const float zc = acc[mi][2][reg] + bc;
-                float zo = acc[mi][3][reg] + bo; zo = fmaf(a.peep[2 * pstride + pbase + pix], cold, zo);
-                if (EIG_ABLATE == 2) {  // measurement only: gate math removed
-                    a.c_state[cbase + pix] = zi + zf;
-                    a.h_out[cbase + pix] = zc + zo;
-                    continue;
-                }
+            auto cell = [&](float zi_, float zf_, float zc_, float zo_, float cold, float pi_, float pf_, float po_, float& cn, float& hn) __attribute__((always_inline)) {
+                float zi = zi_ + bi; zi = fmaf(pi_, cold, zi);
+                float zf = zf_ + bf; zf = fmaf(pf_, cold, zf);
+                const float zc = zc_ + bc;
+                float zo = zo_ + bo; zo = fmaf(po_, cold, zo);
+                if (EIG_ABLATE == 2) { cn = zi + zf; hn = zc + zo; return; }  // measurement only: gate math removed
                 const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
                 const float gi = gg * ii;
-                const float cnew = fmaf(ff, cold, gi);
-                a.c_state[cbase + pix] = cnew;
-                a.h_out[cbase + pix] = oo * det_tanhf(cnew);
+                cn = fmaf(ff, cold, gi);
+                hn = oo * det_tanhf(cn);
+            };
+#pragma unroll
+            for (int sgi = 0; sgi < 4; ++sgi) {
+                const int gy = seg_row(sgi), gx = seg_col(sgi);
+                if (gy >= a.H || gx >= a.W) continue;
+                const int pix = gy * a.W + gx;
+                if (VEC) {
+                    // W % 4 == 0: the four pixels of the segment are ONE aligned 16-byte access per tensor -- a quarter of the memory
+                    // instructions of per-pixel accesses and whole 32-byte sectors per (channel, row)
+                    const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
+                    const f32x4 pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
+                    const f32x4 pf4 = *reinterpret_cast<const f32x4*>(a.peep + pstride + pbase + pix);
+                    const f32x4 po4 = *reinterpret_cast<const f32x4*>(a.peep + 2 * pstride + pbase + pix);
+                    f32x4 cn4, hn4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float cn, hn;
+                        cell(acc[EIG_SEG_MI(sgi, j)][0][EIG_SEG_REG(sgi, j)], acc[EIG_SEG_MI(sgi, j)][1][EIG_SEG_REG(sgi, j)], acc[EIG_SEG_MI(sgi, j)][2][EIG_SEG_REG(sgi, j)],
+                             acc[EIG_SEG_MI(sgi, j)][3][EIG_SEG_REG(sgi, j)], cold4[j], pi4[j], pf4[j], po4[j], cn, hn);
+                        cn4[j] = cn; hn4[j] = hn;
+                    }
+                    *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
+                    *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (gx + j >= a.W) continue;
+                    float cn, hn;
+                    cell(acc[EIG_SEG_MI(sgi, j)][0][EIG_SEG_REG(sgi, j)], acc[EIG_SEG_MI(sgi, j)][1][EIG_SEG_REG(sgi, j)], acc[EIG_SEG_MI(sgi, j)][2][EIG_SEG_REG(sgi, j)],
+                         acc[EIG_SEG_MI(sgi, j)][3][EIG_SEG_REG(sgi, j)], a.c_state[cbase + pix + j], a.peep[pbase + pix + j], a.peep[pstride + pbase + pix + j],
+                         a.peep[2 * pstride + pbase + pix + j], cn, hn);
+                    a.c_state[cbase + pix + j] = cn;
+                    a.h_out[cbase + pix + j] = hn;
+                }
             }
-        } else if (EPI == EPI_LSTM_PACKED) {
-            // C <= 4 (layer 0): ONE 16-column tile holds the 4 gates x 4 channel slots, column = 4*gate + channel, so the
-            // four gates of a cell sit in four lanes (same pixel rows q, columns ch, ch+4, ch+8, ch+12) and each of those
-            // lanes holds them for the four pixels of its 2x2 window (reg 0..3).  A 4x4 transpose across the four lanes
-            // gives lane (group g = col>>2, channel ch) ALL FOUR gates of pixel reg = g: one cell per lane and sub-tile
-            // instead of four cells in a quarter of the lanes (the gate math is ~190 instructions per cell).
-            // Round d: every lane offers its register (g+d)&3, lane g pulls from group (g-d)&3 -> that group's gate, pixel g.
-            const int ch = col & 3, g = col >> 2;
-            const bool active = ch < a.Cout;
-            const int cc = active ? ch : 0;
+        }
+    } else if constexpr (EPI == EPI_LSTM_PACKED) {
+        // C <= 4 (layer 0): ONE 16-column tile holds the 4 gates x 4 channel slots, column = 4*gate + channel, so the
+        // four gates of a cell sit in four lanes (same q, columns ch, ch+4, ch+8, ch+12) and each of those lanes holds them for
+        // its four windows (reg 0..3) of every class sub-tile.  A 4x4 transpose across the four lanes gives lane (group
+        // g = col>>2, channel ch) ALL FOUR gates of register g: one cell per lane and sub-tile instead of four cells in a
+        // quarter of the lanes (the gate math is ~190 instructions per cell).
+        // Round d: every lane offers its register (g+d)&3, lane g pulls from group (g-d)&3 -> that group's gate, register g.
+        const int ch = col & 3, g = col >> 2;
+        const bool active = ch < a.Cout;
+        const int cc = active ? ch : 0;
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
             float r[4];
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
@@ -752,15 +716,17 @@ conv3x3_mfma(const ConvArgs a)
                 r[d] = (d == 0) ? v : __shfl(v, (lane & ~12) | (((g - d) & 3) << 2), 64);
             }
             // r[d] is gate (g-d)&3; gate s arrived in round (g-s)&3
-            auto gate = [&](int s) {
-                const int d = (g - s) & 3;
+            auto gate = [&](int sg) {
+                const int d = (g - sg) & 3;
                 return d == 0 ? r[0] : (d == 1 ? r[1] : (d == 2 ? r[2] : r[3]));
             };
             const float ai = gate(0), af = gate(1), ac = gate(2), ao = gate(3);
-            const int gy = gy0 + (g >> 1), gx = gx0 + (g & 1);
+            // pixel of (class mi, register g)
+            const int gy = ey0 + ((TW == 16) ? 2 * (g >> 1) + (mi >> 1) : 2 * q + (mi >> 1));
+            const int gx = ex0 + ((TW == 16) ? 4 * q + 2 * (g & 1) + (mi & 1) : 2 * g + (mi & 1));
             if (!active || gy >= a.H || gx >= a.W) continue;
             const float bi = a.bias[cc], bf = a.bias[a.Cout + cc], bc = a.bias[2 * a.Cout + cc], bo = a.bias[3 * a.Cout + cc];
-            const size_t cbase = ((size_t)b * a.Cout + cc) * HW;
+            const size_t cbase = ((size_t)eb * a.Cout + cc) * HW;
             const size_t pbase = (size_t)cc * HW;
             const size_t pstride = (size_t)a.Cout * HW;
             const int pix = gy * a.W + gx;
@@ -774,60 +740,94 @@ conv3x3_mfma(const ConvArgs a)
             const float cnew = fmaf(ff, cold, gi);
             a.c_state[cbase + pix] = cnew;
             a.h_out[cbase + pix] = oo * det_tanhf(cnew);
-        } else if (EPI == EPI_CONVA) {
-            const int Ho = a.H >> 1, Wo = a.W >> 1;
-            float pv[NI];
+        }
+    } else if constexpr (EPI == EPI_CONVA) {
+        // max-pool: window `reg` of the lane = the same register of the four class sub-tiles.  Pooled pixels of a lane: 16-wide tiles
+        // 2 rows x 2 contiguous columns (two 8-byte accesses per tensor), 8-wide tiles 1 row x 4 columns (one 16-byte access).
+        const int Ho = a.H >> 1, Wo = a.W >> 1;
+        const size_t plane = (size_t)Ho * Wo;
+        constexpr int NPR = (TW == 16) ? 2 : 1, NPC = (TW == 16) ? 2 : 4;  // pooled rows x contiguous pooled columns per lane
+        const int pyo = (ey0 >> 1) + ((TW == 16) ? 0 : q), pxo = (ex0 >> 1) + ((TW == 16) ? 2 * q : 0);
+        const bool vec_ok = VEC && (TW == 16 || (a.W % 8) == 0);  // 16-wide: W % 4 == 0 makes the pooled pairs 8-byte aligned; 8-wide: 16-byte rows need Wo % 4 == 0
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {  // all P loads of this sub-tile before the first E store (E and P might alias for the compiler)
-                const int ch = nblk * NB + ni * 16 + col;
-                pv[ni] = (ch < a.Cout) ? a.P[(((size_t)b * a.Cout + ch) * Ho + (gy0 >> 1)) * Wo + (gx0 >> 1)] : 0.0f;
+        for (int ni = 0; ni < NI; ++ni) {
+            const int ch = nblk * NB + ni * 16 + col;
+            if (ch >= a.Cout) continue;
+            const float bb = a.bias[ch];
+            float A[4];
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const float v0 = relu_f(acc[0][ni][reg] + bb), v1 = relu_f(acc[1][ni][reg] + bb);
+                const float v2 = relu_f(acc[2][ni][reg] + bb), v3 = relu_f(acc[3][ni][reg] + bb);
+                A[reg] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
             }
+            const float* Pc = a.P + ((size_t)eb * a.Cout + ch) * plane;
+            float* Ec = a.E + ((size_t)eb * 2 * a.Cout + ch) * plane;
+            float* Ec2 = Ec + (size_t)a.Cout * plane;
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int ch = nblk * NB + ni * 16 + col;
-                if (ch >= a.Cout) continue;
-                const float bb = a.bias[ch];
-                const float v0 = relu_f(acc[mi][ni][0] + bb), v1 = relu_f(acc[mi][ni][1] + bb);
-                const float v2 = relu_f(acc[mi][ni][2] + bb), v3 = relu_f(acc[mi][ni][3] + bb);
-                const float A = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
-                const float p = pv[ni];
-                const size_t e = (((size_t)b * 2 * a.Cout + ch) * Ho + (gy0 >> 1)) * Wo + (gx0 >> 1);
-                a.E[e] = relu_f(A - p);
-                a.E[e + (size_t)a.Cout * Ho * Wo] = relu_f(p - A);
-            }
-        } else if (EPI == EPI_CONVP) {
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int ch = nblk * NB + ni * 16 + col;
-                if (ch >= a.Cout) continue;
-                const float bb = a.bias[ch];
-                const size_t base = ((size_t)b * a.Cout + ch) * HW;
-                if (VEC && !a.frame && !a.E0 && gx0 + 1 < a.W) {  // layers > 0: P only, aligned 8-byte stores of the window rows
-                    typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int r2 = 0; r2 < 2; ++r2) {
-                        if (gy0 + r2 >= a.H) continue;
-                        float v0 = relu_f(acc[mi][ni][r2 * 2] + bb), v1 = relu_f(acc[mi][ni][r2 * 2 + 1] + bb);
-                        if (a.clip) { v0 = fminf(v0, 1.0f); v1 = fminf(v1, 1.0f); }
-                        *reinterpret_cast<f32x2*>(a.Pout + base + (gy0 + r2) * a.W + gx0) = (f32x2){v0, v1};
+            for (int pr = 0; pr < NPR; ++pr) {
+                const int yo = pyo + pr;
+                if (yo >= Ho || pxo >= Wo) continue;
+                const size_t o = (size_t)yo * Wo + pxo;
+                if (vec_ok) {
+                    if constexpr (TW == 16) {
+                        const f32x2 p2 = *reinterpret_cast<const f32x2*>(Pc + o);
+                        const float A0 = A[2 * pr], A1 = A[2 * pr + 1];
+                        *reinterpret_cast<f32x2*>(Ec + o) = (f32x2){relu_f(A0 - p2[0]), relu_f(A1 - p2[1])};
+                        *reinterpret_cast<f32x2*>(Ec2 + o) = (f32x2){relu_f(p2[0] - A0), relu_f(p2[1] - A1)};
+                    } else {
+                        const f32x4 p4 = *reinterpret_cast<const f32x4*>(Pc + o);
+                        *reinterpret_cast<f32x4*>(Ec + o) = (f32x4){relu_f(A[0] - p4[0]), relu_f(A[1] - p4[1]), relu_f(A[2] - p4[2]), relu_f(A[3] - p4[3])};
+                        *reinterpret_cast<f32x4*>(Ec2 + o) = (f32x4){relu_f(p4[0] - A[0]), relu_f(p4[1] - A[1]), relu_f(p4[2] - A[2]), relu_f(p4[3] - A[3])};
                     }
                     continue;
                 }
 #pragma unroll
-                for (int reg = 0; reg < 4; ++reg) {
-                    const int gy = gy0 + (reg >> 1), gx = gx0 + (reg & 1);
-                    if (gy >= a.H || gx >= a.W) continue;
-                    const int pix = gy * a.W + gx;
-                    float v = relu_f(acc[mi][ni][reg] + bb);
+                for (int pc = 0; pc < NPC; ++pc) {
+                    if (pxo + pc >= Wo) continue;
+                    const float Av = A[(TW == 16) ? 2 * pr + pc : pc];
+                    const float p = Pc[o + pc];
+                    Ec[o + pc] = relu_f(Av - p);
+                    Ec2[o + pc] = relu_f(p - Av);
+                }
+            }
+        }
+    } else if constexpr (EPI == EPI_CONVP) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int ch = nblk * NB + ni * 16 + col;
+            if (ch >= a.Cout) continue;
+            const float bb = a.bias[ch];
+            const size_t base = ((size_t)eb * a.Cout + ch) * HW;
+#pragma unroll
+            for (int sgi = 0; sgi < 4; ++sgi) {
+                const int gy = seg_row(sgi), gx = seg_col(sgi);
+                if (gy >= a.H || gx >= a.W) continue;
+                const int pix = gy * a.W + gx;
+                if (VEC && !a.frame && !a.E0) {  // layers > 0: P only, one aligned 16-byte store per segment
+                    f32x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float v = relu_f(acc[EIG_SEG_MI(sgi, j)][ni][EIG_SEG_REG(sgi, j)] + bb);
+                        if (a.clip) v = fminf(v, 1.0f);
+                        v4[j] = v;
+                    }
+                    *reinterpret_cast<f32x4*>(a.Pout + base + pix) = v4;
+                    continue;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (gx + j >= a.W) continue;
+                    float v = relu_f(acc[EIG_SEG_MI(sgi, j)][ni][EIG_SEG_REG(sgi, j)] + bb);
                     if (a.clip) v = fminf(v, 1.0f);
-                    a.Pout[base + pix] = v;
-                    if (a.frame) a.frame[(size_t)b * a.frame_bstride + (size_t)ch * HW + pix] = (uint8_t)(int)(v * 255.0f);
+                    a.Pout[base + pix + j] = v;
+                    if (a.frame) a.frame[(size_t)eb * a.frame_bstride + (size_t)ch * HW + pix + j] = (uint8_t)(int)(v * 255.0f);
                     if (a.E0) {
                         float x;
-                        if (a.img) x = (float)a.img[base + pix] / 255.0f;
+                        if (a.img) x = (float)a.img[base + pix + j] / 255.0f;
                         else if (a.requant) x = (float)(uint8_t)(int)(v * 255.0f) / 255.0f;
                         else x = v;
-                        const size_t e = ((size_t)b * 2 * a.Cout + ch) * HW + pix;
+                        const size_t e = ((size_t)eb * 2 * a.Cout + ch) * HW + pix + j;
                         a.E0[e] = relu_f(x - v);
                         a.E0[e + (size_t)a.Cout * HW] = relu_f(v - x);
                     }
@@ -835,6 +835,8 @@ conv3x3_mfma(const ConvArgs a)
             }
         }
     }
+#undef EIG_SEG_MI
+#undef EIG_SEG_REG
     timeline_record(0);
 }
 
