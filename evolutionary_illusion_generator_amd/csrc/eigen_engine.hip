@@ -53,6 +53,9 @@ struct ConvOp {
     double macs = 0;  // algorithmic multiply-accumulates per image (real channels only)
     double ms = 0;    // profiling accumulator
     int launches = 0;
+    // ConvLSTM with the chain of its unpooled source computed in-kernel (conv_mfma.h: FUSE); the weights live in Layer::d_upw
+    bool fused = false;
+    int up_C = 0, up_kb = 0;
 };
 
 struct Layer {
@@ -68,6 +71,7 @@ struct Layer {
     // The unpooled source R_{l+1} of the ConvLSTM in its 2x2 form (conv_mfma.h: EPI_UP4), launched at the resolution of
     // layer l+1 ahead of the ConvLSTM launch, which adds the result to its own chain (eigen_engine::d_raw4).
     ConvOp up4;
+    float* d_upw = nullptr;  // FUSE: 2x2-form weights of R_{l+1}, [n_nblk][up_kb][KC*4][4 classes][16][4 gates]
 };
 
 template <typename T> struct DevBuf {
@@ -306,6 +310,26 @@ static std::vector<float> pack_weights_up4(const ConvOp& op, const float* const 
     return out;
 }
 
+// FUSE (conv_mfma.h): the 2x2-form weights of the unpooled source as the ConvLSTM kernel stages them, K-block by K-block:
+// [n_nblk][up_kb][row = (channel in K-block, a, b)][4 classes][16 columns][4 gates]; channels past Cin are zero rows.
+static std::vector<float> pack_weights_upfuse(int Cout, int n_nblk, int Cin, const float* const srcw[4])
+{
+    const int up_kb = (Cin + KC - 1) / KC;
+    std::vector<float> out((size_t)n_nblk * up_kb * UP_WFLOATS, 0.0f);
+    for (int nb = 0; nb < n_nblk; ++nb)
+        for (int c = 0; c < Cin; ++c)
+            for (int tap = 0; tap < 4; ++tap)
+                for (int cls = 0; cls < 4; ++cls) {
+                    float* dst = &out[(((size_t)nb * up_kb + c / KC) * (KC * 4) + (size_t)(c % KC) * 4 + tap) * UP_WROW + (size_t)cls * 64];
+                    for (int n = 0; n < 64; ++n) {
+                        const int g = n / 16, o = nb * 16 + (n % 16);
+                        if (o >= Cout) continue;
+                        dst[(n % 16) * 4 + g] = presum_up_weight(srcw[g] + ((size_t)o * Cin + c) * 9, cls >> 1, cls & 1, tap >> 1, tap & 1);
+                    }
+                }
+    return out;
+}
+
 // EPI_UP4C (conv_mfma.h): the four classes are the four N-tiles of ONE block: [n_nblk][krows][16 columns][4 classes]
 static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const srcw[4], int lstm)
 {
@@ -326,15 +350,15 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
     return out;
 }
 
-template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
+template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
-    constexpr int lds = conv_lds_bytes<NI, TW, VEC, epi_taps(EPI), ONEKB>();
+    constexpr int lds = FUSE ? 2 * conv_fuse_buf_floats<NI, TW, VEC>() * 4 : conv_lds_bytes<NI, TW, VEC, epi_taps(EPI), ONEKB>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC, ONEKB>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
     return hipGetLastError();
 }
 
@@ -411,7 +435,10 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         r = hipGetLastError();
     } else
     switch (op.epi) {
-        case EPI_LSTM: r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec); break;
+        case EPI_LSTM:
+            if (op.fused && a.up_src) r = launch_inst2<4, 16, EPI_LSTM, true, false, true>(a, grid, st);  // chain of the unpooled source in-kernel
+            else r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec);
+            break;
         case EPI_LSTM_PACKED: r = (op.TW == 16) ? launch_inst<1, 16, EPI_LSTM_PACKED>(a, grid, st, vec) : launch_inst<1, 8, EPI_LSTM_PACKED>(a, grid, st, vec); break;
         case EPI_CONVA: {
             // the image layer's ConvA (K = 9 x 6 channels): one K-block, its own instantiation (conv_mfma.h: ONEKB)
@@ -468,7 +495,7 @@ int eigen_destroy(eigen_engine* e)
     (void)hipSetDevice(e->cfg.device);
     for (int l = 0; l < e->L; ++l) {
         Layer& y = e->layer[l];
-        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw, y.lstm.d_wraw, y.convA_t0.d_wpk, y.lstm_t0.d_wpk, y.up4.d_wpk};
+        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw, y.lstm.d_wraw, y.convA_t0.d_wpk, y.lstm_t0.d_wpk, y.up4.d_wpk, y.d_upw};
         for (float* p : ptrs) if (p) (void)hipFree(p);
     }
     if (e->d_planes) (void)hipFree(e->d_planes);
@@ -660,9 +687,20 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             t0.krows = pad4(C) * 9; t0.macs = (double)y.H * y.W * 4 * C * C * 9;
             std::vector<float> pk0 = pack_weights(t0, sw, lstm_mode);
             if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, step 0)", l);
+            // The chain of the unpooled source R_{l+1}: inside the ConvLSTM kernel where its wide instantiation runs (16-wide tiles,
+            // 16-byte staging of the half-resolution rows: W % 8 == 0), otherwise a pass of its own at the source resolution
+            static const bool fuse_up = !(getenv("EIGEN_NO_FUSEUP") && atoi(getenv("EIGEN_NO_FUSEUP")));  // A/B measurements only
+            const bool fused = fuse_up && l < L - 1 && op.epi == EPI_LSTM && op.TW == 16 && (op.W % 8) == 0 && KC == 8;
+            if (fused) {
+                const int Cup = e->layer[l + 1].C;
+                std::vector<float> pf = pack_weights_upfuse(C, op.n_nblk, Cup, wx1);
+                if (upload(&y.d_upw, pf.data(), pf.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, fused unpooled source)", l);
+                const double up_macs = (double)y.H * y.W * 4 * C * Cup * 4;  // 4 taps per output pixel and channel instead of 9
+                for (ConvOp* f : {&op, &t0}) { f->fused = true; f->up_C = Cup; f->up_kb = (Cup + KC - 1) / KC; f->macs += up_macs; }
+            }
             ConvOp& u = y.up4;
             { float* k0 = u.d_wpk; u = ConvOp(); u.d_wpk = k0; }
-            if (l < L - 1) {  // R_{l+1}, at ITS resolution; columns = the ConvLSTM's
+            if (l < L - 1 && !fused) {  // R_{l+1}, at ITS resolution; columns = the ConvLSTM's
                 const Layer& yu = e->layer[l + 1];
                 u.epi = EPI_UP4; u.layer = l; u.nsrc = 1; u.src_C[0] = e->layer[l + 1].C; u.H = yu.H; u.W = yu.W; u.Cout = C;
                 u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W);
@@ -854,7 +892,10 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
                 ConvArgs a;
                 memset(&a, 0, sizeof(a));
                 int s = 0;
-                if (l < L - 1) {  // R_{l+1} of THIS step, 2x2 form -> partial chains
+                if (l < L - 1 && y.lstm.fused) {  // R_{l+1} of THIS step: its chain runs inside the ConvLSTM launch
+                    a.up_src = e->layer[l + 1].h[cur ^ 1];
+                    a.up_C = y.lstm.up_C; a.up_kb = y.lstm.up_kb; a.up_wpk = y.d_upw;
+                } else if (l < L - 1) {  // R_{l+1} of THIS step, 2x2 form -> partial chains
                     ConvArgs u;
                     memset(&u, 0, sizeof(u));
                     u.src[0].ptr = e->layer[l + 1].h[cur ^ 1];

@@ -223,7 +223,7 @@ print("FRAMES", *out)
 
 def test_specialised_operators_equal_the_general_mfma_path(cuda):
     """Every A/B switch of the engine (step-0 operators, single-K-block ConvA, one-block 2x2 pass, the two direct image-layer
-    kernels) turned off one at a time in a fresh process: all six PredNet frames of two small roll-outs are byte-identical."""
+    kernels, the in-kernel chain of the unpooled source) turned off one at a time in a fresh process: all six PredNet frames of two small roll-outs are byte-identical."""
     import subprocess
     script = _FRAMES_SCRIPT % {"root": ROOT}
 
@@ -237,5 +237,5 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
         return line[0]
 
     base = run({})
-    for switch in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA"):
+    for switch in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA", "EIGEN_NO_FUSEUP"):
         assert run({switch: "1"}) == base, switch

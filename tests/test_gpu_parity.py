@@ -133,7 +133,10 @@ def test_cppn_render_saturating_bands_byte_exact(cuda, oracle_lib, w, h, structu
 
 @pytest.mark.parametrize("w,h,ch,requant", [(64, 64, [1, 16, 32, 64], False), (48, 32, [3, 8, 16, 32], False),
                                               (80, 40, [3, 12, 20], True), (160, 120, [1, 16, 32, 64], False),
-                                              (20, 12, [1, 4, 8], False)])  # widths 20 / 10 / 5: mixed VEC and 4-byte DMA layers
+                                              (20, 12, [1, 4, 8], False),   # widths 20 / 10 / 5: mixed VEC and 4-byte DMA layers
+                                              # the unpooled source's chain INSIDE the ConvLSTM kernel (FUSE): partial last K-block
+                                              # (12 channels) with ragged tile rows (layer 1: 80 x 60 = 3.75 tiles), one-K-block source (8)
+                                              (160, 120, [1, 8, 12, 8], False), (64, 96, [1, 8, 12, 8], True)])
 def test_prednet_rollout_frames_bit_exact(cuda, oracle_lib, w, h, ch, requant):
     import torch
     from oracle import cppn
