@@ -237,5 +237,5 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
         return line[0]
 
     base = run({})
-    for switch in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA", "EIGEN_NO_FUSEUP"):
+    for switch in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA", "EIGEN_FUSEUP"):
         assert run({switch: "1"}) == base, switch
