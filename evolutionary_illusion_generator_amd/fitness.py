@@ -119,7 +119,9 @@ def _dist():
         import torch.distributed as dist
     except Exception:
         return None
-    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1) else None
+    # EIGEN_DIST_SINGLE=1: take the collective path even in a group of ONE rank (tests: RCCL on a single-GPU box)
+    min_world = 1 if os.environ.get("EIGEN_DIST_SINGLE") == "1" else 2
+    return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world) else None
 
 
 def sharded_map(n_items, evaluate, group=None, extra=None):

@@ -260,6 +260,52 @@ def test_two_ranks_over_rccl(cuda, oracle_lib, source):
     assert np.allclose(res[0][0], ref, rtol=1e-9, atol=1e-12)
 
 
+_RCCL1_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=%(port)r, RANK="0", WORLD_SIZE="1", EIGEN_DIST_SINGLE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+import numpy as np, torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from evolutionary_illusion_generator_amd import fitness as F, synth as S, weights as W
+assert F._dist() is not None and dist.get_backend() == "nccl"
+w, h, ch = 64, 64, [1, 8, 16]
+cfg = S.make_config(2, 1)
+wts = W.synthetic_prednet_weights(ch, w, h, seed=6)
+out = {}
+for source in ("rank0", "replicated"):
+    F.GENOME_SOURCE = source
+    pop = S.make_population(7, cfg, seed=12)
+    F.get_fitnesses_neat(2, pop, wts, cfg, w, h, ch, c_dim=1, best_dir=None)
+    out[source] = [g.fitness for _, g in pop]
+blob = bytes(range(256)) * 40 + b"tail"
+assert F._broadcast_bytes(blob) == blob
+v, ex = F.sharded_map(5, lambda lo, hi: np.arange(lo, hi) * 1.5, extra=7.0)
+assert v.tolist() == [0.0, 1.5, 3.0, 4.5, 6.0] and ex.tolist() == [7.0]
+dist.barrier(); dist.destroy_process_group()
+print("RCCL1", repr(out))
+"""
+
+
+def test_collective_path_on_rccl_with_one_rank(cuda, oracle_lib):
+    """The multi-rank code path (broadcast of the genome wire arrays, all-gather of the fitness scalars, barrier) on the `nccl` =
+    RCCL backend with DEVICE tensors, in a process group of ONE rank -- what a single-GPU box can exercise of it."""
+    import subprocess
+    from oracle import grids as ogrids, pipeline
+    r = subprocess.run([sys.executable, "-c", _RCCL1_SCRIPT % {"root": ROOT, "port": str(_free_port())}], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RCCL1")][-1]
+    out = eval(line[len("RCCL1 "):])
+    w, h, ch = 64, 64, [1, 8, 16]
+    cfg = synth.make_config(2, 1)
+    pop = synth.make_population(7, cfg, seed=12)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=6)
+    grid = ogrids.create_grid(2, w, h, 10)
+    ref = np.array([pipeline.genome_fitness(g, cfg, grid, wts, ch, w, h, 2) for _, g in pop])
+    assert out["rank0"] == out["replicated"]
+    assert np.allclose(out["rank0"], ref, rtol=1e-9, atol=1e-12) and (ref != 0).any()
+
+
 def test_bench_gpus_flag_launches_ranks(cuda):
     """`python bench.py --gpus N` must BE N ranks (the flag was parsed and dropped).  On a 1-GPU box: N = 1 prints
     n_gpus 1 and N = 2 refuses loudly instead of silently running one rank."""
