@@ -49,6 +49,9 @@
 
 #include <type_traits>
 
+#ifndef EIG_S8
+#define EIG_S8 16  // LDS row stride of 8-wide tiles (16-byte staging): 16 or 20, see TileGeom
+#endif
 #ifndef EIG_ABLATE
 #define EIG_ABLATE 0  // measurement-only builds (scripts/ablate_conv.py): 1 = no staging after the first K-block, 2 = ConvLSTM gate math removed
 #endif
@@ -159,10 +162,12 @@ __device__ __forceinline__ float relu_f(float v) { return v > 0.0f ? v : 0.0f; }
 template <int TW, bool VEC> struct TileGeom {
     static constexpr int TH = (TW == 16) ? 16 : 8;
     static constexpr int NIMG = 256 / (TH * TW);
-    // row stride in floats.  VEC: the aligned chunks x0-4 .. x0+TW+3 (TW + 8 floats); 8-wide tiles carry one more chunk so
-    // that 2 S = 8 (mod 32): the four window rows of a class sub-tile then start 8 banks apart (conflict-free gather; with
-    // S = 16 they would all start on the same bank).  16-wide: S = 24, 2 S = 16 (mod 32), two window rows x 8 even columns.
-    static constexpr int S = VEC ? (TW == 16 ? TW + 8 : TW + 12) : TW + 2;
+    // row stride in floats.  VEC: the aligned chunks x0-4 .. x0+TW+3 (TW + 8 floats).  16-wide: S = 24, 2 S = 16 (mod 32): the two
+    // window rows x 8 even columns of a class sub-tile cover 16 distinct banks.  8-wide: S = 16 puts the four window rows of a
+    // sub-tile on the same banks (4-way conflict on the A gather); one more chunk per row (EIG_S8 = 20: 2 S = 8 mod 32) would
+    // make it conflict-free but takes the block from 78 to 88 KB of LDS = ONE block per CU: measured 362 vs 396+ evals/s at
+    // 160x120 colour, so the conflicts are the cheaper evil (scripts/ab_bench.sh).
+    static constexpr int S = VEC ? (TW == 16 ? TW + 8 : EIG_S8) : TW + 2;
     static constexpr int XO = VEC ? 3 : 0;
     static constexpr int PH = TH + 2;
     static constexpr int PLANE = NIMG * PH * S;  // floats per channel in LDS

@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libeigen_hip.so")
+LIB_PATH = os.environ.get("EIGEN_HIP_LIB") or os.path.join(_HERE, "libeigen_hip.so")  # EIGEN_HIP_LIB: A/B builds (scripts/)
 ABI_VERSION = 2  # include/eigen_engine.h: EIGEN_ABI_VERSION
 MAX_LAYERS = 8
 
