@@ -687,14 +687,17 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             t0.krows = pad4(C) * 9; t0.macs = (double)y.H * y.W * 4 * C * C * 9;
             std::vector<float> pk0 = pack_weights(t0, sw, lstm_mode);
             if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, step 0)", l);
-            // The chain of the unpooled source R_{l+1}: a pass of its own at the source resolution (EPI_UP4), or -- EIGEN_FUSEUP=1 --
-            // inside the ConvLSTM kernel where its wide instantiation runs (16-wide tiles, 16-byte staging of the half-resolution
-            // rows: W % 8 == 0).  Same chain, bit for bit.  Measured on one box, 256^2 colour, 256 genomes (scripts/ab_bench.sh,
-            // profiles/r02_b_ab_fuseup.txt): in-kernel 177.9 evals/s, own pass 178.6 -- the in-kernel K-blocks stage the weights of
-            // all four parity classes (32 KB per 128 MFMAs of a wave: 10 LDS-DMA instructions and four ds_read_b128 per step against 9
-            // per 288 MFMAs and one), which costs what the pass's prologue / epilogue and its 6 GB round trip per layer-1 step save.
-            // The default is the faster one; the in-kernel form halves the partial-chain workspace (3.2 -> 1.1 GB) and removes 42 launches.
-            static const bool fuse_up = getenv("EIGEN_FUSEUP") && atoi(getenv("EIGEN_FUSEUP"));
+            // The chain of the unpooled source R_{l+1}: a pass of its own at the source resolution (EPI_UP4), or inside the ConvLSTM
+            // kernel where its wide instantiation runs (conv_mfma.h: FUSE; 16-wide tiles, 16-byte staging of the half-resolution
+            // rows: W % 8 == 0).  Same chain, bit for bit.  Measured (scripts/ab_bench.sh, profiles/r02_b_ab_fuseup.txt): at 256^2
+            // colour the own pass wins by 0.3-0.4 % at every device batch 32..256 (in-kernel K-blocks stage the weights of all four
+            // parity classes: 10 LDS-DMA instructions and four ds_read_b128 per step against 9 per 18 steps and one, which costs what
+            // the pass's prologue / epilogue and its round trip save); where the pass is a SHORT kernel its fixed costs dominate and
+            // the in-kernel form wins: 160x120 colour pop 50 +2.3 %, 160x120 gray +5 %.  Hence: in-kernel iff the pass would
+            // execute < 2.5e10 multiply-adds per launch at this engine's device batch (~0.35 ms); EIGEN_FUSEUP=0 / 1 force it.
+            static const int fuse_env = getenv("EIGEN_FUSEUP") ? atoi(getenv("EIGEN_FUSEUP")) : -1;
+            const double pass_macs = l < L - 1 ? (double)e->B * y.H * y.W * 4 * C * e->layer[l + 1].C * 4 : 0;
+            const bool fuse_up = fuse_env >= 0 ? fuse_env != 0 : pass_macs < 2.5e10;
             const bool fused = fuse_up && l < L - 1 && op.epi == EPI_LSTM && op.TW == 16 && (op.W % 8) == 0 && KC == 8;
             if (fused) {
                 const int Cup = e->layer[l + 1].C;

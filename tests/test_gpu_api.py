@@ -239,3 +239,4 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
     base = run({})
     for switch in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA", "EIGEN_FUSEUP"):
         assert run({switch: "1"}) == base, switch
+    assert run({"EIGEN_FUSEUP": "0"}) == base  # these small roll-outs take the in-kernel chain by default: the separate pass

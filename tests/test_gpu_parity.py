@@ -140,8 +140,8 @@ def test_cppn_render_saturating_bands_byte_exact(cuda, oracle_lib, w, h, structu
 def test_prednet_rollout_frames_bit_exact(cuda, oracle_lib, w, h, ch, requant, monkeypatch):
     import torch
     if ch == [1, 8, 12, 8]:
-        # the in-kernel form of the unpooled source's chain (conv_mfma.h: FUSE) is opt-in; the switch is read when the weights
-        # are set, so a fresh engine in this process picks it up only if no engine read it before -> run these cases in a child
+        # the in-kernel form of the unpooled source's chain (conv_mfma.h: FUSE) is chosen automatically for short passes; force it
+        # here (the switch is read once per process, when the first weights are set -> a child process)
         import os, subprocess, sys
         if os.environ.get("EIGEN_FUSEUP") != "1":
             env = dict(os.environ, EIGEN_FUSEUP="1")
