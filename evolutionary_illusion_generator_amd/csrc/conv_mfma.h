@@ -49,6 +49,9 @@
 
 #include <type_traits>
 
+#ifndef EIG_KLOOP_PRIO
+#define EIG_KLOOP_PRIO 0  // s_setprio level of a wave while it is inside the K loop (0: none)
+#endif
 #ifndef EIG_S8
 #define EIG_S8 16  // LDS row stride of 8-wide tiles (16-byte staging): 16 or 20, see TileGeom
 #endif
@@ -511,6 +514,11 @@ conv3x3_mfma(const ConvArgs a)
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     const unsigned long long t_prewait = EIG_TIMING ? __builtin_readcyclecounter() : 0;  // first K-block issued, gather addresses ready
+#if EIG_KLOOP_PRIO
+    // A wave inside the K loop outranks its SIMD partner (the other block's wave) while that one is in its VALU-dense prologue or
+    // epilogue: the arbitration between the two is by priority, then age (MI355X_MICROARCH.md, "Two waves per SIMD")
+    __builtin_amdgcn_s_setprio(EIG_KLOOP_PRIO);
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -697,6 +705,9 @@ conv3x3_mfma(const ConvArgs a)
         if (has_up) { kiter(0, std::true_type{}); kb_begin = 1; }
     }
     for (int kb = kb_begin; kb < nkb; ++kb) kiter(kb, std::false_type{});
+#if EIG_KLOOP_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     const unsigned long long t_loop1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
 
     // ---------------------------------------------------------------- epilogue
