@@ -137,6 +137,8 @@ def sharded_map(n_items, evaluate, group=None, extra=None):
     R, r = dist.get_world_size(group), dist.get_rank(group)
     lo, hi, per = shard_bounds(n_items, R, r)
     slot = per + (1 if extra is not None else 0)
+    if slot == 0:  # an empty population: nothing to exchange (every rank sees the same n_items)
+        return np.zeros(0, dtype=np.float64)
     local = np.zeros(slot, dtype=np.float64)
     if hi > lo:
         local[:hi - lo] = evaluate(lo, hi)
