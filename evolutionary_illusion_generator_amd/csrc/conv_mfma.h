@@ -49,6 +49,16 @@
 
 #include <type_traits>
 
+// s_setprio level of a wave in its PROLOGUE / EPILOGUE (0: none).  Same-box A/Bs at 256^2 colour, 256 genomes
+// (profiles/r02_b_ab_fuseup.txt): prologue at 1 -> +0.4..0.5 % (a young wave's ~400 prologue instructions took 19K cycles beside
+// the old partner wave's MFMA stream, scripts/timeline.py; outranking it gets the wave into its own K loop sooner), at 2 or 3 the
+// same or less; the epilogue at 1 -> nothing; the K loop at 1 or 3 -> -0.5 % (EIG_KLOOP_PRIO).
+#ifndef EIG_PRO_PRIO
+#define EIG_PRO_PRIO 1
+#endif
+#ifndef EIG_EPI_PRIO
+#define EIG_EPI_PRIO 0
+#endif
 #ifndef EIG_KLOOP_PRIO
 #define EIG_KLOOP_PRIO 0  // s_setprio level of a wave while it is inside the K loop (0: none)
 #endif
@@ -248,6 +258,12 @@ conv3x3_mfma(const ConvArgs a)
     constexpr int TAPS = epi_taps(EPI);
     static_assert(EPI != EPI_UP4C || NI == 4, "EPI_UP4C: the four N-tiles are the four parity classes");
     const unsigned long long t_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;
+#if EIG_PRO_PRIO
+    // Prologue and epilogue outrank the SIMD partner's K loop: the two waves of a SIMD (one per resident block) are arbitrated by
+    // priority, then age, and a young wave's ~400 prologue instructions were taking 19K cycles beside an old wave's MFMA stream
+    // (scripts/timeline.py) -- time during which the matrix pipe has ONE wave feeding it
+    __builtin_amdgcn_s_setprio(EIG_PRO_PRIO);
+#endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool FAST = conv_fast_dma<NI, TW, VEC>();
     constexpr int INF = conv_in_floats<NI, TW, VEC>();  // floats of the input area (KC * PLANE, padded for FAST)
@@ -515,9 +531,11 @@ conv3x3_mfma(const ConvArgs a)
 
     const unsigned long long t_prewait = EIG_TIMING ? __builtin_readcyclecounter() : 0;  // first K-block issued, gather addresses ready
 #if EIG_KLOOP_PRIO
-    // A wave inside the K loop outranks its SIMD partner (the other block's wave) while that one is in its VALU-dense prologue or
-    // epilogue: the arbitration between the two is by priority, then age (MI355X_MICROARCH.md, "Two waves per SIMD")
+    // (tried: a wave inside the K loop outranking its SIMD partner -- 0.5 % slower: it starves the partner's prologue / epilogue)
     __builtin_amdgcn_s_setprio(EIG_KLOOP_PRIO);
+#endif
+#if EIG_PRO_PRIO
+    __builtin_amdgcn_s_setprio(0);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -707,6 +725,9 @@ conv3x3_mfma(const ConvArgs a)
     for (int kb = kb_begin; kb < nkb; ++kb) kiter(kb, std::false_type{});
 #if EIG_KLOOP_PRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
+#if EIG_EPI_PRIO
+    __builtin_amdgcn_s_setprio(EIG_EPI_PRIO);
 #endif
     const unsigned long long t_loop1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
 
