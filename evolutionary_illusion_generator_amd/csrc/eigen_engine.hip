@@ -1289,7 +1289,7 @@ struct FlattenScratch {
         auto span = [&](const int32_t* p, int n) { for (int i = 0; i < n; ++i) { if (first) { lo = hi = p[i]; first = false; } lo = std::min(lo, (int)p[i]); hi = std::max(hi, (int)p[i]); } };
         span(in_keys, n_in); span(out_keys, n_out); span(nk, n_nodes); span(ci_, nc); span(co_, nc);
         const long range = (long)hi - lo + 1;
-        direct = range <= (1L << 22);
+        direct = range <= (1L << 18);  // 2 MB of tables at most; NEAT keys grow by one per added node
         if (direct) {
             kmin = lo; n_ids = 0;
             if ((long)dstamp.size() < range) { dstamp.assign(range, 0); dmap.resize(range); epoch = 0; }

@@ -138,6 +138,21 @@ def test_native_flattening_is_the_python_specification():
             assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y), (seed, k)
         n_checked += len(gs)
     assert n_checked == 720
+    # keys spread over a huge range (the library's sorted-table fallback instead of its direct id table)
+    cfg = synth.make_config(2, 3)
+    gs = [g for _, g in synth.make_population(20, cfg, seed=9, num_hidden=12)]
+    for g in gs:
+        far = lambda k: k + (1 << 20) * (k % 5) if k >= 3 else k      # hidden keys only; inputs (< 0) and outputs (0..2) stay
+        g.nodes = {far(k): n for k, n in g.nodes.items()}
+        for n_key, n in g.nodes.items():
+            n.key = n_key
+        g.connections = {(far(a), far(b)): c for (a, b), c in g.connections.items()}
+        for key, c in g.connections.items():
+            c.key = key
+    a = genome.GenomeBatch(gs, cfg, 3, native=True)
+    b = genome.GenomeBatch(gs, cfg, 3, native=False)
+    for k in fields:
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
     cfg = synth.make_config(2, 1)
     bad = synth.make_genome(1, cfg, 0)
     bad.nodes[0].activation = "cube"
