@@ -390,3 +390,21 @@ def test_get_fitnesses_neat_contract_single_process(monkeypatch):
     fitness.get_fitnesses_neat(1, pop, "synthetic", cfg, 64, 64, [1, 4, 8], c_dim=1, best_dir=".")
     assert [g.fitness for _, g in pop] == vals.tolist() and all(isinstance(g.fitness, float) for _, g in pop)
     assert saved["best"] is pop[3][1]  # '>=': the LAST maximal genome wins (generate_illusion.py:625)
+
+
+def test_bench_refuses_what_it_cannot_launch():
+    """bench.py --gpus N must BE N ranks: without N visible GPUs, or joined under a launcher with another world size, it says so
+    and exits non-zero (the flag used to be parsed and dropped).  No GPU needed for the refusals."""
+    import subprocess
+    import torch
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    bench = os.path.join(ROOT, "bench.py")
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "GPU(s) visible" in (r.stdout + r.stderr)
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--steps", "1", "--warmup", "0"], env=dict(env, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
+    import bench as B
+    assert len(B.kernel_sources_sha()) == 16 and B.kernel_sources_sha() == B.kernel_sources_sha()
+    assert set(B.SHAPES) == {"headline", "ref160", "c2", "c4", "c5"} and B.SHAPES["headline"][:2] == (256, 256) and B.SHAPES["headline"][7] == 256
