@@ -8,7 +8,7 @@ BASELINE.json configs[2]: neat_configs/circles.txt (num_hidden 20, 3 outputs), c
 structure, 256x256, ONE population of 256 genomes.  Data: seeded synthetic genomes and seeded synthetic PredNet weights
 (the trained weights are external downloads and fix the size to 160x120).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--weak] [--no-cpu-baseline] [--no-roofline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--weak] [--no-cpu-baseline] [--no-roofline] [--no-parity] [--no-supplementary]
 
 --gpus N > 1 without a torch.distributed environment re-executes itself under
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU, backend
@@ -19,7 +19,10 @@ Scaling: the metric names ONE population of 256, so for N > 1 that population is
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel: the fused
 ConvLSTM 3x3 convolution on the fp32 MFMA pipe, timed live with HIP events on its launch stream), `roofline_hbm` (the two
 HBM-side stages: CPPN render and the flow stencils) and `cpu_baseline` (the CPU oracle's path -- numpy CPPN + torch-CPU fp32
-PredNet + C Lucas-Kanade + numpy scores -- on a bounded sample of >= 8 genomes).
+PredNet + C Lucas-Kanade + numpy scores -- on a bounded sample of >= 8 genomes at the best of a small thread sweep),
+`parity_check` (genome 0 against the bit-exact C oracle; ALL genomes of the population classified against the reference's
+element-wise order, oracle/classify.py) and `supplementary` (the other BASELINE.json configs, a few seconds each, never part
+of `value`).  All of these legs run AFTER the timed region, on rank 0 only.
 """
 import argparse
 import hashlib
@@ -35,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
+LSTM_KERNEL_TAG = "conv3x3_mfma<4, 16, 1"  # the dominant kernel's name in rocprofv3 output (EPI_LSTM = 1)
 N_STEPS_PREDNET = 21          # steps 1-20 + first extension (the 22nd step is never read on the population path)
 
 SHAPES = {
@@ -73,8 +77,11 @@ def git_head():
         return None
 
 
-def cpu_baseline(cfg, pop, wts, grid, shape, min_genomes=8, seconds_budget=30.0):
-    """The oracle's CPU path on a bounded sample of the same workload (rank 0, N = 1 only), with a per-stage split."""
+def cpu_baseline(cfg, pop, wts, grid, shape, min_genomes=8, seconds_budget=30.0, flops_per_genome=None):
+    """The oracle's CPU path on a bounded sample of the same workload (rank 0, N = 1 only), with a per-stage split.
+    The PredNet leg (99 % of it) is torch-CPU / oneDNN; its thread count is the best of a small sweep on 2 genomes each
+    (batch-1 convolutions on a 256-CPU host are slower on 128 threads than on 32: VERDICT r2), and the >= 8-genome measurement
+    runs at that setting."""
     import numpy as np
     import torch
     from oracle import pipeline, scores
@@ -82,7 +89,21 @@ def cpu_baseline(cfg, pop, wts, grid, shape, min_genomes=8, seconds_budget=30.0)
     import oracle
     W, H, CHANNELS, C_DIM, STRUCTURE = shape[:5]
     net = PredNetTorch(wts, CHANNELS, W, H)
-    threads = torch.get_num_threads()
+    default_threads = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
+    imgs = [pipeline.render_chw(pop[i][1], cfg, grid, C_DIM, W, H) for i in range(2)]
+    net.rollout(imgs[0][None], n_repeat=1, n_ext=0)  # primitive creation is not part of anyone's measurement
+    sweep = {}
+    for th in sorted({t for t in (8, 32, 128) if t <= ncpu} or {default_threads}):
+        torch.set_num_threads(th)
+        t0 = time.time()
+        for im in imgs:
+            net.rollout(im[None], n_repeat=20, n_ext=1)
+        sweep[th] = (time.time() - t0) / len(imgs)
+        if sweep[th] > 3.0 * min(sweep.values()):
+            break  # clearly past the optimum: do not spend the budget there
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     done, t0 = 0, time.time()
     fits, split = [], {"render_s": 0.0, "prednet_s": 0.0, "flow_s": 0.0, "score_s": 0.0}
     while done < len(pop) and (done < min_genomes or time.time() - t0 < seconds_budget):
@@ -100,11 +121,47 @@ def cpu_baseline(cfg, pop, wts, grid, shape, min_genomes=8, seconds_budget=30.0)
             split[k] += d
         done += 1
     dt = time.time() - t0
-    return {"value": done / dt, "unit": "genome evals/s", "cores": threads, "kind": "port",
-            "host_cpus": os.cpu_count(), "genomes": done, "seconds": dt,
-            "per_stage_s_per_genome": {k: v / done for k, v in split.items()},
-            "sample": "%d genomes of the same %dx%d population, full path (numpy float64 CPPN 1 thread, torch-CPU/oneDNN fp32 "
-                      "PredNet 21 steps on %d threads, C Lucas-Kanade 1 thread, numpy scores), %.1f s" % (done, W, H, threads, dt)}, fits
+    torch.set_num_threads(default_threads)
+    out = {"value": done / dt, "unit": "genome evals/s", "cores": threads, "kind": "port",
+           "host_cpus": ncpu, "genomes": done, "seconds": dt,
+           "per_stage_s_per_genome": {k: v / done for k, v in split.items()},
+           "thread_sweep_prednet_s_per_genome": {str(k): round(v, 3) for k, v in sweep.items()},
+           "sample": "%d genomes of the same %dx%d population, full path (numpy float64 CPPN 1 thread, torch-CPU/oneDNN fp32 "
+                     "PredNet 21 steps on %d threads = best of the sweep %s, C Lucas-Kanade 1 thread, numpy scores), %.1f s"
+                     % (done, W, H, threads, sorted(sweep), dt)}
+    if flops_per_genome:
+        out["prednet_gflops"] = flops_per_genome / (split["prednet_s"] / done) / 1e9  # the reference's 9-tap formulation
+    return out, fits
+
+
+def classify_population(eng, fitness_mod, genomes, cfg, wts, shape, n_max=256, batch=8):
+    """north_star's "within 1e-4 relative" as a property checked for EVERY genome of the benchmark population (untimed leg):
+    the HIP path's frames / vectors / fitness against the reference's element-wise order (chainer ConvLSTM: separate
+    convolution tensors added left to right, un-fused gate products, sigmoid = tanh(x/2)/2 + 1/2, plain unpool -> 9-tap)
+    with im2col + rocBLAS matmul convolutions on the GPU; Lucas-Kanade and scores of that side by the C / numpy oracle.
+    oracle/classify.py: a genome outside 1e-4 must be reproduced by ONE +-1 byte flip applied to the HIP path's own frames."""
+    import numpy as np
+    import torch
+    from evolutionary_illusion_generator_amd import genome as genome_mod
+    from oracle import classify
+    from oracle.prednet_torch import PredNetTorch
+    W, H, CHANNELS, C_DIM, STRUCTURE = shape[:5]
+    n = min(n_max, len(genomes), eng.max_batch)
+    t0 = time.time()
+    gb = genome_mod.GenomeBatch(genomes[:n], cfg, C_DIM, n_leaves=len(cfg.genome_config.input_keys))
+    d_img = torch.empty((n, C_DIM, H, W), dtype=torch.uint8, device="cuda")
+    eng.render_cppn(gb, d_img)
+    fit, vecs = eng.eval_images(d_img, n, STRUCTURE, pairing=0)
+    d_fr = torch.empty((n, 2, C_DIM, H, W), dtype=torch.uint8, device="cuda")
+    eng.prednet_rollout(d_img, n, 21, 19, d_fr)
+    torch.cuda.synchronize()
+    imgs, frames = d_img.cpu().numpy(), d_fr.cpu().numpy()
+    torch.backends.cuda.matmul.allow_tf32 = False
+    net = PredNetTorch(wts, CHANNELS, W, H, device="cuda", conv="matmul", order="chainer")
+    summ, _ = classify.population_report(STRUCTURE, W, H, imgs, frames, vecs, fit, net, batch=batch)
+    summ["against"] = "reference element-wise order (chainer ConvLSTM.__call__), im2col + rocBLAS fp32 matmul on the GPU; C Lucas-Kanade + numpy scores"
+    summ["seconds"] = time.time() - t0
+    return summ, fit
 
 
 def respawn_under_torchrun(n):
@@ -120,6 +177,60 @@ def respawn_under_torchrun(n):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def conv_roofline(eng, fitness_mod, workload, nb):
+    """Per-launch HIP-event timing of every conv kernel of one more roll-out pass (events on the launch stream) ->
+    (rows, dominant-kernel summary, all-conv summary)."""
+    STRUCTURE, genomes, wts, cfg, W, H, CHANNELS, C_DIM, max_batch = workload
+    eng.conv_profile(True, reset=True)
+    fitness_mod.evaluate_population(STRUCTURE, genomes[:nb], wts, cfg, W, H, CHANNELS, c_dim=C_DIM, gradient=1, max_batch=max_batch)
+    rows = eng.conv_profile(False, reset=True)
+    all_fl = sum(r["flops_per_image"] * nb * r["launches"] for r in rows)
+    all_ms = sum(r["ms"] for r in rows)
+    allc = {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "frac": all_fl / (all_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+            "total_ms": all_ms, "launches": sum(r["launches"] for r in rows)}
+    return rows, all_fl, allc
+
+
+def make_workload(shape_name, global_pop):
+    from evolutionary_illusion_generator_amd import synth, weights
+    W, H, CHANNELS, C_DIM, STRUCTURE, n_hidden, n_outputs, _, _ = SHAPES[shape_name]
+    cfg = synth.make_config(2, n_outputs)
+    population = synth.make_population(global_pop, cfg, seed=0, num_hidden=n_hidden)  # identical on every rank (seeded)
+    wts = weights.synthetic_prednet_weights(CHANNELS, W, H, seed=0)
+    return cfg, population, wts
+
+
+def supplementary_shape(name, pop, steps, warmup=1):
+    """One of the other BASELINE.json configurations, single GPU, a few seconds: evals/s through the same drop-in path and the
+    all-conv roofline fraction of one profiled pass.  Never part of `value`."""
+    import torch
+    from evolutionary_illusion_generator_amd import fitness
+    W, H, CHANNELS, C_DIM, STRUCTURE, _, _, default_pop, label = SHAPES[name]
+    cfg, population, wts = make_workload(name, pop)
+    genomes = [g for _, g in population]
+    max_batch = min(pop, 256)
+    eng = fitness.get_engine(wts, W, H, CHANNELS, max_batch=max_batch)
+    run = lambda: fitness.population_fitness(STRUCTURE, genomes, wts, cfg, W, H, CHANNELS, c_dim=C_DIM, gradient=1, max_batch=max_batch)
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fit = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nb = min(max_batch, pop)
+    _, all_fl, allc = conv_roofline(eng, fitness, (STRUCTURE, genomes, wts, cfg, W, H, CHANNELS, C_DIM, max_batch), nb)
+    flops_ref = eng.flops_per_step() * N_STEPS_PREDNET
+    out = {"workload": "%s pop=%d, %dx%d, PredNet %s, %s score%s" % (label, pop, W, H, ",".join(map(str, CHANNELS)), SCORE_NAMES[STRUCTURE],
+                                                                    "" if pop == default_pop else " (config pop %d: device-batch sample)" % default_pop),
+           "value": pop * steps / dt, "unit": "genome evals/s", "steps": steps, "ms_per_step": 1e3 * dt / steps, "device_batch": max_batch,
+           "nonzero_fitness": int((fit != 0).sum()),
+           "all_conv_frac": allc["frac"], "all_conv_tflops": allc["achieved"], "conv_launches": allc["launches"],
+           "effective_tflops_reference_formulation": flops_ref * pop * steps / dt / 1e12}
+    return out
 
 
 def main():
@@ -139,6 +250,8 @@ def main():
     ap.add_argument("--source", default=None, choices=["rank0", "replicated"], help="multi-rank genome source (fitness.GENOME_SOURCE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity legs (C-oracle spot check, whole-population classification)")
+    ap.add_argument("--no-supplementary", action="store_true", help="skip the untimed supplementary block (ref160, c2, c4, c5 at a device-batch sample)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -155,8 +268,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     import torch.distributed as dist
-    if world > 1:
+    # EIGEN_DIST_SINGLE=1 (tests): take the whole multi-rank path -- RCCL group, broadcast, all-gather, per-rank report, leaving the
+    # group before rank 0's untimed legs -- in a group of ONE rank, which is all a single-GPU box can run of it
+    use_dist = world > 1 or os.environ.get("EIGEN_DIST_SINGLE") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1 and "MASTER_PORT" not in os.environ:
+            s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         assert dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus
 
@@ -164,19 +282,19 @@ def main():
     W, H, CHANNELS, C_DIM, STRUCTURE, n_hidden, n_outputs, default_pop, label = shape
     supplementary = args.shape != "headline" or args.flow != "lk" or args.weak
     if supplementary:
-        args.no_cpu_baseline = True  # supplementary numbers: no CPU leg
+        args.no_cpu_baseline = args.no_parity = args.no_supplementary = True  # supplementary numbers: no CPU / parity legs
     pop_arg = args.pop or default_pop
+    if pop_arg != default_pop:
+        args.no_supplementary = True
     global_pop = pop_arg * world if args.weak else pop_arg
     per_rank = -(-global_pop // world)
     max_batch = min(per_rank, 256)
 
-    from evolutionary_illusion_generator_amd import fitness, grids, synth, weights
+    from evolutionary_illusion_generator_amd import fitness, grids
     if args.flow != "lk":
         fitness.FLOW_METHOD = args.flow
-    cfg = synth.make_config(2, n_outputs)
-    population = synth.make_population(global_pop, cfg, seed=0, num_hidden=n_hidden)  # identical on every rank (seeded)
+    cfg, population, wts = make_workload(args.shape, global_pop)
     genomes = [g for _, g in population]
-    wts = weights.synthetic_prednet_weights(CHANNELS, W, H, seed=0)
     eng = fitness.get_engine(wts, W, H, CHANNELS, max_batch=max_batch, **({} if args.flow == "lk" else {"flow": args.flow}))
 
     def step():
@@ -184,7 +302,7 @@ def main():
                                           max_batch=max_batch, source=args.source)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -192,14 +310,31 @@ def main():
         step()
     fence()
     t0 = time.perf_counter()
+    shard_stats = []
     for _ in range(args.steps):
         fit = step()
+        if use_dist:
+            shard_stats.append(dict(fitness.LAST_SHARD_STATS))
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    multi = None
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        # what every rank spent inside its shard's evaluate() (rode in the fitness all-gather itself) and what the collective cost here:
+        # a straggling GPU shows as max >> min, a slow collective as collective_ms; averaged over the timed steps
+        loc = np.asarray([s_["local_ms"] for s_ in shard_stats], dtype=np.float64).mean(axis=0)
+        multi = {"per_rank_device_ms": [round(float(x), 3) for x in loc], "device_ms_max": float(loc.max()), "device_ms_min": float(loc.min()),
+                 "collective_ms_rank0": float(np.mean([s_["collective_ms"] for s_ in shard_stats])),
+                 "note": "per-rank evaluate() wall time of its shard (flatten/slice + render + roll-out + flow + score + D2H), mean over the timed "
+                         "steps; collective_ms = rank 0's all-gather incl. its wait for the slowest rank"}
+        # Everything below is rank 0's untimed reporting: leave the process group TOGETHER now, so that no rank sits in a
+        # collective (with its watchdog) while rank 0 profiles -- the other ranks are done.
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank != 0:
+            return
     stage = eng.timings()
 
     out = {
@@ -217,24 +352,21 @@ def main():
                    "channels": CHANNELS, "structure": STRUCT_NAMES[STRUCTURE],
                    "parallelism": "pop-shard x%d (%s) + all-gather(fitness f64, %s)" % (
                        world, "genome wire arrays broadcast from rank 0" if (args.source or fitness.GENOME_SOURCE) == "rank0" else "replicated seeded populations",
-                       "RCCL" if world > 1 else "single process")},
+                       "RCCL" if use_dist else "single process")},
         "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items() if k.endswith("_ms") and k != "conv_ms"},
         "nonzero_fitness": int((fit != 0).sum()),
         "commit": git_head(), "kernel_sources_sha": kernel_sources_sha(),
     }
+    if multi:
+        out["multi_gpu"] = multi
 
-    if rank == 0 and not args.no_roofline:
+    if not args.no_roofline:
         nb = min(max_batch, len(genomes))
-        # per-launch HIP-event timing of every conv kernel of one more roll-out pass (events on the launch stream)
-        eng.conv_profile(True, reset=True)
-        fitness.evaluate_population(STRUCTURE, genomes[:nb], wts, cfg, W, H, CHANNELS, c_dim=C_DIM, gradient=1, max_batch=max_batch)
-        rows = eng.conv_profile(False, reset=True)
+        rows, all_fl, allc = conv_roofline(eng, fitness, (STRUCTURE, genomes, wts, cfg, W, H, CHANNELS, C_DIM, max_batch), nb)
         lstm = [r for r in rows if r["epi"] == "lstm" and r["NI"] == 4]
         fl = sum(r["flops_per_image"] * nb * r["launches"] for r in lstm)
         ms = sum(r["ms"] for r in lstm)
         n_l = sum(r["launches"] for r in lstm)
-        all_fl = sum(r["flops_per_image"] * nb * r["launches"] for r in rows)
-        all_ms = sum(r["ms"] for r in rows)
         ach = fl / (ms * 1e-3) / 1e12
         # HBM traffic per launch of the same kernel: rocprofv3 --pmc passes cannot be collected from inside this process
         # (separate runs of this command: scripts/pmc_passes.sh + scripts/summarize_pmc.py; FETCH_SIZE doubled as
@@ -251,7 +383,7 @@ def main():
                 traffic_note = "PMC summary is for a device batch of %s genomes, this run uses %d: not reported" % (pm.get("pop"), nb)
             else:
                 for kname, kv in pm["kernels"].items():
-                    if "conv3x3_mfma<4, 16, 1" in kname:
+                    if LSTM_KERNEL_TAG in kname:
                         traffic = kv.get("hbm_read_bytes_per_launch", 0.0) + kv.get("hbm_write_bytes_per_launch", 0.0)
         except Exception as e:  # noqa: BLE001
             traffic_note = "no PMC summary: %s" % e
@@ -266,48 +398,65 @@ def main():
                            "algorithmic_flops_reference_per_genome": flops_step * N_STEPS_PREDNET,
                            "executed_flops_per_genome": all_fl / nb,
                            "effective_tflops_reference_formulation": flops_step * N_STEPS_PREDNET * out["value"] / 1e12,
-                           "all_conv_kernels": {"achieved": all_fl / (all_ms * 1e-3) / 1e12, "frac": all_fl / (all_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                                "total_ms": all_ms, "launches": sum(r["launches"] for r in rows)},
+                           "all_conv_kernels": allc,
                            "per_op": [{"layer": r["layer"], "op": r["epi"] + ("(step 0: zero sources skipped)" if r.get("step0") else ""), "ms": round(r["ms"], 3), "launches": r["launches"],
                                        "tflops": (r["flops_per_image"] * nb * r["launches"] / (r["ms"] * 1e-3) / 1e12) if r["ms"] > 0 else 0.0}
                                       for r in rows if r["launches"] > 0]}
-        # The two HBM-side stages (SURVEY 8(d) "report both"): algorithmic bytes / HIP-event time of the stage / 8 TB/s.
+        # The two HBM-side stages (SURVEY 8(d) "report both"): algorithmic bytes / HIP-event time of the stage / 8 TB/s -- and the
+        # bound that actually binds them, which is not HBM: both move ~1 MB per genome.
         N = W * H
         n_in = 2
         render_bytes = nb * (C_DIM * N + n_in * N * 8)        # uint8 planes out + the float64 coordinate planes read per genome block
         flow_bytes = nb * int(2 * N * (1 + 0.25 + 1.0 / 16) * (1 + 2 * 2))  # 2 gray frames x 3 pyramid levels x (u8 + 2 x i16 derivatives)
         st = eng.timings()
         hb = []
-        for name, b, msk in (("cppn_render_kernel (a2+a3)", render_bytes, "render_ms"), ("flow stage: gray, pyrDown, Scharr, min-eig, corner select, LK track (a6)", flow_bytes, "flow_ms")):
+        for name, b, msk, binds in (
+                ("cppn_render_kernel (a2+a3)", render_bytes, "render_ms",
+                 "fp64 VALU: ~25 nodes x (fdlibm exp / Cephes tanh, sin in float64, ~60-150 fp64 ops each) per pixel and genome; one pass over 1.25 MB per genome"),
+                ("flow stage: gray, pyrDown, Scharr, min-eig, corner select, LK track (a6)", flow_bytes, "flow_ms",
+                 "latency: one workgroup per image in corner_select_kernel (greedy min-distance selection is sequential in the corner rank) "
+                 "and mineig_kernel; 10 dependent launches over 0.9 MB per genome")):
             t_ms = st[msk]
             a_ = b / (t_ms * 1e-3) / 1e12 if t_ms > 0 else 0.0
-            hb.append({"bound": "hbm", "kernel": name, "algorithmic_bytes": b, "ms": t_ms, "achieved": a_, "peak": PEAK_HBM_TBS,
-                       "unit": "TB/s", "frac": a_ / PEAK_HBM_TBS})
+            hb.append({"bound": "hbm", "binding_bound": binds, "kernel": name, "algorithmic_bytes": b, "ms": t_ms, "achieved": a_, "peak": PEAK_HBM_TBS,
+                       "unit": "TB/s", "frac": a_ / PEAK_HBM_TBS, "share_of_generation": t_ms / out["ms_per_step"]})
         out["roofline_hbm"] = hb
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    grid = None
+    if world == 1 and not args.no_cpu_baseline:
         grid = grids.create_grid(STRUCTURE, W, H, 10)
-        cb, cpu_fit = cpu_baseline(cfg, population, wts, grid, shape)
+        cb, cpu_fit = cpu_baseline(cfg, population, wts, grid, shape, flops_per_genome=eng.flops_per_step() * N_STEPS_PREDNET)
         out["cpu_baseline"] = cb
         out["gpu_over_cpu"] = out["value"] / cb["value"]
-        # parity spot check at the FULL size against the bit-exact C oracle (one genome, ~20 s of CPU) and against the
-        # independently ordered torch-CPU PredNet of the CPU leg (north_star: 1e-4 relative)
+    if world == 1 and not args.no_parity:
+        # (a) genome 0 at the FULL size against the bit-exact C oracle (~20 s of CPU): the canonical arithmetic, bit for bit
         from oracle import pipeline
+        grid = grid or grids.create_grid(STRUCTURE, W, H, 10)
         t1 = time.time()
         ref0 = pipeline.genome_fitness(genomes[0], cfg, grid, wts, CHANNELS, W, H, STRUCTURE)
-        cpu_fit = np.asarray(cpu_fit)
-        gpu_s = fit[:len(cpu_fit)]
-        rel = np.abs(gpu_s - cpu_fit) / np.maximum(np.abs(cpu_fit), 1e-300)
-        rel[(cpu_fit == 0) & (gpu_s == 0)] = 0.0
         out["parity_check"] = {"genome": 0, "gpu": float(fit[0]), "oracle_c": float(ref0),
                                "rel_err": float(abs(fit[0] - ref0) / max(abs(ref0), 1e-300)) if ref0 != 0 else float(abs(fit[0])),
-                               "torch_cpu_sample": [float(x) for x in cpu_fit], "gpu_sample": [float(x) for x in gpu_s],
-                               "max_rel_err_vs_independent_order": float(rel.max()) if len(rel) else None,
                                "oracle_seconds": time.time() - t1}
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()  # rank 0 is still in its (untimed) roofline pass: leave together
-        dist.destroy_process_group()
+        # (b) EVERY genome of the population against the reference's element-wise order (north_star: 1e-4 relative)
+        summ, fit2 = classify_population(eng, fitness, genomes, cfg, wts, shape)
+        assert np.array_equal(fit2, fit[:len(fit2)]), "the staged entry points and the fused population path disagree"
+        out["parity_check"]["population_vs_reference_order"] = summ
+    if world == 1 and not args.no_supplementary:
+        # the other BASELINE.json configurations, same process, a few seconds each (driver-visible numbers)
+        sup = {}
+        fitness.clear_engines()
+        torch.cuda.empty_cache()
+        for name, pop_s, steps_s, key in (("ref160", 50, 10, "ref160 (the reference's own default shape, pop 50)"), ("c2", 50, 20, "configs[1]"),
+                                          ("c4", 512, 2, "configs[3] (single-GPU: two device batches of 256)"), ("c5", 64, 2, "configs[4] (single-GPU sample: one device batch of 64)")):
+            try:
+                r = supplementary_shape(name, pop_s, steps_s)
+                r["config"] = key
+                sup[name] = r
+            except Exception as e:  # noqa: BLE001  (a supplementary failure must not cost the headline line)
+                sup[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+            fitness.clear_engines()
+            torch.cuda.empty_cache()
+        out["supplementary"] = sup
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":

@@ -14,25 +14,38 @@
  *                .nodes {key: gene(.bias, .response, .activation, .aggregation)}
  *     act_ids  : dict activation-name -> id (unknown names are written as 255)
  *     the rest : writable buffers (int32 / float64 / uint8) sized by the caller from len(g.connections), len(g.nodes)
- * The dict KEY of a connection is taken as its (in, out) pair -- neat-python keeps `connections[key].key == key`.
+ * The (in, out) pair of a connection is its gene's `.key` attribute, as _marshal_python and PyTorch-NEAT's create_cppn
+ * (`i, o = cg.key`) read it -- not the dict key it is stored under.  Keys must fit int32 (OverflowError otherwise).
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
 #include <stdint.h>
 
-static PyObject *s_connections, *s_nodes, *s_weight, *s_enabled, *s_bias, *s_response, *s_activation, *s_aggregation;
+static PyObject *s_connections, *s_nodes, *s_weight, *s_enabled, *s_bias, *s_response, *s_activation, *s_aggregation, *s_key;
 
-/* instance attribute: straight from the instance __dict__ when there is one (plain objects, SimpleNamespace, neat-python
- * genes), the generic protocol otherwise (slots, properties).  Returns a NEW reference or NULL with an exception set. */
+/* instance attribute: straight from the instance __dict__ when there is one AND the type defines nothing under that name
+ * (plain objects, SimpleNamespace, neat-python genes); the generic protocol otherwise, so that properties, data descriptors
+ * and slots on the class win exactly as they do for `getattr` in _marshal_python.  Returns a NEW reference or NULL with an
+ * exception set. */
 static PyObject* attr(PyObject* o, PyObject* name)
 {
-    PyObject** dp = _PyObject_GetDictPtr(o);
+    PyObject** dp = _PyType_Lookup(Py_TYPE(o), name) == NULL ? _PyObject_GetDictPtr(o) : NULL;
     if (dp && *dp) {
         PyObject* v = PyDict_GetItemWithError(*dp, name);
         if (v) { Py_INCREF(v); return v; }
         if (PyErr_Occurred()) return NULL;
     }
     return PyObject_GetAttr(o, name);
+}
+
+/* Python int -> int32 with a range check (a silent cast would alias distinct node keys) */
+static int as_i32(PyObject* o, int32_t* out)
+{
+    const long v = PyLong_AsLong(o);
+    if (v == -1 && PyErr_Occurred()) return -1;
+    if (v < INT32_MIN || v > INT32_MAX) { PyErr_Format(PyExc_OverflowError, "gene key %ld does not fit int32", v); return -1; }
+    *out = (int32_t)v;
+    return 0;
 }
 
 static int as_double(PyObject* o, PyObject* name, double* out)
@@ -95,10 +108,12 @@ static PyObject* walk(PyObject* self, PyObject* args)
             Py_ssize_t pos = 0; PyObject *k, *v;
             while (PyDict_Next(conns, &pos, &k, &v)) {
                 if (nc >= cap_c) { Py_DECREF(conns); PyErr_SetString(PyExc_ValueError, "connection buffers too small"); goto done; }
-                if (!PyTuple_Check(k) || PyTuple_GET_SIZE(k) != 2) { Py_DECREF(conns); PyErr_SetString(PyExc_TypeError, "connection keys must be (in, out) tuples"); goto done; }
-                const long ki = PyLong_AsLong(PyTuple_GET_ITEM(k, 0)), ko = PyLong_AsLong(PyTuple_GET_ITEM(k, 1));
-                if ((ki == -1 || ko == -1) && PyErr_Occurred()) { Py_DECREF(conns); goto done; }
-                cin[nc] = (int32_t)ki; cout[nc] = (int32_t)ko;
+                PyObject* ck = attr(v, s_key);  /* the gene's own key: `i, o = cg.key` */
+                if (!ck) { Py_DECREF(conns); goto done; }
+                if (!PyTuple_Check(ck) || PyTuple_GET_SIZE(ck) != 2) { Py_DECREF(ck); Py_DECREF(conns); PyErr_SetString(PyExc_TypeError, "connection gene .key must be an (in, out) tuple"); goto done; }
+                const int kerr = as_i32(PyTuple_GET_ITEM(ck, 0), &cin[nc]) || as_i32(PyTuple_GET_ITEM(ck, 1), &cout[nc]);
+                Py_DECREF(ck);
+                if (kerr) { Py_DECREF(conns); goto done; }
                 if (as_double(v, s_weight, &cw[nc]) != 0) { Py_DECREF(conns); goto done; }
                 PyObject* en = attr(v, s_enabled);
                 if (!en) { Py_DECREF(conns); goto done; }
@@ -116,9 +131,7 @@ static PyObject* walk(PyObject* self, PyObject* args)
             pos = 0;
             while (PyDict_Next(nodes, &pos, &k, &v)) {
                 if (nn >= cap_n) { Py_DECREF(nodes); PyErr_SetString(PyExc_ValueError, "node buffers too small"); goto done; }
-                const long key = PyLong_AsLong(k);
-                if (key == -1 && PyErr_Occurred()) { Py_DECREF(nodes); goto done; }
-                nkey[nn] = (int32_t)key;
+                if (as_i32(k, &nkey[nn]) != 0) { Py_DECREF(nodes); goto done; }
                 PyObject* a = attr(v, s_activation);
                 if (!a) { Py_DECREF(nodes); goto done; }
                 PyObject* id = PyDict_GetItemWithError(act_ids, a);  /* borrowed */
@@ -154,5 +167,6 @@ PyMODINIT_FUNC PyInit__genome_walk(void)
     s_weight = PyUnicode_InternFromString("weight"); s_enabled = PyUnicode_InternFromString("enabled");
     s_bias = PyUnicode_InternFromString("bias"); s_response = PyUnicode_InternFromString("response");
     s_activation = PyUnicode_InternFromString("activation"); s_aggregation = PyUnicode_InternFromString("aggregation");
+    s_key = PyUnicode_InternFromString("key");
     return PyModule_Create(&moddef);
 }

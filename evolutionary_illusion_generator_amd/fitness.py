@@ -33,13 +33,24 @@ SCALING = 10          # generate_illusion.py:501
 DEFAULT_MAX_BATCH = 256
 
 _engines = {}
+_dict_digests = {}
 
 
 def _weights_key(model_name):
     """Cache key of a weight source WITHOUT reading it: get_fitnesses_neat resolves its engine several times per
     generation, and a 33 MB npz (0.2 s) or a synthetic set (0.6 s) must only be materialised on a cache miss."""
     if isinstance(model_name, dict):
-        return ("dict", id(model_name))
+        # content digest, computed once per dict OBJECT (the table keeps the dict alive, so its id cannot be reused): two equal
+        # weight dicts resolve to ONE engine instead of two 9.5 GB ones
+        ent = _dict_digests.get(id(model_name))
+        if ent is None or ent[0] is not model_name:
+            import hashlib
+            hsh = hashlib.sha1()
+            for k in sorted(model_name):
+                a = np.ascontiguousarray(model_name[k])
+                hsh.update(k.encode()); hsh.update(str(a.shape).encode()); hsh.update(a.tobytes())
+            ent = _dict_digests[id(model_name)] = (model_name, hsh.hexdigest())
+        return ("dict", ent[1])
     name = str(model_name)
     if name.startswith("synthetic"):
         return ("synthetic", int(name.split(":")[1]) if ":" in name else 0)
@@ -62,13 +73,19 @@ def _local_device():
     return torch.cuda.current_device()
 
 
-def get_engine(model_name, w, h, channels, max_batch=None, **kw):
-    """Engine handles are cached per (device, size, channels, weights): workspaces and packed weights stay in HBM
-    across generations."""
+def get_engine(model_name, w, h, channels, max_batch=None, any_batch=False, **kw):
+    """Engine handles are cached per (device, size, channels, weights, device batch): workspaces and packed weights stay in
+    HBM across generations.  any_batch: a caller that evaluates a single image (best artefacts, get_vectors) takes whatever
+    engine of this shape and these weights already exists instead of building a second full-size one."""
     channels = [int(c) for c in channels]
     dev = _local_device()
+    wk, kwk = _weights_key(model_name), tuple(sorted(kw.items()))
+    if any_batch and max_batch is None:
+        for k, e in _engines.items():
+            if len(k) == 7 and k[:5] == (dev, w, h, tuple(channels), wk) and k[6] == kwk:
+                return e
     mb = int(max_batch or int(os.environ.get("EIGEN_MAX_BATCH", DEFAULT_MAX_BATCH)))
-    key = (dev, w, h, tuple(channels), _weights_key(model_name), mb, tuple(sorted(kw.items())))
+    key = (dev, w, h, tuple(channels), wk, mb, kwk)
     eng = _engines.get(key)
     if eng is None:
         eng = Engine(w, h, channels, mb, device=dev, **kw)
@@ -83,6 +100,7 @@ def clear_engines():
     for e in _engines.values():
         e.close()
     _engines.clear()
+    _dict_digests.clear()
 
 
 def leaf_planes(structure, w, h, n_inputs=2):
@@ -124,47 +142,69 @@ def _dist():
     return dist if (dist.is_available() and dist.is_initialized() and dist.get_world_size() >= min_world) else None
 
 
+# What the last sharded_map call cost on THIS rank and, from the extras that rode in its all-gather, on every rank:
+# {"local_ms": [R] each rank's evaluate() wall time, "collective_ms": this rank's all-gather incl. device round trip}.
+# bench.py --gpus N prints it so that a multi-GPU run explains its own efficiency (stragglers vs. collective latency).
+LAST_SHARD_STATS = {}
+
+
 def sharded_map(n_items, evaluate, group=None, extra=None):
     """Evaluate items [lo, hi) of this rank with ``evaluate(lo, hi) -> float64 array`` and all-gather the
     scalars so that every rank returns the full float64 vector.  One collective per call; no data-path exchange.
-    ``extra``: one float64 per rank that rides in the same collective (a digest, a timing); when given the result
-    is ``(vector, extras[R])``."""
+    ``extra``: float64 value(s) per rank that ride in the same collective (a digest, a timing) -- a scalar or a
+    sequence; when given the result is ``(vector, extras[R])`` (``extras[R, k]`` for a sequence of k).  Every rank's
+    evaluate() wall time always rides along (LAST_SHARD_STATS)."""
+    import time
     dist = _dist()
+    scalar_extra = extra is not None and np.ndim(extra) == 0
+    ex = np.zeros(0) if extra is None else np.atleast_1d(np.asarray(extra, dtype=np.float64))
     if dist is None:
+        t0 = time.perf_counter()
         res = np.asarray(evaluate(0, n_items), dtype=np.float64)
-        return res if extra is None else (res, np.asarray([extra], dtype=np.float64))
+        LAST_SHARD_STATS.clear()
+        LAST_SHARD_STATS.update(local_ms=[1e3 * (time.perf_counter() - t0)], collective_ms=0.0)
+        return res if extra is None else (res, ex.copy() if scalar_extra else ex[None, :].copy())
     import torch
     R, r = dist.get_world_size(group), dist.get_rank(group)
     lo, hi, per = shard_bounds(n_items, R, r)
-    slot = per + (1 if extra is not None else 0)
-    if slot == 0:  # an empty population: nothing to exchange (every rank sees the same n_items)
-        return np.zeros(0, dtype=np.float64)
+    slot = per + len(ex) + 1
     local = np.zeros(slot, dtype=np.float64)
+    t0 = time.perf_counter()
     if hi > lo:
         local[:hi - lo] = evaluate(lo, hi)
-    if extra is not None:
-        local[per] = extra
+    t1 = time.perf_counter()
+    local[per:per + len(ex)] = ex
+    local[slot - 1] = 1e3 * (t1 - t0)
     t = torch.from_numpy(local)
     if dist.get_backend(group) == "nccl":
         t = t.cuda()
     out = torch.empty(slot * R, dtype=torch.float64, device=t.device)
     dist.all_gather_into_tensor(out, t, group=group)
     full = out.cpu().numpy().reshape(R, slot)
+    LAST_SHARD_STATS.clear()
+    LAST_SHARD_STATS.update(local_ms=full[:, slot - 1].tolist(), collective_ms=1e3 * (time.perf_counter() - t1))
     res = np.zeros(n_items, dtype=np.float64)
     for k in range(R):
         a, b, _ = shard_bounds(n_items, R, k)
         res[a:b] = full[k, :b - a]
-    return res if extra is None else (res, full[:, per].copy())
+    if extra is None:
+        return res
+    exs = full[:, per:per + len(ex)].copy()
+    return res, (exs[:, 0] if scalar_extra else exs)
 
 
 def _broadcast_bytes(payload, src=0, group=None):
-    """bytes of rank ``src`` -> every rank (two broadcasts: length, then the buffer; device tensors under nccl = RCCL)."""
+    """bytes of rank ``src`` -> every rank (two broadcasts: length, then the buffer; device tensors under nccl = RCCL).
+    payload None on ``src`` = "I failed before I had anything to send": the length goes out as -1 and EVERY rank gets
+    None back straight after the first broadcast, so nobody is left waiting in the second one."""
     import torch
     dist = _dist()
     dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
     me = dist.get_rank(group)
-    n = torch.tensor([len(payload) if me == src else 0], dtype=torch.int64, device=dev)
+    n = torch.tensor([(-1 if payload is None else len(payload)) if me == src else 0], dtype=torch.int64, device=dev)
     dist.broadcast(n, src, group=group)
+    if int(n.item()) < 0:
+        return None
     if me == src:
         buf = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
     else:
@@ -219,6 +259,9 @@ def evaluate_population(structure, genomes, model_name, config, w, h, channels, 
                           pairing=pairing, max_batch=max_batch, flow=flow)
 
 
+_warned_diverged = [False]
+
+
 def population_digest(genomes):
     """Cheap fingerprint of a population (keys, sizes and one weight / bias per genome; < 0.2 ms for 256 genomes): two
     NEAT runs that were not seeded alike differ in it from the first generation on."""
@@ -253,14 +296,28 @@ def population_fitness(structure, genomes, model_name, config, w, h, channels, c
     if source != "rank0":
         raise ValueError("GENOME_SOURCE must be 'rank0' or 'replicated', got %r" % (source,))
     n_in = len(config.genome_config.input_keys)
-    payload = b""
+    payload, err = b"", None
     if dist.get_rank() == 0:
-        payload = GenomeBatch(genomes, config, c_dim if gradient == 1 else 1, n_leaves=n_in).to_bytes()
-    gb = GenomeBatch.from_bytes(_broadcast_bytes(payload))
-    return sharded_map(gb.n_genomes, lambda lo, hi: evaluate_batch(structure, gb.slice(lo, hi), n_in, model_name, w, h, channels, **kw))
-
-
-_warned_diverged = [False]
+        try:  # a cyclic / invalid genome raises HERE, on rank 0 only: tell the others instead of leaving them in the broadcast
+            payload = GenomeBatch(genomes, config, c_dim if gradient == 1 else 1, n_leaves=n_in).to_bytes()
+        except Exception as e:  # noqa: BLE001
+            payload, err = None, e
+    wire = _broadcast_bytes(payload)
+    if wire is None:
+        if err is not None:
+            raise err
+        raise EngineError("rank 0 could not flatten its population (see its traceback): no genomes were broadcast")
+    gb = GenomeBatch.from_bytes(wire)
+    scores, digests = sharded_map(gb.n_genomes, lambda lo, hi: evaluate_batch(structure, gb.slice(lo, hi), n_in, model_name, w, h, channels, **kw),
+                                  extra=population_digest(genomes))
+    # rank 0 is authoritative; a rank whose OWN population differs from rank 0's (same length or not) is told so once
+    me = dist.get_rank()
+    if me != 0 and digests[me] != digests[0] and not _warned_diverged[0]:
+        print("eigen: rank %d's population is not rank 0's (digest %.0f vs %.0f): rank 0 is authoritative and its fitness values "
+              "are assigned here by list index; seed `random` identically on every rank (INTEGRATION.md section 1) to keep the "
+              "replicas in step" % (me, digests[me], digests[0]))
+        _warned_diverged[0] = True
+    return scores
 
 
 def get_fitnesses_neat(structure, population, model_name, config, w, h, channels,
@@ -293,7 +350,9 @@ def get_fitnesses_neat(structure, population, model_name, config, w, h, channels
 def render_images(structure, genomes, model_name, config, w, h, channels, c_dim=3, gradient=1, bg=1, max_batch=None):
     """uint8 [n, C, H, W] images of get_image_from_cppn (generate_illusion.py:372-460) for a list of genomes."""
     import torch
-    eng = _engine_for(model_name, w, h, [int(c) for c in channels], max_batch, None)  # the engine the fitness path uses
+    # the engine the fitness path uses (any device batch of it: a render needs no workspace of its own)
+    eng = get_engine(model_name, w, h, [int(c) for c in channels], max_batch=max_batch, any_batch=True,
+                     **({} if FLOW_METHOD == "lk" else {"flow": FLOW_METHOD}))
     n_in = len(config.genome_config.input_keys)
     _set_grid(eng, structure, w, h, n_in)
     out = []
@@ -331,7 +390,7 @@ def save_best_artifacts(structure, genome, model_name, config, w, h, channels, c
     black = render_images(structure, [genome], model_name, config, w, h, channels, c_dim, gradient, 0)[0]
     to_pil(black).save(os.path.join(best_dir, "best_black_bg.png"), "PNG")
     # flow overlay: population pairing (prediction@20 -> first extension) and flow method, as the fitness used
-    eng = _engine_for(model_name, w, h, [int(c) for c in channels], None, None)
+    eng = get_engine(model_name, w, h, [int(c) for c in channels], any_batch=True, **({} if FLOW_METHOD == "lk" else {"flow": FLOW_METHOD}))
     d = torch.from_numpy(np.ascontiguousarray(white[None])).cuda()
     _, vecs = eng.eval_images(d, 1, int(structure), pairing=PAIR_POPULATION)
     np.save(os.path.join(best_dir, "best_flow_vectors.npy"), np.asarray(vecs[0], dtype=np.float32).reshape(-1, 4))
@@ -394,7 +453,7 @@ def get_vectors(image_path, model_name, channels, w, h):
         img = np.ascontiguousarray(a[top:top + h, left:left + w].transpose(2, 0, 1).astype(np.uint8))
     else:
         img = _read_image_chw(image_path, c_dim, w, h)
-    eng = get_engine(model_name, w, h, channels)
+    eng = get_engine(model_name, w, h, channels, any_batch=True)
     d = torch.from_numpy(img[None]).cuda()
     _, vecs = eng.eval_images(d, 1, int(StructureType.Free), pairing=PAIR_SINGLE)
     return np.asarray(vecs[0], dtype=np.float64) if len(vecs[0]) else [None]
@@ -429,7 +488,20 @@ def _device_score(structure, vectors, w, h):
 def inside_outside_score(vectors, width, height):
     """fitness_calculator.inside_outside_score (:219-304) on the device scorer.  The reference only reaches it through an
     else branch that raises NameError, so it is offered under its own name rather than through calculate_fitness."""
-    return _device_score(4, vectors, width, height)
+    v = np.array(vectors, dtype=np.float64).reshape(-1, 4) if (len(vectors) and vectors[0] is not None) else np.zeros((0, 4))
+    # The reference indexes numpy arrays of shape (w, h) with i = int(x / step), j = int(y / step) (:235-236): an index past the
+    # end raises IndexError, a negative one wraps Python-style.  The device scorer only uses a position to find its cell, so the
+    # same semantics are applied here: out-of-range raises, a wrapped vector is moved to the centre of the cell it wraps to.
+    step = width / 5
+    nw, nh = int(width / step) + 1, int(height / step) + 1
+    for r in v:
+        for k, n in ((0, nw), (1, nh)):
+            c = int(r[k] / step)
+            if c >= n or c < -n:
+                raise IndexError("index %d is out of bounds for axis %d with size %d" % (c, k, n))
+            if c < 0:
+                r[k] = (c + n + 0.5) * step
+    return _device_score(4, v, width, height)
 
 
 def _score_engine(w, h, n):

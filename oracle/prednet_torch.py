@@ -22,9 +22,16 @@ def _conv_matmul(x, w, b, padding=1):
 
 
 class PredNetTorch:
-    def __init__(self, weights, channels, w, h, device="cpu", conv="library"):
+    def __init__(self, weights, channels, w, h, device="cpu", conv="library", order="stacked"):
         """device: "cpu" (oneDNN) or a cuda device (rocBLAS): two more fp32 summation orders, both independent of the build's
-        canonical chain.  conv: "library" = F.conv2d, "matmul" = im2col + matmul."""
+        canonical chain.  conv: "library" = F.conv2d, "matmul" = im2col + matmul (what chainer's CPU Convolution2D does:
+        im2col + tensordot -> BLAS sgemm).
+        order: "stacked" = the sources' convolutions summed, bias, then library sigmoid / tanh (round 1-2 cross-check);
+               "chainer" = the element-wise order of the reference's own ConvLSTM, as far as it is knowable without its BLAS
+               (see _lstm_chainer)."""
+        if order not in ("stacked", "chainer"):
+            raise ValueError("order must be 'stacked' or 'chainer'")
+        self.order = order
         self.ch, self.w, self.h, self.L = list(channels), w, h, len(channels)
         self.dev = torch.device(device)
         self.conv = F.conv2d if conv == "library" else _conv_matmul
@@ -37,6 +44,42 @@ class PredNetTorch:
             b = torch.cat([self.p["ConvLSTM%d/h_%s/b" % (l, g)] for g in GATES], 0)
             self.lstm.append((ws, b))
         self.reset(1)
+
+    def _lstm_chainer(self, l, srcs):
+        """One ConvLSTM step in the order chainer_prednet's PredNet/net.py ConvLSTM.__call__ evaluates it (quadjr/PredNet
+        lineage, UPSTREAM-RECALL: SURVEY.md B.2 -- the submodule is absent from /root/reference, .gitmodules:1-3):
+
+            ii = self.x_i0(x[0]); ii += self.x_i1(x[1]); ii += self.h_i(self.h); ii += self.c_i(self.c); ii = F.sigmoid(ii)
+            ff = ... the same with x_f*, h_f, c_f ...
+            cc = self.x_c0(x[0]); cc += self.x_c1(x[1]); cc += self.h_c(self.h); cc = F.tanh(cc); cc *= ii; cc += (ff * self.c)
+            oo = ... x_o*, h_o, c_o(self.c) -- the OLD c ...; oo = F.sigmoid(oo)
+            self.c = cc; self.h = oo * F.tanh(self.c)
+
+        i.e. every convolution is a tensor of its own (x_* without bias, h_* = Convolution2D WITH bias, added to its own
+        output), the tensors are added left to right with one fp32 rounding each, the peephole EltFilter `c_g(c) = W * c`
+        is a rounded product added last, the cell update is two rounded products and one addition (no fma), and chainer's
+        CPU F.sigmoid is `tanh(x * 0.5) * 0.5 + 0.5` (chainer/functions/activation/sigmoid.py, forward_cpu).  The four
+        gates' convolutions of one source are stacked along the output channels here: each output channel is still its
+        own dot product, so the element-wise order per gate is exactly the one above.  What stays unknowable is the
+        summation order INSIDE a convolution (chainer: im2col + the host's BLAS)."""
+        p = self.p
+        ws, b = self.lstm[l]
+        names = (["x0", "x1", "h"] if len(srcs) == 3 else ["x0", "h"])
+        z = None
+        for s, w_, nm in zip(srcs, ws, names):
+            y = self.conv(s, w_, b if nm == "h" else None, padding=1)  # h_*: the bias is added to that convolution's output
+            z = y if z is None else z + y
+        zi, zf, zc, zo = torch.chunk(z, 4, 1)
+        c = self.cs[l]
+        sig = lambda x: torch.tanh(x * 0.5) * 0.5 + 0.5
+        ii = sig(zi + p["ConvLSTM%d/c_i/W" % l] * c)
+        ff = sig(zf + p["ConvLSTM%d/c_f/W" % l] * c)
+        cc = torch.tanh(zc)
+        cc = cc * ii
+        cc = cc + ff * c
+        oo = sig(zo + p["ConvLSTM%d/c_o/W" % l] * c)
+        self.cs[l] = cc
+        self.hs[l] = oo * torch.tanh(cc)
 
     def reset(self, B):
         z = lambda l, m=1: torch.zeros(B, m * self.ch[l], self.h >> l, self.w >> l, device=self.dev)
@@ -55,6 +98,11 @@ class PredNetTorch:
         for l in reversed(range(L)):
             ws, b = self.lstm[l]
             srcs = [E[l]] + ([F.interpolate(self.hs[l + 1], scale_factor=2, mode="nearest")] if l < L - 1 else []) + [self.hs[l]]
+            if self.order == "chainer":
+                self._lstm_chainer(l, srcs)
+                v = self.conv(self.hs[l], p["ConvP%d/W" % l], p["ConvP%d/b" % l], padding=1)
+                self.P[l] = v.clamp(0.0, 1.0) if l == 0 else F.relu(v)
+                continue
             z = sum(self.conv(s, w_, None, padding=1) for s, w_ in zip(srcs, ws)) + b.view(1, -1, 1, 1)
             zi, zf, zc, zo = torch.chunk(z, 4, 1)
             c = self.cs[l]

@@ -226,6 +226,33 @@ def test_c_genome_walker_is_the_python_marshalling():
     same([g])
     arrays = genome._marshal([g])
     assert arrays[3].tolist() == [0.25, -1.0] and arrays[4].tolist() == [1, 0] and arrays[8].tolist() == [0, 0] and arrays[7].tolist() == [3, 3]
+    # a data descriptor on the CLASS wins over a same-named entry of the instance __dict__ (as it does for getattr),
+    # the (in, out) pair is the gene's .key (what create_cppn reads), not the dict key it is filed under
+    class ShadowNode:
+        def __init__(self, b):
+            self.__dict__["bias"] = 123.0          # stale value in the instance dict ...
+            self._b = b
+            self.response, self.activation, self.aggregation = 1.0, "sin", "sum"
+
+        bias = property(lambda self: self._b, lambda self, v: None)  # ... shadowed by the class-level property
+
+    g2 = synth.Genome(3)
+    g2.connections = {("filed", "elsewhere"): synth.ConnectionGene(key=(-2, 0), weight=1.25, enabled=True)}
+    g2.nodes = {0: ShadowNode(-0.75)}
+    same([g2])
+    arrays = genome._marshal([g2])
+    assert arrays[1].tolist() == [-2] and arrays[2].tolist() == [0] and arrays[9].tolist() == [-0.75]
+    big = synth.Genome(4)
+    big.connections = {(-1, 0): synth.ConnectionGene(key=(-1, 1 << 31), weight=1.0, enabled=True)}
+    big.nodes = {}
+    for fn in (genome._marshal, genome._marshal_python):
+        with pytest.raises(OverflowError):     # no silent cast to int32
+            fn([big])
+    big.connections = {}
+    big.nodes = {1 << 40: synth.NodeGene(key=1 << 40, bias=0.0, response=1.0, activation="sin", aggregation="sum")}
+    for fn in (genome._marshal, genome._marshal_python):
+        with pytest.raises(OverflowError):
+            fn([big])
     bad = synth.Genome(2)
     bad.connections = {(-1, 0): SlotConn((-1, 0), "heavy", True)}
     bad.nodes = {}
@@ -362,6 +389,107 @@ def test_rank0_is_authoritative_when_the_ranks_populations_diverge():
 def test_replicated_source_refuses_diverged_populations():
     (r0, out0, full0, calls0, e0), (r1, out1, full1, calls1, e1) = _run_gloo("replicated", diverged=True)
     assert e0 and e1 and "different populations" in e0 and "EngineError" in e0
+
+
+def _gloo8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import io
+    import contextlib
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from evolutionary_illusion_generator_amd import fitness, genome, synth
+    fitness.GENOME_SOURCE = "rank0"
+    calls = []
+
+    def fake_batch(structure, gb, n_in, *a, **k):
+        calls.append(gb.n_genomes)
+        return _fake_fitness_of_batch(gb)
+
+    fitness.evaluate_batch = fake_batch
+    cfg = synth.make_config(2, 1)
+    out, stats, err, log = {}, {}, None, io.StringIO()
+    try:
+        for P in (256, 50, 5, 0):   # even shards, a ragged last shard (7 x 7 + 1), fewer genomes than ranks, none
+            genomes = [g for _, g in synth.make_population(P, cfg, seed=3)]
+            out[P] = fitness.population_fitness(1, genomes, "synthetic", cfg, 64, 64, [1, 4, 8], c_dim=1).tolist()
+            stats[P] = dict(fitness.LAST_SHARD_STATS)
+        # same length, different content on rank 5: rank 0 stays authoritative and rank 5 is told
+        genomes = [g for _, g in synth.make_population(16, cfg, seed=3 if rank != 5 else 77)]
+        with contextlib.redirect_stdout(log):
+            out["div"] = fitness.population_fitness(1, genomes, "synthetic", cfg, 64, 64, [1, 4, 8], c_dim=1).tolist()
+        # rank 0 cannot flatten its population (a cycle): EVERY rank raises straight away instead of waiting in a broadcast
+        bad = [g for _, g in synth.make_population(4, cfg, seed=3)]
+        if rank == 0:
+            a, b = 1 + 5, 1 + 6  # two hidden nodes (outputs: 0; hidden: 1..20)
+            bad[2].connections[(a, b)] = synth.ConnectionGene(key=(a, b), weight=1.0, enabled=True)
+            bad[2].connections[(b, a)] = synth.ConnectionGene(key=(b, a), weight=1.0, enabled=True)
+            bad[2].connections[(b, 0)] = synth.ConnectionGene(key=(b, 0), weight=1.0, enabled=True)
+        try:
+            fitness.population_fitness(1, bad, "synthetic", cfg, 64, 64, [1, 4, 8], c_dim=1)
+            out["bad"] = "no error"
+        except Exception as e:  # noqa: BLE001
+            out["bad"] = type(e).__name__
+        out["after"] = fitness.population_fitness(1, [g for _, g in synth.make_population(9, cfg, seed=3)], "synthetic", cfg, 64, 64, [1, 4, 8], c_dim=1).tolist()
+    except Exception as e:  # noqa: BLE001
+        err = "%s: %s" % (type(e).__name__, e)
+    q.put((rank, out, stats, calls, log.getvalue(), err))
+    dist.destroy_process_group()
+
+
+def test_population_sharding_gloo_world8():
+    """SURVEY 8(e) at the world size the metric names (8 ranks, gloo on CPU): pop 256 (32 per rank), pop 50 (ragged: 7 x 7 + 1),
+    pop 5 (three ranks own nothing), pop 0; every rank's evaluate() time rides in the one all-gather (what bench.py --gpus N
+    prints per rank); a diverged replica is warned by content, a failure on rank 0 reaches every rank."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, out, stats, calls, log, err in res:
+        assert err is None, (rank, err)
+        for P in (256, 50, 5):
+            assert out[P] == _expected(P)
+            assert len(stats[P]["local_ms"]) == 8 and all(t >= 0 for t in stats[P]["local_ms"]) and stats[P]["collective_ms"] >= 0
+        assert out[0] == []
+        assert out["div"] == _expected(16)                  # rank 0's genomes, whatever rank 5 holds
+        assert ("is not rank 0's" in log) == (rank == 5)
+        assert out["bad"] in ("ValueError", "EngineError") and out["after"] == _expected(9)
+    shards = {r[0]: r[3][:3] for r in res}
+    assert all(shards[r][0] == 32 for r in range(8))                                   # pop 256
+    assert [shards[r][1] for r in range(7)] == [7] * 7 and shards[7][1] == 1           # pop 50: the last shard is ragged
+    assert res[0][3] == [32, 7, 1, 2, 2] and res[4][3] == [32, 7, 1, 2, 1]             # pops 256, 50, 5, 16 (diverged), 9
+    assert res[7][3] == [32, 1, 2]                                                     # rank 7 owns nothing of pop 5 and pop 9: evaluate() is not called
+
+
+def test_inside_outside_score_index_semantics_are_checked_on_the_host():
+    """fitness_calculator.inside_outside_score (:235-236) indexes numpy arrays with int(x / step): past the end -> IndexError.
+    The host mirror raises the same way BEFORE anything reaches the device (no GPU needed); the wrap of negative indices is
+    compared with the oracle on the GPU box (tests/test_gpu_round2.py)."""
+    from evolutionary_illusion_generator_amd import fitness
+    v = np.array([[10.0, 10.0, 0.1, 0.0], [50.0, 60.0, 0.0, 0.1]])
+    for k, val in ((0, 6.5 * 32), (1, 4.2 * 32), (0, -7.0 * 32)):
+        bad = v.copy(); bad[1, k] = val
+        with pytest.raises(IndexError, match="out of bounds for axis %d" % k):
+            fitness.inside_outside_score(bad, 160, 120)
+
+
+def test_equal_weight_dicts_share_one_engine_key():
+    """dict weights were keyed by id(), so two equal dicts built two 9.5 GB engines.  The key is a content digest,
+    computed once per dict object."""
+    from evolutionary_illusion_generator_amd import fitness, weights
+    a = weights.synthetic_prednet_weights([1, 4, 8], 16, 8, seed=1)
+    b = {k: v.copy() for k, v in a.items()}
+    c = weights.synthetic_prednet_weights([1, 4, 8], 16, 8, seed=2)
+    assert fitness._weights_key(a) == fitness._weights_key(b) != fitness._weights_key(c)
+    assert fitness._dict_digests[id(a)][0] is a      # memoised per object (and kept alive, so the id cannot be recycled)
+    fitness._dict_digests.clear()
 
 
 def test_genome_batch_slice_and_wire_round_trip():
