@@ -196,18 +196,19 @@ constexpr int KC = EIG_KC;  // channels per K-block
 template <int NI, int TW, bool VEC> constexpr bool conv_fast_dma() { return VEC && TW == 16 && KC == 8 && NI >= 3; }  // narrow tiles: the padding would cost a block per CU
 // weight area: NI == 4 keeps its exact 4.5 rounds (the half round is issued by all four waves, two of them repeating the
 // other two); narrower slabs are rounded up to whole rounds, the extra lanes fetch the following rows into the padding
-template <int NI, int TW, bool VEC, int TAPS = 9> constexpr int conv_w_floats()
+// (NT = threads per block: 256, or 512 for the eight-wave instantiations -- a round is NT 16-byte chunks)
+template <int NI, int TW, bool VEC, int TAPS = 9, int NT = 256> constexpr int conv_w_floats()
 {
-    return (conv_fast_dma<NI, TW, VEC>() && !(NI == 4 && TAPS == 9)) ? ((KC * TAPS * NI * 4 + 255) / 256) * 1024 : KC * TAPS * NI * 16;
+    return (conv_fast_dma<NI, TW, VEC>() && !(NI == 4 && TAPS == 9)) ? ((KC * TAPS * NI * 4 + NT - 1) / NT) * NT * 4 : KC * TAPS * NI * 16;
 }
-template <int NI, int TW, bool VEC> constexpr int conv_in_floats()
+template <int NI, int TW, bool VEC, int NT = 256> constexpr int conv_in_floats()
 {
-    return conv_fast_dma<NI, TW, VEC>() ? ((KC * TileGeom<TW, VEC>::PLANE / 4 + 255) / 256) * 1024 : KC * TileGeom<TW, VEC>::PLANE;
+    return conv_fast_dma<NI, TW, VEC>() ? ((KC * TileGeom<TW, VEC>::PLANE / 4 + NT - 1) / NT) * NT * 4 : KC * TileGeom<TW, VEC>::PLANE;
 }
 // ONEKB: operators whose whole K fits ONE K-block (ConvA of the image layer: 6 channels) never stage a second buffer
-template <int NI, int TW, bool VEC, int TAPS = 9, bool ONEKB = false> constexpr int conv_lds_bytes()
+template <int NI, int TW, bool VEC, int TAPS = 9, bool ONEKB = false, int NT = 256> constexpr int conv_lds_bytes()
 {
-    return (ONEKB ? 1 : 2) * (conv_in_floats<NI, TW, VEC>() + conv_w_floats<NI, TW, VEC, TAPS>()) * 4;
+    return (ONEKB ? 1 : 2) * (conv_in_floats<NI, TW, VEC, NT>() + conv_w_floats<NI, TW, VEC, TAPS, NT>()) * 4;
 }
 
 // FUSE (conv3x3_mfma<4, 16, EPI_LSTM, true, false, true>): LDS buffer = max(main K-block, unpooled-source K-block).
@@ -232,7 +233,16 @@ template <int NI, int TW, bool VEC> constexpr int conv_fuse_buf_floats()
 #ifndef EIG_CONV_OCC
 #define EIG_CONV_OCC 2  // blocks per CU the register allocation is capped for (__launch_bounds__ 2nd argument)
 #endif
-constexpr int CONV_THREADS = 256;  // 4 waves per block
+constexpr int CONV_THREADS = 256;  // 4 waves per block (W8 instantiations: 512 = 8 waves)
+// W8: EIGHT waves share the block's 256-pixel x NB-column tile -- waves 0..3 own parity classes (0, px) of the four 64-pixel
+// regions, waves 4..7 classes (1, px): two 16-row sub-tiles x NI accumulators per wave instead of four.  Same LDS tile, same
+// DMA bytes, half the accumulators and half the epilogue per wave, so FOUR waves per SIMD are resident (two blocks per CU):
+// while one block's waves run prologue / epilogue the SIMD still has two waves feeding the matrix pipe (a lone wave sustains
+// 0.70 of peak, two 0.93: scripts/mfma_occupancy.hip), and small maps whose launches do not fill the chip get twice as many
+// waves out of the same tiles.  Which lane computes a pixel changes, its fma chain does not: results are bit-identical.
+#ifndef EIG_W8_OCC
+#define EIG_W8_OCC 4  // waves per SIMD the W8 register allocation is capped for
+#endif
 
 #ifndef EIG_UP4_OCC
 #define EIG_UP4_OCC 2  // the 2x2-form pass would fit a third block per CU (88 VGPRs, 48 KB of LDS); measured: no faster (96.9 vs 95.8 ms)
@@ -240,11 +250,14 @@ constexpr int CONV_THREADS = 256;  // 4 waves per block
 #ifndef EIG_ONEKB_OCC
 #define EIG_ONEKB_OCC 4  // single-K-block operators: one LDS buffer (32 KB), four blocks per CU -- their time is prologue + DMA round trip +
 #endif                   // epilogue around 216 MFMAs per wave, which only other blocks' MFMAs can cover
-template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false>
-__global__ void __launch_bounds__(CONV_THREADS, ONEKB ? EIG_ONEKB_OCC : ((EPI == EPI_UP4 && NI == 4 && TW == 16 && VEC) ? EIG_UP4_OCC : EIG_CONV_OCC))
+template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false, bool W8 = false>
+__global__ void __launch_bounds__(W8 ? 512 : CONV_THREADS, W8 ? EIG_W8_OCC : (ONEKB ? EIG_ONEKB_OCC : ((EPI == EPI_UP4 && NI == 4 && TW == 16 && VEC) ? EIG_UP4_OCC : EIG_CONV_OCC)))
 conv3x3_mfma(const ConvArgs a)
 {
     static_assert(!FUSE || (EPI == EPI_LSTM && NI == 4 && TW == 16 && VEC && KC == 8 && !ONEKB), "FUSE: the wide ConvLSTM instantiation only");
+    static_assert(!W8 || (VEC && !ONEKB && !FUSE && EPI != EPI_UP4C && EPI != EPI_LSTM_PACKED), "W8: 16-byte staging, per-pixel or pooled epilogues");
+    constexpr int NT = W8 ? 512 : CONV_THREADS;  // threads per block; a DMA round is NT 16-byte chunks
+    constexpr int MI_N = W8 ? 2 : 4;             // 16-row sub-tiles (parity classes) per wave
     using G = TileGeom<TW, VEC>;
     constexpr int TH = G::TH, NIMG = G::NIMG, S = G::S, XO = G::XO, PH = G::PH, PLANE = G::PLANE;
     constexpr int NB = NI * 16;
@@ -266,12 +279,14 @@ conv3x3_mfma(const ConvArgs a)
 #endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool FAST = conv_fast_dma<NI, TW, VEC>();
-    constexpr int INF = conv_in_floats<NI, TW, VEC>();  // floats of the input area (KC * PLANE, padded for FAST)
-    constexpr int BUF = FUSE ? conv_fuse_buf_floats<NI, TW, VEC>() : INF + conv_w_floats<NI, TW, VEC, epi_taps(EPI)>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
+    constexpr int INF = conv_in_floats<NI, TW, VEC, NT>();  // floats of the input area (KC * PLANE, padded for FAST)
+    constexpr int BUF = FUSE ? conv_fuse_buf_floats<NI, TW, VEC>() : INF + conv_w_floats<NI, TW, VEC, epi_taps(EPI), NT>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave of the block: its DMA share
+    const int ws = W8 ? (wv & 3) : wv;                         // which 64-pixel region of the tile (16-wide: rows 4 ws ..; 8-wide: image ws)
+    const int ch2 = W8 ? (wv >> 2) : 0;                        // W8: row parity py of the two classes this wave computes
     const int q = lane >> 4;
     const int col = lane & 15;
 
@@ -301,11 +316,11 @@ conv3x3_mfma(const ConvArgs a)
     // K-block is (tid + 256 r) / slots-per-channel); !VEC: slots are the floats of ONE channel plane.
     constexpr int RC = S / 4;
     constexpr int PER_C = VEC ? NIMG * PH * RC : PLANE;
-    constexpr int NR = VEC ? (KC * PER_C + 255) / 256 : (PLANE + 255) / 256;
+    constexpr int NR = VEC ? (KC * PER_C + NT - 1) / NT : (PLANE + NT - 1) / NT;
     int sl_off[NR], sl_img[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int p = tid + r * 256;
+        const int p = tid + r * NT;
         int rem = VEC ? p % PER_C : p;
         constexpr int RW = VEC ? RC : S;
         const int img = rem / (PH * RW);
@@ -326,7 +341,7 @@ conv3x3_mfma(const ConvArgs a)
     // The DMA instructions of K-block kb+1 are INTERLEAVED with the 18 MFMA steps of K-block kb (one every other
     // step): a DMA issued while the wave would anyway be waiting for the matrix pipe costs nothing, whereas a burst
     // of them ahead of the MFMAs measured ~0.7 % of the K-block time per instruction.  ONE barrier per K-block.
-    constexpr int NWR = (KC * TAPS * (NB / 4) + 255) / 256;       // weight DMA rounds per K-block
+    constexpr int NWR = (KC * TAPS * (NB / 4) + NT - 1) / NT;     // weight DMA rounds per K-block
     constexpr int NIN = VEC ? NR : KC * NR;                       // input DMA ops per K-block
     constexpr int NOPS = NWR + NIN;
     constexpr int NSTEP = KC * TAPS / 4;                          // 18 (8 for the 2x2 form)
@@ -373,23 +388,23 @@ conv3x3_mfma(const ConvArgs a)
         src.Ct = k.s == 0 ? a.src[0].Ct : (k.s == 1 ? a.src[1].Ct : a.src[2].Ct);
         if (j < NWR) {
             const int n16 = k.kc * TAPS * (NB / 4);
-            const int base = j * 256 + wv * 64, ch = base + lane;
+            const int base = j * NT + wv * 64, ch = base + lane;
             if (ch < n16)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(buf + INF + (size_t)base * 4), 16,
-                                                         tid * 16, (wrow * NB + j * 1024) * 4, 0, 0);
+                                                         tid * 16, (wrow * NB + j * NT * 4) * 4, 0, 0);
             return;
         }
         const int chs = a.H * a.W;
         if (VEC) {
             const int r = j - NWR;
-            const int p = tid + r * 256;
+            const int p = tid + r * NT;
             const int soff = k.c0 * chs * 4;
             const bool tail = k.c0 + KC > src.C;  // padded channels present: mask them explicitly (rare, tiny layers)
             if (r < NR) {
                 int vo = sl_off[r < NR ? r : 0];
                 if (NIMG > 1) vo = vo < 0 ? vo : vo + sl_img[r < NR ? r : 0] * src.Ct * chs * 4;
                 if (tail && k.c0 + p / PER_C >= src.C) vo = -1;
-                if (p < k.kc * PER_C) buf_dma16(k.s, buf + (r * 256 + wv * 64) * 4, vo, soff);
+                if (p < k.kc * PER_C) buf_dma16(k.s, buf + (r * NT + wv * 64) * 4, vo, soff);
             }
         } else {
             const int c = (j - NWR) / NR, r = (j - NWR) % NR;
@@ -398,9 +413,9 @@ conv3x3_mfma(const ConvArgs a)
                 const int gy = pok ? sl_off[r] / a.W : 0, gx = pok ? sl_off[r] - gy * a.W : 0;
                 const float* g = (pok && (k.c0 + c < src.C))
                                      ? src.ptr + ((size_t)sl_img[r] * src.Ct + k.c0 + c) * chs + gy * a.W + gx : a.zeros;
-                if (tid + r * 256 < PLANE)
+                if (tid + r * NT < PLANE)
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                                     (__attribute__((address_space(3))) void*)(buf + c * PLANE + r * 256 + wv * 64), 4, 0, 0);
+                                                     (__attribute__((address_space(3))) void*)(buf + c * PLANE + r * NT + wv * 64), 4, 0, 0);
             }
         }
     };
@@ -410,10 +425,11 @@ conv3x3_mfma(const ConvArgs a)
     // time).  The K-block's byte offset is folded into the lane offset with a SATURATING add, so that the descriptor's
     // range check sees the whole offset: channels >= C (padding) and rows >= krows fall out of range and read zeros,
     // `no next K-block` is an offset of 2^31, and an invalid slot (-1) stays 0xffffffff.  NIMG == 1 here (TW == 16).
-    const int vw_full = tid * 16;                                   // weight rounds 0..3: chunk j*256 + tid
-    const int vw_last = (1024 + (wv & 1) * 64 + lane) * 16;         // round 4 holds 128 chunks: waves 2,3 repeat waves 0,1
-    static_assert(!FAST || NI != 4 || TAPS != 9 || (KC * 9 * (NB / 4)) % 256 == 128, "FAST staging: the last weight round of NI = 4 must hold 128 chunks");
-    static_assert(!FAST || TAPS != 4 || NI != 4 || (KC * 4 * (NB / 4)) % 256 == 0, "FAST staging, 2x2 form: whole weight rounds");
+    constexpr int LASTW = (NWR - 1) * NT;                           // first chunk of the last weight round (NI = 4, 9 taps: 1024)
+    const int vw_full = tid * 16;                                   // whole weight rounds: chunk j*NT + tid
+    const int vw_last = (LASTW + (wv & 1) * 64 + lane) * 16;        // the last round holds 128 chunks: waves 2,3 repeat waves 0,1 (W8: waves 2..7 skip it)
+    static_assert(!FAST || NI != 4 || TAPS != 9 || (KC * 9 * (NB / 4)) % NT == 128, "FAST staging: the last weight round of NI = 4 must hold 128 chunks");
+    static_assert(!FAST || TAPS != 4 || NI != 4 || (KC * 4 * (NB / 4)) % NT == 0, "FAST staging, 2x2 form: whole weight rounds");
     const int aH = a.H, aW = a.W;
     // descriptor of the source a K-block reads, from SCALAR selects of base pointer and size (selecting between whole
     // descriptors ends in a scratch table + waterfall loop)
@@ -438,8 +454,9 @@ conv3x3_mfma(const ConvArgs a)
         if (j < NWR) {
             const unsigned soff = soff_w;
             const bool lastw = TAPS == 9 && NI == 4 && (j == NWR - 1);
-            const unsigned vo = __builtin_elementwise_add_sat((unsigned)(lastw ? vw_last : vw_full + j * 4096), soff);
-            float* dst = buf + INF + (lastw ? (1024 + (wv & 1) * 64) * 4 : (j * 256 + wv * 64) * 4);
+            if (W8 && lastw && wv >= 2) return;  // wave-uniform: 128 chunks = two waves
+            const unsigned vo = __builtin_elementwise_add_sat((unsigned)(lastw ? vw_last : vw_full + j * NT * 16), soff);
+            float* dst = buf + INF + (lastw ? (LASTW + (wv & 1) * 64) * 4 : (j * NT + wv * 64) * 4);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, 0, 0, 0);
             return;
         }
@@ -447,7 +464,7 @@ conv3x3_mfma(const ConvArgs a)
         const unsigned soff = soff_in;
         const int slot = r < NR ? sl_off[r < NR ? r : 0] : -1;
         const unsigned vo = __builtin_elementwise_add_sat((unsigned)slot, soff);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(buf + (r * 256 + wv * 64) * 4), 16, (int)vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_k, (__attribute__((address_space(3))) void*)(buf + (r * NT + wv * 64) * 4), 16, (int)vo, 0, 0, 0);
     };
 
     const unsigned long long t_setup = EIG_TIMING ? __builtin_readcyclecounter() : 0;  // slots and descriptors ready
@@ -508,8 +525,9 @@ conv3x3_mfma(const ConvArgs a)
     // class-major map: MFMA row r of sub-tile (py, px) is pixel (2 wy + py, 2 wx + px) of the wave's region
     const int g_wy = (TW == 16) ? (col & 3) >> 1 : col >> 2;
     const int g_wx = (TW == 16) ? 2 * (col >> 2) + (col & 1) : col & 3;
-    const int g_base = (TW == 16) ? (wv * 4 + 2 * g_wy) * S + 2 * g_wx + XO      // sub-tile mi adds (mi >> 1) * S + (mi & 1)
-                                  : wv * PH * S + 2 * g_wy * S + 2 * g_wx + XO;  // one image per wave
+    const int g_base = ((TW == 16) ? (ws * 4 + 2 * g_wy) * S + 2 * g_wx + XO      // sub-tile of class (py, px) adds py * S + px
+                                   : ws * PH * S + 2 * g_wy * S + 2 * g_wx + XO)  // one image per wave
+                       + ch2 * S;  // W8: this wave's classes are (ch2, 0) and (ch2, 1) -- the row parity goes into the base register
     {
 #pragma unroll
         for (int s = 0; s < 9; ++s) {
@@ -523,9 +541,10 @@ conv3x3_mfma(const ConvArgs a)
     const int addr4 = g_base + ((q >> 1) + (cls >> 1)) * S + (q & 1) + (cls & 1);
     const int boff = q * NB + col * NI;  // weight slab row k = [16 channels][NI tiles]: a lane's NI values are contiguous
 
-    f32x4 acc[4][NI];
+    // acc[mi]: !W8 sub-tile mi = class (mi >> 1, mi & 1); W8 sub-tile mi = class (ch2, mi)
+    f32x4 acc[MI_N][NI];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < MI_N; ++mi)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -548,8 +567,8 @@ conv3x3_mfma(const ConvArgs a)
     // 21K cycles, scripts/timeline.py), so they are SPREAD over the MFMA steps of K-block 0 and land long before the K loop ends.
     constexpr bool HAS_UP = !FUSE && (EPI == EPI_LSTM || EPI == EPI_LSTM_PACKED || EPI == EPI_RAW);  // operators that can be handed an unpooled source's chain
     constexpr int UPV = (TW == 16) ? 2 : 1;             // loads per (class, N-tile)
-    constexpr int NUPL = HAS_UP ? 4 * NI * UPV : 0;     // loads per lane
-    f32x4 upc[4][HAS_UP ? NI : 1];
+    constexpr int NUPL = HAS_UP ? MI_N * NI * UPV : 0;  // loads per lane
+    f32x4 upc[MI_N][HAS_UP ? NI : 1];
     const bool has_up = HAS_UP && a.acc_init != nullptr;
     int up_off[UPV];
     const float* up_base = a.acc_init;
@@ -558,11 +577,11 @@ conv3x3_mfma(const ConvArgs a)
         const int Hs = a.H >> 1, Ws = a.W >> 1;
         up_hw = Hs * Ws;
         up_cstride = a.n_nblk * NB * up_hw;
-        const int b = bgrp * NIMG + (TW == 16 ? 0 : wv);
+        const int b = bgrp * NIMG + (TW == 16 ? 0 : ws);
 #pragma unroll
         for (int v = 0; v < UPV; ++v) {
             // window row / first window column of this load, in pixels of THIS launch's resolution
-            const int gy0 = (TW == 16) ? y0 + 4 * wv + 2 * v : tyi * TH + 2 * q;
+            const int gy0 = (TW == 16) ? y0 + 4 * ws + 2 * v : tyi * TH + 2 * q;
             const int gx0 = (TW == 16) ? x0 + 4 * q : txi * TW;
             // element offset inside this wave's image block [4][n_nblk*NB][Hs][Ws] (the image is wave-uniform); windows outside
             // the image read element 0 instead -- their accumulators are never stored
@@ -575,7 +594,7 @@ conv3x3_mfma(const ConvArgs a)
     // addresses the compiler hoists the loop-invariant 64-bit pointers out of the K loop (128 VGPRs, spilled)
     const __amdgpu_buffer_rsrc_t rs_up = __builtin_amdgcn_make_buffer_rsrc((void*)up_base, 0, has_up ? 4 * up_cstride * 4 : 0, 0x00020000);
     auto up_load = [&](int mi, int ni, int v) __attribute__((always_inline)) {
-        const int soff = (ni * 16 * up_hw + mi * up_cstride) * 4;
+        const int soff = (ni * 16 * up_hw + (W8 ? 2 * ch2 + mi : mi) * up_cstride) * 4;  // plane = parity class of sub-tile mi
         if constexpr (TW == 16) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_up, up_off[v], soff, 0));
@@ -614,11 +633,11 @@ conv3x3_mfma(const ConvArgs a)
                 // body keeps the DMA instructions free of control flow
                 if (FAST || (TAPS == 9 ? (st < 9 || cur_kb.kc > 4) : st < cur_kb.kc)) {
                     const int per = st / 9, s9 = st % 9;
-                    float av[4], bv[NI];
-                    float avc[4][3];  // EPI_UP4C: the gathers of classes 1..3
+                    float av[MI_N], bv[NI];
+                    float avc[MI_N][3];  // EPI_UP4C: the gathers of classes 1..3
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi) {
-                        const int moff = (mi >> 1) * S + (mi & 1);  // parity class (py, px) of sub-tile mi
+                    for (int mi = 0; mi < MI_N; ++mi) {
+                        const int moff = W8 ? mi : (mi >> 1) * S + (mi & 1);  // parity class (py, px) of sub-tile mi (W8: py is in the base register)
                         av[mi] = (TAPS == 9) ? in_lds[ad[s9] + per * 4 * PL + moff] : in_lds[addr4 + st * PL + moff];
                         if constexpr (EPI == EPI_UP4C) {  // class c = (py, px) shifts the tap window by (py, px)
 #pragma unroll
@@ -634,7 +653,7 @@ conv3x3_mfma(const ConvArgs a)
                         for (int ni = 0; ni < NI; ++ni) bv[ni] = w_lds[st * 4 * NB + ni];
                     }
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
+                    for (int mi = 0; mi < MI_N; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
                             acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32((EPI == EPI_UP4C && ni > 0) ? avc[mi][ni > 0 ? ni - 1 : 0] : av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
@@ -652,7 +671,7 @@ conv3x3_mfma(const ConvArgs a)
                 }
                 if constexpr (FIRST) {
 #pragma unroll
-                    for (int mi = 0; mi < 4; ++mi)
+                    for (int mi = 0; mi < MI_N; ++mi)
 #pragma unroll
                         for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -740,7 +759,7 @@ conv3x3_mfma(const ConvArgs a)
     }
     if (has_up) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
+        for (int mi = 0; mi < MI_N; ++mi)
 #pragma unroll
             for (int ni = 0; ni < (HAS_UP ? NI : 1); ++ni) acc[mi][ni] = acc[mi][ni] + upc[mi][ni];
     }
@@ -761,14 +780,20 @@ conv3x3_mfma(const ConvArgs a)
     // Pooled / half-resolution view: register reg of every sub-tile is window (wy, wx): 16-wide (reg >> 1, 2 q + (reg & 1)) of the
     // wave's 2 x 8 windows, 8-wide (q, reg).
     typedef float f32x2 __attribute__((ext_vector_type(2)));
-    const int eb = bgrp * NIMG + (TW == 16 ? 0 : wv);          // image of this wave
-    const int ey0 = (TW == 16) ? y0 + 4 * wv : tyi * TH;       // first row / column of the wave's region
+    const int eb = bgrp * NIMG + (TW == 16 ? 0 : ws);          // image of this wave
+    const int ey0 = (TW == 16) ? y0 + 4 * ws : tyi * TH;       // first row / column of the wave's region
     const int ex0 = (TW == 16) ? x0 : txi * TW;
     auto seg_row = [&](int sgi) __attribute__((always_inline)) { return ey0 + ((TW == 16) ? sgi : 2 * q + (sgi >> 1)); };
     auto seg_col = [&](int sgi) __attribute__((always_inline)) { return ex0 + ((TW == 16) ? 4 * q : 4 * (sgi & 1)); };
-#define EIG_SEG_MI(sgi, j) ((TW == 16) ? 2 * ((sgi) & 1) + ((j) & 1) : 2 * ((sgi) >> 1) + ((j) & 1))
-#define EIG_SEG_REG(sgi, j) ((TW == 16) ? 2 * ((sgi) >> 1) + ((j) >> 1) : 2 * ((sgi) & 1) + ((j) >> 1))
-    if (eb >= a.B) { timeline_record(0); return; }
+    // A wave walks its segments sl = 0 .. NSEG-1.  !W8: all four (sgi = sl).  W8: the two whose row parity is this wave's ch2
+    // (16-wide: rows ch2, ch2 + 2 of the region; 8-wide: row 2 q + ch2, both column halves); element j of such a segment is
+    // register 2 sl + (j >> 1) of the wave's sub-tile j & 1 -- compile-time indices either way.
+    constexpr int NSEG = W8 ? 2 : 4;
+#define EIG_SGI(sl) (W8 ? ((TW == 16) ? ch2 + 2 * (sl) : 2 * ch2 + (sl)) : (sl))
+#define EIG_SEG_MI(sl, j) (W8 ? ((j) & 1) : ((TW == 16) ? 2 * ((sl) & 1) + ((j) & 1) : 2 * ((sl) >> 1) + ((j) & 1)))
+#define EIG_SEG_REG(sl, j) (W8 ? 2 * (sl) + ((j) >> 1) : ((TW == 16) ? 2 * ((sl) >> 1) + ((j) >> 1) : 2 * ((sl) & 1) + ((j) >> 1)))
+    const bool alive = eb < a.B;
+    if (!alive && !(W8 && EPI == EPI_CONVA)) { timeline_record(0); return; }  // (W8 ConvA: every wave takes part in the pooling exchange)
 
     if constexpr (EPI == EPI_RAW || EPI == EPI_UP4 || EPI == EPI_UP4C) {
 #pragma unroll
@@ -782,8 +807,8 @@ conv3x3_mfma(const ConvArgs a)
                 dst = a.raw + ((size_t)eb * a.Cout + o) * HW;
             }
 #pragma unroll
-            for (int sgi = 0; sgi < 4; ++sgi) {
-                const int gy = seg_row(sgi), gx = seg_col(sgi);
+            for (int sgi = 0; sgi < NSEG; ++sgi) {
+                const int gy = seg_row(EIG_SGI(sgi)), gx = seg_col(EIG_SGI(sgi));
                 if (gy >= a.H || gx >= a.W) continue;
                 if (VEC) {  // W % 4 == 0: the whole segment is inside, one aligned 16-byte store
                     *reinterpret_cast<f32x4*>(dst + gy * a.W + gx) = (f32x4){acc[EIG_SEG_MI(sgi, 0)][ni][EIG_SEG_REG(sgi, 0)], acc[EIG_SEG_MI(sgi, 1)][ni][EIG_SEG_REG(sgi, 1)],
@@ -814,8 +839,8 @@ conv3x3_mfma(const ConvArgs a)
                 hn = oo * det_tanhf(cn);
             };
 #pragma unroll
-            for (int sgi = 0; sgi < 4; ++sgi) {
-                const int gy = seg_row(sgi), gx = seg_col(sgi);
+            for (int sgi = 0; sgi < NSEG; ++sgi) {
+                const int gy = seg_row(EIG_SGI(sgi)), gx = seg_col(EIG_SGI(sgi));
                 if (gy >= a.H || gx >= a.W) continue;
                 const int pix = gy * a.W + gx;
                 if (VEC) {
@@ -902,23 +927,48 @@ conv3x3_mfma(const ConvArgs a)
         constexpr int NPR = (TW == 16) ? 2 : 1, NPC = (TW == 16) ? 2 : 4;  // pooled rows x contiguous pooled columns per lane
         const int pyo = (ey0 >> 1) + ((TW == 16) ? 0 : q), pxo = (ex0 >> 1) + ((TW == 16) ? 2 * q : 0);
         const bool vec_ok = VEC && (TW == 16 || (a.W % 8) == 0);  // 16-wide: W % 4 == 0 makes the pooled pairs 8-byte aligned; 8-wide: 16-byte rows need Wo % 4 == 0
+        // W8: a pooling window's classes (0, px) and (1, px) sit in the SAME lane of the two waves ws and ws + 4 -- each takes the
+        // max over its own two, the pair meets through LDS (free after the K loop), then wave ch2 stores pooled row ch2 (16-wide)
+        // or the N-tiles of parity ch2 (8-wide).  max(max(v0, v1), max(v2, v3)) as before.
+        float* const xch = lds;  // [8 waves][NI][4 registers][64 lanes]
+        if constexpr (W8) {
+            __syncthreads();  // every wave is done reading the last K-block's operands
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int chx = nblk * NB + ni * 16 + col;
+                const float bbx = chx < a.Cout ? a.bias[chx] : 0.0f;
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg)
+                    xch[((wv * NI + ni) * 4 + reg) * 64 + lane] = fmaxf(relu_f(acc[0][ni][reg] + bbx), relu_f(acc[1][ni][reg] + bbx));
+            }
+            __syncthreads();
+            if (!alive) { timeline_record(0); return; }
+        }
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             const int ch = nblk * NB + ni * 16 + col;
             if (ch >= a.Cout) continue;
+            if (W8 && TW != 16 && NI > 1 && (ni & 1) != ch2) continue;   // 8-wide: the pair splits the N-tiles
+            if (W8 && TW != 16 && NI == 1 && ch2 != 0) continue;
             const float bb = a.bias[ch];
             float A[4];
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
-                const float v0 = relu_f(acc[0][ni][reg] + bb), v1 = relu_f(acc[1][ni][reg] + bb);
-                const float v2 = relu_f(acc[2][ni][reg] + bb), v3 = relu_f(acc[3][ni][reg] + bb);
-                A[reg] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                if constexpr (W8) {
+                    const float m0 = xch[(((ws) * NI + ni) * 4 + reg) * 64 + lane], m1 = xch[(((ws + 4) * NI + ni) * 4 + reg) * 64 + lane];
+                    A[reg] = fmaxf(m0, m1);
+                } else {
+                    const float v0 = relu_f(acc[0][ni][reg] + bb), v1 = relu_f(acc[1][ni][reg] + bb);
+                    const float v2 = relu_f(acc[MI_N - 2][ni][reg] + bb), v3 = relu_f(acc[MI_N - 1][ni][reg] + bb);
+                    A[reg] = fmaxf(fmaxf(v0, v1), fmaxf(v2, v3));
+                }
             }
             const float* Pc = a.P + ((size_t)eb * a.Cout + ch) * plane;
             float* Ec = a.E + ((size_t)eb * 2 * a.Cout + ch) * plane;
             float* Ec2 = Ec + (size_t)a.Cout * plane;
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {
+                if (W8 && TW == 16 && pr != ch2) continue;  // 16-wide: wave ch2 of the pair stores pooled row ch2
                 const int yo = pyo + pr;
                 if (yo >= Ho || pxo >= Wo) continue;
                 const size_t o = (size_t)yo * Wo + pxo;
@@ -953,8 +1003,8 @@ conv3x3_mfma(const ConvArgs a)
             const float bb = a.bias[ch];
             const size_t base = ((size_t)eb * a.Cout + ch) * HW;
 #pragma unroll
-            for (int sgi = 0; sgi < 4; ++sgi) {
-                const int gy = seg_row(sgi), gx = seg_col(sgi);
+            for (int sgi = 0; sgi < NSEG; ++sgi) {
+                const int gy = seg_row(EIG_SGI(sgi)), gx = seg_col(EIG_SGI(sgi));
                 if (gy >= a.H || gx >= a.W) continue;
                 const int pix = gy * a.W + gx;
                 if (VEC && !a.frame && !a.E0) {  // layers > 0: P only, one aligned 16-byte store per segment
@@ -988,6 +1038,7 @@ conv3x3_mfma(const ConvArgs a)
             }
         }
     }
+#undef EIG_SGI
 #undef EIG_SEG_MI
 #undef EIG_SEG_REG
     timeline_record(0);

@@ -124,6 +124,11 @@ struct eigen_engine {
     // timing
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pev0 = nullptr, pev1 = nullptr;
+    // Side stream of the roll-out: ConvP_l (l > 0) only feeds ConvA_l of the NEXT step, so it leaves the critical chain
+    // ConvA_1..L -> ConvLSTM_L..0 -> ConvP_0 and runs beside the ConvLSTMs of the layers below it (fork / join with events;
+    // same kernels, same arguments: results are untouched).  Worth most where a launch does not fill the chip.
+    hipStream_t aux = nullptr;
+    hipEvent_t ev_h[EIGEN_MAX_LAYERS] = {nullptr}, ev_p[EIGEN_MAX_LAYERS] = {nullptr};
     bool profile_convs = false;
     double ms[6] = {0, 0, 0, 0, 0, 0};
     int hflip = 0;  // which h buffer holds the current R
@@ -131,6 +136,9 @@ struct eigen_engine {
 
 // ------------------------------------------------------------------------------------------------ helpers
 static int pad4(int c) { return (c + 3) & ~3; }
+#ifndef EIGEN_W8_GRID
+#define EIGEN_W8_GRID 2048
+#endif
 
 // ---- Farneback constants (host; the same double-precision recipe as oracle/farneback.c, checked by tests/test_gpu_parity.py) ----
 static int fb_levels_used(int H, int W, int levels)  // calcOpticalFlowFarneback: no level below 32 pixels
@@ -350,38 +358,43 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
     return out;
 }
 
-template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
+template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false, bool W8 = false> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
-    constexpr int lds = FUSE ? 2 * conv_fuse_buf_floats<NI, TW, VEC>() * 4 : conv_lds_bytes<NI, TW, VEC, epi_taps(EPI), ONEKB>();
+    constexpr int NT = W8 ? 512 : CONV_THREADS;
+    constexpr int lds = FUSE ? 2 * conv_fuse_buf_floats<NI, TW, VEC>() * 4 : conv_lds_bytes<NI, TW, VEC, epi_taps(EPI), ONEKB, NT>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE>), dim3(grid), dim3(CONV_THREADS), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE, W8>), dim3(grid), dim3(NT), lds, st, a);
     return hipGetLastError();
 }
 
-template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec)
+// w8: the eight-wave instantiation (conv_mfma.h: W8) -- 16-byte staging only, chosen per operator in eigen_set_prednet_weights
+template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec, bool w8 = false)
 {
+    if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP || EPI == EPI_CONVA || EPI == EPI_UP4 || EPI == EPI_RAW) {
+        if (w8 && vec) return launch_inst2<NI, TW, EPI, true, false, false, true>(a, grid, st);
+    }
     return vec ? launch_inst2<NI, TW, EPI, true>(a, grid, st) : launch_inst2<NI, TW, EPI, false>(a, grid, st);
 }
 
-template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& a, int grid, hipStream_t st, bool vec)
+template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& a, int grid, hipStream_t st, bool vec, bool w8 = false)
 {
     if (TW == 16) {
         switch (NI) {
-            case 1: return launch_inst<1, 16, EPI>(a, grid, st, vec);
-            case 2: return launch_inst<2, 16, EPI>(a, grid, st, vec);
-            case 3: return launch_inst<3, 16, EPI>(a, grid, st, vec);
-            default: return launch_inst<4, 16, EPI>(a, grid, st, vec);
+            case 1: return launch_inst<1, 16, EPI>(a, grid, st, vec, w8);
+            case 2: return launch_inst<2, 16, EPI>(a, grid, st, vec, w8);
+            case 3: return launch_inst<3, 16, EPI>(a, grid, st, vec, w8);
+            default: return launch_inst<4, 16, EPI>(a, grid, st, vec, w8);
         }
     }
     switch (NI) {
-        case 1: return launch_inst<1, 8, EPI>(a, grid, st, vec);
-        case 2: return launch_inst<2, 8, EPI>(a, grid, st, vec);
-        case 3: return launch_inst<3, 8, EPI>(a, grid, st, vec);
-        default: return launch_inst<4, 8, EPI>(a, grid, st, vec);
+        case 1: return launch_inst<1, 8, EPI>(a, grid, st, vec, w8);
+        case 2: return launch_inst<2, 8, EPI>(a, grid, st, vec, w8);
+        case 3: return launch_inst<3, 8, EPI>(a, grid, st, vec, w8);
+        default: return launch_inst<4, 8, EPI>(a, grid, st, vec, w8);
     }
 }
 
@@ -411,6 +424,14 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         static const int tile_map = getenv("EIGEN_TILE_MAP") ? atoi(getenv("EIGEN_TILE_MAP")) : 1;  // 0 only for A/B measurements
         a.tile_map = tile_map;
     }
+    // Eight-wave instantiations (conv_mfma.h: W8).  Measured (profiles/r03_b_ab_w8.txt): where a launch fills the chip many times
+    // over they change nothing (256 genomes at 256^2: every operator within +-0.5 %), where it does not they gain 4-5 % (160x120,
+    // 50 genomes: twice as many waves out of the same few blocks).  Hence: launches of at most EIGEN_W8_GRID blocks (four rounds of
+    // the 512 block slots).  EIGEN_W8 = bit mask forces it for operator classes whatever the grid (1 ConvLSTM, 2 ConvA, 4 ConvP,
+    // 8 the 2x2-form pass, 16 raw test convolutions), EIGEN_W8=0 switches it off: A/B measurements and the parity tests.
+    static const int w8_env = getenv("EIGEN_W8") ? atoi(getenv("EIGEN_W8")) : -1;
+    const int w8_mask = w8_env >= 0 ? w8_env : (grid <= EIGEN_W8_GRID ? 15 : 0);
+    const bool w8 = w8_mask != 0 && vec && (op.epi != EPI_LSTM || (w8_mask & 1));
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
     static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
@@ -437,20 +458,20 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     switch (op.epi) {
         case EPI_LSTM:
             if (op.fused && a.up_src) r = launch_inst2<4, 16, EPI_LSTM, true, false, true>(a, grid, st);  // chain of the unpooled source in-kernel
-            else r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec);
+            else r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec, w8) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec, w8);
             break;
         case EPI_LSTM_PACKED: r = (op.TW == 16) ? launch_inst<1, 16, EPI_LSTM_PACKED>(a, grid, st, vec) : launch_inst<1, 8, EPI_LSTM_PACKED>(a, grid, st, vec); break;
         case EPI_CONVA: {
             // the image layer's ConvA (K = 9 x 6 channels): one K-block, its own instantiation (conv_mfma.h: ONEKB)
             static const bool onekb = !(getenv("EIGEN_NO_ONEKB") && atoi(getenv("EIGEN_NO_ONEKB")));  // A/B measurements only
             if (onekb && op.NI == 3 && op.TW == 16 && vec && op.nsrc == 1 && pad4(op.src_C[0]) <= KC) r = launch_inst2<3, 16, EPI_CONVA, true, true>(a, grid, st);
-            else r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st, vec);
+            else r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st, vec, w8 && (w8_mask & 2));
             break;
         }
-        case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st, vec); break;
-        case EPI_UP4: r = launch_epi<EPI_UP4>(op.NI, op.TW, a, grid, st, vec); break;
+        case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st, vec, w8 && (w8_mask & 4)); break;
+        case EPI_UP4: r = launch_epi<EPI_UP4>(op.NI, op.TW, a, grid, st, vec, w8 && (w8_mask & 8)); break;
         case EPI_UP4C: r = launch_inst2<4, 16, EPI_UP4C, true>(a, grid, st); break;  // chosen only for 16-wide tiles and 16-byte staging
-        default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec); break;
+        default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec, w8 && (w8_mask & 16)); break;  // (eigen_test_conv)
     }
 #if EIG_TIMING
     if (tl_dbg) {
@@ -511,6 +532,9 @@ int eigen_destroy(eigen_engine* e)
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->pev0) (void)hipEventDestroy(e->pev0);
     if (e->pev1) (void)hipEventDestroy(e->pev1);
+    for (auto& ev : e->ev_h) if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->ev_p) if (ev) (void)hipEventDestroy(ev);
+    if (e->aux) (void)hipStreamDestroy(e->aux);
     delete e;
     return EIGEN_OK;
 }
@@ -592,6 +616,11 @@ int eigen_create(const eigen_config* cfg, eigen_engine** out)
     for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipEventCreate(&e->pev0));
     HIPCHK(hipEventCreate(&e->pev1));
+    HIPCHK(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));  // no implicit ordering against the caller's (possibly NULL) stream: events only
+    for (int l = 0; l < L; ++l) {
+        HIPCHK(hipEventCreateWithFlags(&e->ev_h[l], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&e->ev_p[l], hipEventDisableTiming));
+    }
     *out = e;
     return EIGEN_OK;
 }
@@ -696,8 +725,9 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             // the in-kernel form wins: 160x120 colour pop 50 +2.3 %, 160x120 gray +5 %.  Hence: in-kernel iff the pass would
             // execute < 2.5e10 multiply-adds per launch at this engine's device batch (~0.35 ms); EIGEN_FUSEUP=0 / 1 force it.
             static const int fuse_env = getenv("EIGEN_FUSEUP") ? atoi(getenv("EIGEN_FUSEUP")) : -1;
+            static const int fuse_mask = getenv("EIGEN_FUSEUP_MASK") ? atoi(getenv("EIGEN_FUSEUP_MASK")) : -1;  // bit l: layer l in-kernel (A/B)
             const double pass_macs = l < L - 1 ? (double)e->B * y.H * y.W * 4 * C * e->layer[l + 1].C * 4 : 0;
-            const bool fuse_up = fuse_env >= 0 ? fuse_env != 0 : pass_macs < 2.5e10;
+            const bool fuse_up = fuse_mask >= 0 ? ((fuse_mask >> l) & 1) != 0 : (fuse_env >= 0 ? fuse_env != 0 : pass_macs < 2.5e10);
             const bool fused = fuse_up && l < L - 1 && op.epi == EPI_LSTM && op.TW == 16 && (op.W % 8) == 0 && KC == 8;
             if (fused) {
                 const int Cup = e->layer[l + 1].C;
@@ -880,6 +910,13 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
         HIPCHK(hipMemsetAsync(y.P, 0, n, st));
     }
     int cur = 0;  // h[cur] holds the state of the previous step
+    // EIGEN_SIDE_STREAM=1 forks ConvP_l (l > 0) onto the side stream.  OFF by default: measured on one box (profiles/r03_b_ab_w8.txt,
+    // run 2) it changes nothing at 256^2 / 256 genomes (177.6 vs 177.8 evals/s) and nothing where launches under-fill the chip
+    // (160x120 colour 430.6 vs 435.2, gray 2452 vs 2472): a launch's blocks occupy the CUs in dispatch order, and the time of an
+    // under-filled launch is the CU that holds two of its blocks -- a second queue adds blocks to CUs, it does not balance them.
+    static const bool side_env = getenv("EIGEN_SIDE_STREAM") && atoi(getenv("EIGEN_SIDE_STREAM"));
+    const bool side = side_env && !e->profile_convs && L > 1;
+    bool p_pending[EIGEN_MAX_LAYERS] = {false};  // ConvP_l of the previous step is in flight on the side stream
     static const bool skip_zero_sources = !(getenv("EIGEN_NO_T0") && atoi(getenv("EIGEN_NO_T0")));  // A/B measurements only
     hipLaunchKernelGGL(e0_init_kernel, dim3(1024), dim3(256), 0, st, d_images, e->layer[0].E, e->C0, (int)HW, batch);
     HIPCHK(hipGetLastError());
@@ -891,6 +928,7 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
             memset(&a, 0, sizeof(a));
             a.src[0].ptr = e->layer[l - 1].E;
             a.bias = y.biasA; a.P = y.P; a.E = y.E;
+            if (p_pending[l]) { HIPCHK(hipStreamWaitEvent(st, e->ev_p[l], 0)); p_pending[l] = false; }  // join: P_l of the previous step
             HIPCHK(launch_conv(e, (t == 0 && skip_zero_sources) ? y.convA_t0 : y.convA, a, batch, st));
         }
         // top-down: R_l, then P_l
@@ -923,6 +961,14 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
                 memset(&a, 0, sizeof(a));
                 a.src[0].ptr = y.h[cur ^ 1];
                 a.bias = y.biasP; a.Pout = y.P; a.clip = (l == 0) ? 1 : 0;
+                if (side && l > 0) {  // fork: ConvP_l beside the ConvLSTMs below it
+                    HIPCHK(hipEventRecord(e->ev_h[l], st));
+                    HIPCHK(hipStreamWaitEvent(e->aux, e->ev_h[l], 0));
+                    HIPCHK(launch_conv(e, y.convP, a, batch, e->aux));
+                    HIPCHK(hipEventRecord(e->ev_p[l], e->aux));
+                    p_pending[l] = true;
+                    continue;
+                }
                 if (l == 0) {
                     if (t + 1 < n_steps) {  // error units of the next step
                         a.E0 = y.E;
@@ -939,6 +985,8 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
         }
         cur ^= 1;
     }
+    for (int l = 1; l < L; ++l)  // (nothing is pending after the last step -- its ConvP_l are not launched -- but keep the join explicit)
+        if (p_pending[l]) HIPCHK(hipStreamWaitEvent(st, e->ev_p[l], 0));
     e->hflip = cur;
     return EIGEN_OK;
 }

@@ -239,4 +239,9 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
     base = run({})
     for switch in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA", "EIGEN_FUSEUP"):
         assert run({switch: "1"}) == base, switch
+    # round 3: the eight-wave instantiations (chosen by launch size: these small roll-outs take them by default) forced off / on
+    # for every operator class, with and without the separate 2x2 pass; ConvP_l forked onto the side stream
+    for env in ({"EIGEN_W8": "0"}, {"EIGEN_W8": "31"}, {"EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_W8": "0", "EIGEN_FUSEUP": "0"},
+                {"EIGEN_SIDE_STREAM": "1"}, {"EIGEN_SIDE_STREAM": "1", "EIGEN_W8": "0"}):
+        assert run(env) == base, env
     assert run({"EIGEN_FUSEUP": "0"}) == base  # these small roll-outs take the in-kernel chain by default: the separate pass
