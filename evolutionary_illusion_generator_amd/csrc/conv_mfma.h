@@ -186,6 +186,9 @@ template <int TW, bool VEC> struct TileGeom {
     static constexpr int PLANE = NIMG * PH * S;  // floats per channel in LDS
 };
 
+#ifndef EIG_DMA_EARLY
+#define EIG_DMA_EARLY 0  // measurement builds: > 0 = DMA op j of the next K-block is issued at MFMA step j * EIG_DMA_EARLY instead of spread over all steps
+#endif
 #ifndef EIG_KC
 #define EIG_KC 8
 #endif
@@ -663,7 +666,7 @@ conv3x3_mfma(const ConvArgs a)
                 } else if constexpr (FAST) {
 #pragma unroll
                     for (int j = 0; j < NOPS; ++j)
-                        if (j * NSTEP / NOPS == st) dma_fast(j, nxt_kb, rs_nxt, soff_in_nxt, soff_w_nxt, nxt);
+                        if ((EIG_DMA_EARLY ? (j * EIG_DMA_EARLY < NSTEP ? j * EIG_DMA_EARLY : NSTEP - 1) : j * NSTEP / NOPS) == st) dma_fast(j, nxt_kb, rs_nxt, soff_in_nxt, soff_w_nxt, nxt);
                 } else if (more_kb) {
 #pragma unroll
                     for (int j = 0; j < NOPS; ++j)
