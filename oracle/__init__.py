@@ -60,6 +60,7 @@ def lib():
             build()
         _LIB = ctypes.CDLL(so)
         _LIB.eig_oracle_prednet_rollout.restype = ctypes.c_int
+        _LIB.eig_oracle_prednet_rollout_order.restype = ctypes.c_int
         _LIB.eig_oracle_lucas_kanade.restype = ctypes.c_int
         _LIB.eig_oracle_good_features.restype = ctypes.c_int
         _LIB.eig_oracle_conv_chain.restype = ctypes.c_int
@@ -91,8 +92,11 @@ def tensor_names(n_layers):
     return names
 
 
-def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=False, return_float=False):
-    """Roll ``img`` (uint8 [C0,H,W]) through PredNet; returns uint8 frames [n_repeat+n_ext, C0, H, W]."""
+def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=False, return_float=False, order="canonical"):
+    """Roll ``img`` (uint8 [C0,H,W]) through PredNet; returns uint8 frames [n_repeat+n_ext, C0, H, W].
+    order: "canonical" = the build's arithmetic (what the HIP kernels reproduce bit for bit); "chainer" = the reference's
+    element-wise order (eig_oracle.c: lstm_reference_order) -- separate convolution tensors added left to right, plain unpool ->
+    9-tap, un-fused gate products, sigmoid = tanh(x/2)/2 + 1/2 on libm."""
     L = len(channels)
     names = tensor_names(L)
     arrs = [np.ascontiguousarray(weights[n], dtype=np.float32) for n in names]
@@ -103,13 +107,27 @@ def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=
     T = n_repeat + n_ext
     out = np.zeros((T, channels[0], h, w), dtype=np.uint8)
     p0 = np.zeros((T, channels[0], h, w), dtype=np.float32) if return_float else None
-    rc = lib().eig_oracle_prednet_rollout(
+    rc = lib().eig_oracle_prednet_rollout_order(
         ctypes.c_int(L), _p(ch, ctypes.c_int), ctypes.c_int(w), ctypes.c_int(h), tab, _p(img, ctypes.c_uint8),
         ctypes.c_int(n_repeat), ctypes.c_int(n_ext), ctypes.c_int(int(requant)), _p(out, ctypes.c_uint8),
-        _p(p0, ctypes.c_float) if return_float else None)
+        _p(p0, ctypes.c_float) if return_float else None, ctypes.c_int({"canonical": 0, "chainer": 1}[order]))
     if rc != 0:
         raise ValueError("eig_oracle_prednet_rollout failed (size must be divisible by 2^(L-1))")
     return (out, p0) if return_float else out
+
+
+class PredNetC:
+    """The C roll-out behind the interface of oracle.prednet_torch.PredNetTorch (``rollout(imgs, n_repeat, n_ext)``), so that
+    oracle.classify.population_report can take it as the 'other' implementation: order="chainer" is the torch-free statement of
+    the reference's element-wise order."""
+
+    def __init__(self, weights, channels, w, h, order="chainer"):
+        self.weights, self.channels, self.w, self.h, self.order = weights, list(channels), w, h, order
+
+    def rollout(self, imgs, n_repeat=20, n_ext=2, requant=False):
+        fr, fl = zip(*[prednet_rollout(self.weights, self.channels, self.w, self.h, im, n_repeat=n_repeat, n_ext=n_ext, requant=requant,
+                                       return_float=True, order=self.order) for im in np.asarray(imgs)])
+        return np.stack(fr), np.stack(fl)
 
 
 def conv_chain(sources, ups, weights, H, W):

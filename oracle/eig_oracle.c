@@ -130,6 +130,7 @@ typedef struct {
     float* gate; /* 4 gate pre-activations scratch */
     float* up;   /* chain of the unpooled source scratch */
     float* tmp;  /* ConvA full-resolution scratch */
+    int order;   /* 0: the build's canonical arithmetic; 1: the reference's element-wise order (lstm_reference_order) */
 } prednet_t;
 
 /* Tensor table order shared with the Python wrapper (oracle/__init__.py: tensor_table()). */
@@ -326,6 +327,61 @@ static void prednet_reset(prednet_t* n)
     }
 }
 
+/* ConvLSTM_l in the element-wise order the REFERENCE evaluates it, as far as that order is knowable without its BLAS
+ * (chainer_prednet PredNet/net.py ConvLSTM.__call__, quadjr/PredNet lineage -- UPSTREAM-RECALL; the submodule is
+ * absent from /root/reference, .gitmodules:1-3):
+ *     ii = x_i0(E); ii += x_i1(unpooling_2d(R_{l+1})); ii += h_i(h); ii += c_i(c); ii = F.sigmoid(ii)      (ff likewise)
+ *     cc = x_c0(E); cc += x_c1(upR); cc += h_c(h); cc = F.tanh(cc); cc *= ii; cc += ff * c
+ *     oo = x_o0(E); oo += x_o1(upR); oo += h_o(h); oo += c_o(c)  [the OLD c]; oo = F.sigmoid(oo);  c = cc; h = oo * F.tanh(c)
+ * i.e. every convolution is a tensor of its own started from 0 (x_* without bias; h_* = Convolution2D WITH bias, added to its own
+ * output), the unpooled source goes through the PLAIN 9-tap convolution (no 2x2 form), the tensors are added left to right with
+ * one fp32 rounding each, the peephole EltFilter is a rounded product added last, the cell update is two rounded products and
+ * one addition (no fma; this file is compiled with -ffp-contract=off), and chainer's CPU F.sigmoid is tanh(x * 0.5) * 0.5 + 0.5
+ * (chainer/functions/activation/sigmoid.py forward_cpu) on the host's libm tanh.  What stays unknowable: the summation order
+ * INSIDE a convolution (chainer: im2col + the host's BLAS) -- the (c, ky, kx) fma chain is kept there.  Used by the tests as a
+ * second, torch-free statement of the same order as oracle/prednet_torch.py order="chainer". */
+static inline float ref_sigmoidf(float x) { return tanhf(x * 0.5f) * 0.5f + 0.5f; }
+static void lstm_reference_order(prednet_t* n, int l)
+{
+    const int L = n->L, H = n->H[l], W = n->W[l], C = n->ch[l];
+    const size_t hw = (size_t)H * W, chw = (size_t)C * hw;
+    float* z = n->gate;                 /* [4][C][hw]: running sum of the tensors */
+    float* t = n->up;                   /* [C][hw]: one convolution's output */
+    for (int g = 0; g < 4; g++) {
+        float* zg = z + (size_t)g * chw;
+        memset(zg, 0, sizeof(float) * chw);
+        fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
+        conv3x3_chain(zg, n->pad, n->wx0[l][g], C, 2 * C, H, W);                       /* x_g0(E) */
+        if (l < L - 1) {
+            memset(t, 0, sizeof(float) * chw);
+            fill_padded(n->pad, n->h[l + 1], n->ch[l + 1], H, W, 1);                    /* unpooling_2d(R_{l+1}, 2) */
+            conv3x3_chain(t, n->pad, n->wx1[l][g], C, n->ch[l + 1], H, W);              /* x_g1(upR): plain 9 taps */
+            for (size_t i = 0; i < chw; i++) zg[i] = zg[i] + t[i];
+        }
+        memset(t, 0, sizeof(float) * chw);
+        fill_padded(n->pad, n->h[l], C, H, W, 0);
+        conv3x3_chain(t, n->pad, n->wh[l][g], C, C, H, W);                              /* h_g(h) ... */
+        for (int o = 0; o < C; o++) {
+            const float b = n->bh[l][g][o];
+            for (size_t p = 0; p < hw; p++) { const size_t i = (size_t)o * hw + p; const float hb = t[i] + b; zg[i] = zg[i] + hb; }  /* ... + its bias, then += */
+        }
+    }
+    for (size_t i = 0; i < chw; i++) {
+        const float cold = n->c[l][i];
+        const float pi = n->peep[l][0][i] * cold, pf = n->peep[l][1][i] * cold, po = n->peep[l][2][i] * cold;  /* EltFilter: W * c */
+        const float ii = ref_sigmoidf(z[i] + pi);
+        const float ff = ref_sigmoidf(z[chw + i] + pf);
+        float cc = tanhf(z[2 * chw + i]);
+        cc = cc * ii;
+        const float fc = ff * cold;
+        cc = cc + fc;
+        const float oo = ref_sigmoidf(z[3 * chw + i] + po);
+        n->c[l][i] = cc;
+        n->hn[l][i] = oo * tanhf(cc);
+    }
+    { float* sw = n->h[l]; n->h[l] = n->hn[l]; n->hn[l] = sw; }
+}
+
 /* One PredNet.__call__(x): x is [C0][H][W] float32.  Afterwards n->P[0] holds the prediction. */
 static void prednet_step(prednet_t* n, const float* x)
 {
@@ -362,6 +418,7 @@ static void prednet_step(prednet_t* n, const float* x)
     for (int l = L - 1; l >= 0; l--) {
         const int H = n->H[l], W = n->W[l], C = n->ch[l];
         const size_t hw = (size_t)H * W;
+        if (n->order == 1) { lstm_reference_order(n, l); goto predict; }
         memset(n->gate, 0, sizeof(float) * 4 * C * hw);
         /* one chain over the full-resolution sources E_l, h_l (ConvLSTM.__call__: x_*0, h_*) ... */
         fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
@@ -399,6 +456,7 @@ static void prednet_step(prednet_t* n, const float* x)
             }
         }
         { float* t = n->h[l]; n->h[l] = n->hn[l]; n->hn[l] = t; }
+    predict:
         /* P_l = act(ConvP_l(R_l)) */
         fill_padded(n->pad, n->h[l], C, H, W, 0);
         memset(n->gate, 0, sizeof(float) * C * hw);
@@ -426,15 +484,27 @@ static void prednet_step(prednet_t* n, const float* x)
  *                1 = feed back the uint8-quantised prediction / 255
  * returns 0, or -1 on bad arguments.
  */
+int eig_oracle_prednet_rollout_order(int L, const int* channels, int W, int H, const float* const* tensors,
+                                     const uint8_t* img, int n_repeat, int n_ext, int requant,
+                                     uint8_t* out_frames, float* out_p0, int order);
 int eig_oracle_prednet_rollout(int L, const int* channels, int W, int H, const float* const* tensors,
                                const uint8_t* img, int n_repeat, int n_ext, int requant,
                                uint8_t* out_frames, float* out_p0)
 {
-    if (L < 1 || L > EIG_MAX_LAYERS) return -1;
+    return eig_oracle_prednet_rollout_order(L, channels, W, H, tensors, img, n_repeat, n_ext, requant, out_frames, out_p0, 0);
+}
+
+/* order: 0 = the build's canonical arithmetic, 1 = the reference's element-wise order (lstm_reference_order) */
+int eig_oracle_prednet_rollout_order(int L, const int* channels, int W, int H, const float* const* tensors,
+                                     const uint8_t* img, int n_repeat, int n_ext, int requant,
+                                     uint8_t* out_frames, float* out_p0, int order)
+{
+    if (L < 1 || L > EIG_MAX_LAYERS || order < 0 || order > 1) return -1;
     if ((W % (1 << (L - 1))) || (H % (1 << (L - 1)))) return -1;
     prednet_t n;
     memset(&n, 0, sizeof(n));
     n.L = L;
+    n.order = order;
     for (int l = 0; l < L; l++) { n.ch[l] = channels[l]; n.W[l] = W >> l; n.H[l] = H >> l; }
     bind_tensors(&n, tensors);
     prednet_alloc(&n);

@@ -212,6 +212,9 @@ def test_fitness_deviation_under_the_reference_element_order_is_explained_genome
     net = PredNetTorch(wts, ch, w, h, conv="matmul", order="chainer")
     genomes = [g for _, g in synth.make_population(28, cfg, seed=5)][12:] + [g for _, g in synth.make_population(8, cfg, seed=0)]
     imgs, frames, vecs, fits = _canonical_population(oracle_lib, st, c_dim, w, h, ch, genomes, cfg, wts)
+    # the same question against the torch-free C statement of the reference order (host-independent apart from libm's tanh)
+    s2, _ = classify.population_report(st, w, h, imgs[:12], frames[:12], vecs[:12], fits[:12], oracle_lib.PredNetC(wts, ch, w, h))
+    assert s2["max_byte_diff"] <= 1 and s2["max_rel_identical"] <= 1e-12 and s2["outside_1e-4_unexplained"] == 0, s2
     s, rows = classify.population_report(st, w, h, imgs, frames, vecs, fits, net)
     print("\n%s" % s)
     assert s["nonzero_both"] >= 8 and s["zero_on_one_side_only"] == 0
@@ -224,6 +227,30 @@ def test_fitness_deviation_under_the_reference_element_order_is_explained_genome
     for d in s["outside_1e-4_detail"]:
         assert 1 <= d["flips"] <= 16 and d["single_lsb_effects_max"] >= 0.25 * d["rel"], d
     assert s["within_1e-4"] >= 0.85 * s["genomes"]
+
+
+def test_reference_order_is_stated_twice_and_deviates_from_the_canonical_one_by_ulps(oracle_lib):
+    """The reference's element-wise ConvLSTM order (separate convolution tensors, plain unpool -> 9-tap, un-fused products,
+    sigmoid = tanh(x/2)/2 + 1/2) in C (eig_oracle.c: lstm_reference_order, fma-chain convolutions, libm tanh) and in torch
+    (prednet_torch order="chainer", im2col + sgemm, vectorised tanh): two independent statements that agree to fp32 round-off
+    on the float predictions of all 22 steps, and both sit within 1e-6 of the canonical arithmetic -- the whole difference
+    between the orders is a handful of +-1 bytes at quantisation boundaries (classified genome by genome elsewhere)."""
+    from evolutionary_illusion_generator_amd import weights
+    from oracle.prednet_torch import PredNetTorch
+    for ch, w, h, seed in (([1, 16, 32, 64], 160, 120, 0), ([3, 12, 24, 48], 64, 64, 1)):
+        wts = weights.synthetic_prednet_weights(ch, w, h, seed=seed)
+        img = (np.random.default_rng(seed).random((ch[0], h, w)) * 255).astype(np.uint8)
+        canon, f0 = oracle_lib.prednet_rollout(wts, ch, w, h, img, 20, 2, return_float=True)
+        ref_c, f1 = oracle_lib.prednet_rollout(wts, ch, w, h, img, 20, 2, return_float=True, order="chainer")
+        ref_t, f2 = PredNetTorch(wts, ch, w, h, conv="matmul", order="chainer").rollout(img[None], 20, 2)
+        fr_c, _ = oracle_lib.PredNetC(wts, ch, w, h).rollout(img[None], 20, 2)
+        assert np.array_equal(fr_c[0], ref_c)
+        assert np.abs(f1 - f2[0]).max() <= 2e-6 and np.abs(f1 - f0).max() <= 2e-6
+        for a, b in ((canon, ref_c), (ref_c, ref_t[0]), (canon, ref_t[0])):
+            d = np.abs(a.astype(int) - b.astype(int))
+            assert d.max() <= 1 and (d != 0).mean() <= 1e-4
+    with pytest.raises(KeyError):
+        oracle_lib.prednet_rollout(wts, ch, w, h, img, 1, 0, order="cudnn")
 
 
 def test_classify_tells_identical_smooth_and_cliff_apart():
