@@ -266,7 +266,10 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # EIGEN_BENCH_BACKEND=gloo (tests only): the N-rank control flow of this file on a box with FEWER GPUs than ranks -- the ranks
+    # share the visible devices and gloo carries the collectives; RCCL refuses two ranks on one device.  Never a measurement.
+    backend = os.environ.get("EIGEN_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     import torch.distributed as dist
     # EIGEN_DIST_SINGLE=1 (tests): take the whole multi-rank path -- RCCL group, broadcast, all-gather, per-rank report, leaving the
     # group before rank 0's untimed legs -- in a group of ONE rank, which is all a single-GPU box can run of it
@@ -275,8 +278,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world == 1 and "MASTER_PORT" not in os.environ:
             s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); os.environ["MASTER_PORT"] = str(s_.getsockname()[1]); s_.close()
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        assert dist.get_backend() == "nccl" and dist.get_world_size() == args.gpus
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_backend() == backend and dist.get_world_size() == args.gpus
 
     shape = SHAPES[args.shape]
     W, H, CHANNELS, C_DIM, STRUCTURE, n_hidden, n_outputs, default_pop, label = shape
@@ -319,7 +325,7 @@ def main():
     dt = time.perf_counter() - t0
     multi = None
     if use_dist:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         # what every rank spent inside its shard's evaluate() (rode in the fitness all-gather itself) and what the collective cost here:
@@ -352,7 +358,7 @@ def main():
                    "channels": CHANNELS, "structure": STRUCT_NAMES[STRUCTURE],
                    "parallelism": "pop-shard x%d (%s) + all-gather(fitness f64, %s)" % (
                        world, "genome wire arrays broadcast from rank 0" if (args.source or fitness.GENOME_SOURCE) == "rank0" else "replicated seeded populations",
-                       "RCCL" if use_dist else "single process")},
+                       ("RCCL" if backend == "nccl" else backend + " (TEST backend, not a measurement)") if use_dist else "single process")},
         "stage_ms_last_step": {k: round(v, 3) for k, v in stage.items() if k.endswith("_ms") and k != "conv_ms"},
         "nonzero_fitness": int((fit != 0).sum()),
         "commit": git_head(), "kernel_sources_sha": kernel_sources_sha(),

@@ -372,6 +372,17 @@ def test_bench_gpus_flag_launches_ranks(cuda):
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "RCCL" in line["config"]["parallelism"] and len(line["multi_gpu"]["per_rank_device_ms"]) == 1 and line["multi_gpu"]["device_ms_max"] > 0
     assert line["roofline"]["all_conv_kernels"]["launches"] > 0   # rank 0's roofline pass ran after the group was left
+    # TWO ranks for real (sharding, broadcast, all-gather with per-rank times, rank 1 leaving while rank 0 profiles) -- on a 1-GPU
+    # box they share the device and gloo carries the collectives (RCCL refuses two ranks on one device): control flow, not a number
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small[:-2] + ["--no-cpu-baseline"],
+                       env=dict(env, EIGEN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly ONE JSON line (rank 0's)"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["genomes_per_gpu"] == 4 and len(line["multi_gpu"]["per_rank_device_ms"]) == 2
+    assert min(line["multi_gpu"]["per_rank_device_ms"]) > 0 and line["roofline"]["all_conv_kernels"]["launches"] > 0 and line["nonzero_fitness"] >= 0
     n = 2
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + small, env=env, capture_output=True, text=True, timeout=900)
     if torch.cuda.device_count() >= n:
