@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp
 run() { # name, counters...
   n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o $n -- python $R/bench.py --pop $POP --steps 1 --warmup 0 --no-cpu-baseline --no-roofline > $OUT/$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -o $n -- python $R/bench.py --pop $POP --steps 1 --warmup 0 --no-cpu-baseline --no-roofline --no-parity --no-supplementary > $OUT/$n.log 2>&1
   echo "pass $n rc=$?"
 }
 run sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA GRBM_GUI_ACTIVE

@@ -12,7 +12,7 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
 python $R/bench.py --steps 3 --warmup 1 > $OUT/bench.json 2> $OUT/bench.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-supplementary > $OUT/bench_under_rocprof.json 2> $OUT/rocprof.err
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 head -8 $OUT/kernel_stats.csv
 cd $R
@@ -21,7 +21,7 @@ cp $R/gpurun_out/pmc_$TAG/pmc_summary.json $OUT/pmc_summary.json 2>/dev/null
 # the bench line again, now that a PMC summary of THIS build exists (roofline.traffic)
 cp $OUT/pmc_summary.json $R/profiles/pmc_summary_latest.json
 cd /tmp
-python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/bench_with_traffic.json 2>/dev/null
+python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --no-supplementary > $OUT/bench_with_traffic.json 2>/dev/null
 rm -rf $OUT/kt $R/gpurun_out/pmc_$TAG/*/  # raw traces are large
 python - <<PY
 import json
