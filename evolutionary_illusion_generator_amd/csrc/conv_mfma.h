@@ -172,9 +172,9 @@ __device__ __forceinline__ float relu_f(float v) { return v > 0.0f ? v : 0.0f; }
 //  LDS column px + kx + 3.  An unpooled (half-resolution) source is staged at ITS resolution (rows y0/2-1 ..,
 //  chunks x0/2-4 ..) and the x2 nearest unpooling happens in the gather address ((py+ky-1)>>1, (px+kx-1)>>1).
 //  !VEC (odd widths): rows of TW+2 floats at output resolution, 4 B/lane DMA, unpooling folded into the DMA source.
-template <int TW, bool VEC> struct TileGeom {
+template <int TW, bool VEC, bool HALF = false> struct TileGeom {
     static constexpr int TH = (TW == 16) ? 16 : 8;
-    static constexpr int NIMG = 256 / (TH * TW);
+    static constexpr int NIMG = HALF ? 2 : 256 / (TH * TW);  // HALF (SPLIT == 2, 8-wide tiles): a 128-pixel block of two images
     // row stride in floats.  VEC: the aligned chunks x0-4 .. x0+TW+3 (TW + 8 floats).  16-wide: S = 24, 2 S = 16 (mod 32): the two
     // window rows x 8 even columns of a class sub-tile cover 16 distinct banks.  8-wide: S = 16 puts the four window rows of a
     // sub-tile on the same banks (4-way conflict on the A gather); one more chunk per row (EIG_S8 = 20: 2 S = 8 mod 32) would
@@ -204,14 +204,14 @@ template <int NI, int TW, bool VEC, int TAPS = 9, int NT = 256> constexpr int co
 {
     return (conv_fast_dma<NI, TW, VEC>() && !(NI == 4 && TAPS == 9)) ? ((KC * TAPS * NI * 4 + NT - 1) / NT) * NT * 4 : KC * TAPS * NI * 16;
 }
-template <int NI, int TW, bool VEC, int NT = 256> constexpr int conv_in_floats()
+template <int NI, int TW, bool VEC, int NT = 256, bool HALF = false> constexpr int conv_in_floats()
 {
-    return conv_fast_dma<NI, TW, VEC>() ? ((KC * TileGeom<TW, VEC>::PLANE / 4 + NT - 1) / NT) * NT * 4 : KC * TileGeom<TW, VEC>::PLANE;
+    return conv_fast_dma<NI, TW, VEC>() ? ((KC * TileGeom<TW, VEC>::PLANE / 4 + NT - 1) / NT) * NT * 4 : KC * TileGeom<TW, VEC, HALF>::PLANE;
 }
 // ONEKB: operators whose whole K fits ONE K-block (ConvA of the image layer: 6 channels) never stage a second buffer
-template <int NI, int TW, bool VEC, int TAPS = 9, bool ONEKB = false, int NT = 256> constexpr int conv_lds_bytes()
+template <int NI, int TW, bool VEC, int TAPS = 9, bool ONEKB = false, int NT = 256, bool HALF = false> constexpr int conv_lds_bytes()
 {
-    return (ONEKB ? 1 : 2) * (conv_in_floats<NI, TW, VEC, NT>() + conv_w_floats<NI, TW, VEC, TAPS, NT>()) * 4;
+    return (ONEKB ? 1 : 2) * (conv_in_floats<NI, TW, VEC, NT, HALF>() + conv_w_floats<NI, TW, VEC, TAPS, NT>()) * 4;
 }
 
 // FUSE (conv3x3_mfma<4, 16, EPI_LSTM, true, false, true>): LDS buffer = max(main K-block, unpooled-source K-block).
@@ -237,12 +237,16 @@ template <int NI, int TW, bool VEC> constexpr int conv_fuse_buf_floats()
 #define EIG_CONV_OCC 2  // blocks per CU the register allocation is capped for (__launch_bounds__ 2nd argument)
 #endif
 constexpr int CONV_THREADS = 256;  // 4 waves per block (W8 instantiations: 512 = 8 waves)
-// W8: EIGHT waves share the block's 256-pixel x NB-column tile -- waves 0..3 own parity classes (0, px) of the four 64-pixel
+// SPLIT = 1 (W8): EIGHT waves share the block's 256-pixel x NB-column tile -- waves 0..3 own parity classes (0, px) of the four 64-pixel
 // regions, waves 4..7 classes (1, px): two 16-row sub-tiles x NI accumulators per wave instead of four.  Same LDS tile, same
 // DMA bytes, half the accumulators and half the epilogue per wave, so FOUR waves per SIMD are resident (two blocks per CU):
 // while one block's waves run prologue / epilogue the SIMD still has two waves feeding the matrix pipe (a lone wave sustains
 // 0.70 of peak, two 0.93: scripts/mfma_occupancy.hip), and small maps whose launches do not fill the chip get twice as many
 // waves out of the same tiles.  Which lane computes a pixel changes, its fma chain does not: results are bit-identical.
+// SPLIT = 2 (H4, 8-wide tiles): the same two-classes-per-wave waves in FOUR-wave blocks of TWO images (128 pixels): wave w computes
+// classes (w >> 1, px) of image w & 1.  Twice as many blocks of half the work, each staging its own weight slab: for launches of
+// FEWER THAN TWO BLOCKS PER CU, whose time is the CU that received ceil(blocks / 256) of them -- 300 blocks on 256 CUs
+// cost two block times, 600 half blocks three halves.
 #ifndef EIG_W8_OCC
 #define EIG_W8_OCC 4  // waves per SIMD the W8 register allocation is capped for
 #endif
@@ -253,15 +257,19 @@ constexpr int CONV_THREADS = 256;  // 4 waves per block (W8 instantiations: 512 
 #ifndef EIG_ONEKB_OCC
 #define EIG_ONEKB_OCC 4  // single-K-block operators: one LDS buffer (32 KB), four blocks per CU -- their time is prologue + DMA round trip +
 #endif                   // epilogue around 216 MFMAs per wave, which only other blocks' MFMAs can cover
-template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false, bool W8 = false>
-__global__ void __launch_bounds__(W8 ? 512 : CONV_THREADS, W8 ? EIG_W8_OCC : (ONEKB ? EIG_ONEKB_OCC : ((EPI == EPI_UP4 && NI == 4 && TW == 16 && VEC) ? EIG_UP4_OCC : EIG_CONV_OCC)))
+template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false, int SPLIT = 0>
+__global__ void __launch_bounds__(SPLIT == 1 ? 512 : CONV_THREADS, SPLIT ? EIG_W8_OCC : (ONEKB ? EIG_ONEKB_OCC : ((EPI == EPI_UP4 && NI == 4 && TW == 16 && VEC) ? EIG_UP4_OCC : EIG_CONV_OCC)))
 conv3x3_mfma(const ConvArgs a)
 {
+    constexpr bool W8 = SPLIT != 0;   // two parity classes per wave (SPLIT 1: eight waves on the 256-pixel tile; SPLIT 2: four waves on two images)
+    constexpr bool H4 = SPLIT == 2;
+    static_assert(!H4 || TW == 8, "SPLIT 2: 8-wide tiles (one image per wave) only");
     static_assert(!FUSE || (EPI == EPI_LSTM && NI == 4 && TW == 16 && VEC && KC == 8 && !ONEKB), "FUSE: the wide ConvLSTM instantiation only");
     static_assert(!W8 || (VEC && !ONEKB && !FUSE && EPI != EPI_UP4C && EPI != EPI_LSTM_PACKED), "W8: 16-byte staging, per-pixel or pooled epilogues");
-    constexpr int NT = W8 ? 512 : CONV_THREADS;  // threads per block; a DMA round is NT 16-byte chunks
+    constexpr int NT = SPLIT == 1 ? 512 : CONV_THREADS;  // threads per block; a DMA round is NT 16-byte chunks
+    constexpr int NWS = H4 ? 2 : 4;              // 64-pixel regions per block
     constexpr int MI_N = W8 ? 2 : 4;             // 16-row sub-tiles (parity classes) per wave
-    using G = TileGeom<TW, VEC>;
+    using G = TileGeom<TW, VEC, H4>;
     constexpr int TH = G::TH, NIMG = G::NIMG, S = G::S, XO = G::XO, PH = G::PH, PLANE = G::PLANE;
     constexpr int NB = NI * 16;
     // EPI_UP4: the 2x2 form of `unpool x2 -> conv3x3`.  The launch runs at the SOURCE resolution; a block
@@ -282,14 +290,14 @@ conv3x3_mfma(const ConvArgs a)
 #endif
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool FAST = conv_fast_dma<NI, TW, VEC>();
-    constexpr int INF = conv_in_floats<NI, TW, VEC, NT>();  // floats of the input area (KC * PLANE, padded for FAST)
+    constexpr int INF = conv_in_floats<NI, TW, VEC, NT, H4>();  // floats of the input area (KC * PLANE, padded for FAST)
     constexpr int BUF = FUSE ? conv_fuse_buf_floats<NI, TW, VEC>() : INF + conv_w_floats<NI, TW, VEC, epi_taps(EPI), NT>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave of the block: its DMA share
-    const int ws = W8 ? (wv & 3) : wv;                         // which 64-pixel region of the tile (16-wide: rows 4 ws ..; 8-wide: image ws)
-    const int ch2 = W8 ? (wv >> 2) : 0;                        // W8: row parity py of the two classes this wave computes
+    const int ws = W8 ? (wv % NWS) : wv;                       // which 64-pixel region of the tile (16-wide: rows 4 ws ..; 8-wide: image ws)
+    const int ch2 = W8 ? (wv / NWS) : 0;                       // W8 / H4: row parity py of the two classes this wave computes
     const int q = lane >> 4;
     const int col = lane & 15;
 
@@ -457,7 +465,7 @@ conv3x3_mfma(const ConvArgs a)
         if (j < NWR) {
             const unsigned soff = soff_w;
             const bool lastw = TAPS == 9 && NI == 4 && (j == NWR - 1);
-            if (W8 && lastw && wv >= 2) return;  // wave-uniform: 128 chunks = two waves
+            if (SPLIT == 1 && lastw && wv >= 2) return;  // wave-uniform: 128 chunks = two waves
             const unsigned vo = __builtin_elementwise_add_sat((unsigned)(lastw ? vw_last : vw_full + j * NT * 16), soff);
             float* dst = buf + INF + (lastw ? (LASTW + (wv & 1) * 64) * 4 : (j * NT + wv * 64) * 4);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)dst, 16, (int)vo, 0, 0, 0);
@@ -933,7 +941,7 @@ conv3x3_mfma(const ConvArgs a)
         // W8: a pooling window's classes (0, px) and (1, px) sit in the SAME lane of the two waves ws and ws + 4 -- each takes the
         // max over its own two, the pair meets through LDS (free after the K loop), then wave ch2 stores pooled row ch2 (16-wide)
         // or the N-tiles of parity ch2 (8-wide).  max(max(v0, v1), max(v2, v3)) as before.
-        float* const xch = lds;  // [8 waves][NI][4 registers][64 lanes]
+        float* const xch = lds;  // [waves][NI][4 registers][64 lanes]
         if constexpr (W8) {
             __syncthreads();  // every wave is done reading the last K-block's operands
 #pragma unroll
@@ -958,7 +966,7 @@ conv3x3_mfma(const ConvArgs a)
 #pragma unroll
             for (int reg = 0; reg < 4; ++reg) {
                 if constexpr (W8) {
-                    const float m0 = xch[(((ws) * NI + ni) * 4 + reg) * 64 + lane], m1 = xch[(((ws + 4) * NI + ni) * 4 + reg) * 64 + lane];
+                    const float m0 = xch[(((ws) * NI + ni) * 4 + reg) * 64 + lane], m1 = xch[(((ws + NWS) * NI + ni) * 4 + reg) * 64 + lane];
                     A[reg] = fmaxf(m0, m1);
                 } else {
                     const float v0 = relu_f(acc[0][ni][reg] + bb), v1 = relu_f(acc[1][ni][reg] + bb);

@@ -358,29 +358,33 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
     return out;
 }
 
-template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false, bool W8 = false> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
+template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false, int SPLIT = 0> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
-    constexpr int NT = W8 ? 512 : CONV_THREADS;
-    constexpr int lds = FUSE ? 2 * conv_fuse_buf_floats<NI, TW, VEC>() * 4 : conv_lds_bytes<NI, TW, VEC, epi_taps(EPI), ONEKB, NT>();
+    constexpr int NT = SPLIT == 1 ? 512 : CONV_THREADS;
+    constexpr int lds = FUSE ? 2 * conv_fuse_buf_floats<NI, TW, VEC>() * 4 : conv_lds_bytes<NI, TW, VEC, epi_taps(EPI), ONEKB, NT, SPLIT == 2>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE, W8>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE, W8>), dim3(grid), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE, SPLIT>), dim3(grid), dim3(NT), lds, st, a);
     return hipGetLastError();
 }
 
-// w8: the eight-wave instantiation (conv_mfma.h: W8) -- 16-byte staging only, chosen per operator in eigen_set_prednet_weights
-template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec, bool w8 = false)
+// split: 0 four waves x four classes; 1 the eight-wave instantiation (conv_mfma.h: W8); 2 four-wave half blocks of two images (H4,
+// 8-wide tiles) -- 16-byte staging only, chosen per launch in launch_conv
+template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec, int split = 0)
 {
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP || EPI == EPI_CONVA || EPI == EPI_UP4 || EPI == EPI_RAW) {
-        if (w8 && vec) return launch_inst2<NI, TW, EPI, true, false, false, true>(a, grid, st);
+        if constexpr (TW == 8) {
+            if (split == 2 && vec) return launch_inst2<NI, TW, EPI, true, false, false, 2>(a, grid, st);
+        }
+        if (split && vec) return launch_inst2<NI, TW, EPI, true, false, false, 1>(a, grid, st);
     }
     return vec ? launch_inst2<NI, TW, EPI, true>(a, grid, st) : launch_inst2<NI, TW, EPI, false>(a, grid, st);
 }
 
-template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& a, int grid, hipStream_t st, bool vec, bool w8 = false)
+template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& a, int grid, hipStream_t st, bool vec, int w8 = 0)
 {
     if (TW == 16) {
         switch (NI) {
@@ -408,8 +412,9 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     a.n_nblk = op.n_nblk; a.krows = op.krows; a.wpk = op.d_wpk; a.Cout = op.Cout; a.zeros = e->d_zeros;
     a.nsrc = op.nsrc;
     for (int s = 0; s < op.nsrc; ++s) { a.src[s].C = op.src_C[s]; a.src[s].Cpad = pad4(op.src_C[s]); a.src[s]._reserved = 0; a.src[s].Ct = op.src_Ct[s] ? op.src_Ct[s] : op.src_C[s]; }
-    const int ntile = ((batch + NIMG - 1) / NIMG) * a.tilesX * a.tilesY;
-    const int grid = op.n_nblk * (op.epi == EPI_UP4 ? 4 : 1) * ((ntile + 7) / 8) * 8;  // XCD-aware tile map (conv_mfma.h): tiles padded to a multiple of 8
+    int ntile = ((batch + NIMG - 1) / NIMG) * a.tilesX * a.tilesY;
+    const int per_tile = op.n_nblk * (op.epi == EPI_UP4 ? 4 : 1);
+    int grid = per_tile * ((ntile + 7) / 8) * 8;  // XCD-aware tile map (conv_mfma.h): tiles padded to a multiple of 8
     // 16-byte DMA staging needs chunk-aligned rows: W % 4 == 0
     const bool vec = (op.W % 4) == 0;
 #if EIG_TIMING
@@ -431,7 +436,18 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     // 8 the 2x2-form pass, 16 raw test convolutions), EIGEN_W8=0 switches it off: A/B measurements and the parity tests.
     static const int w8_env = getenv("EIGEN_W8") ? atoi(getenv("EIGEN_W8")) : -1;
     const int w8_mask = w8_env >= 0 ? w8_env : (grid <= EIGEN_W8_GRID ? 15 : 0);
-    const bool w8 = w8_mask != 0 && vec && (op.epi != EPI_LSTM || (w8_mask & 1));
+    const int cls_bit = op.epi == EPI_LSTM ? 1 : (op.epi == EPI_CONVA ? 2 : (op.epi == EPI_CONVP ? 4 : (op.epi == EPI_UP4 ? 8 : (op.epi == EPI_RAW ? 16 : 0))));
+    int w8 = (vec && (w8_mask & cls_bit)) ? 1 : 0;  // 0: four waves x four classes, 1: eight waves, 2: half blocks (below)
+    // Half blocks (conv_mfma.h: SPLIT 2, 8-wide tiles): two images per block instead of four.  A launch of fewer than ~2 blocks per CU
+    // takes as long as the CU that received ceil(blocks / 256) of them; twice as many blocks of (a little more than) half the work
+    // are chosen when that model says so -- 300 blocks: 2 block times against 3 x 0.55.  EIGEN_H4 = 1 / 0 forces it on / off (A/B).
+    if (w8 && op.TW == 8) {
+        static const int h4_env = getenv("EIGEN_H4") ? atoi(getenv("EIGEN_H4")) : -1;
+        const int ntile2 = ((batch + 1) / 2) * a.tilesX * a.tilesY;
+        const long b1 = (long)per_tile * ntile, b2 = (long)per_tile * ntile2;
+        const bool pays = ((b2 + 255) / 256) * 0.55 < (double)((b1 + 255) / 256);
+        if (h4_env >= 0 ? h4_env != 0 : pays) { w8 = 2; ntile = ntile2; grid = per_tile * ((ntile + 7) / 8) * 8; }
+    }
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
     static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
@@ -465,13 +481,13 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             // the image layer's ConvA (K = 9 x 6 channels): one K-block, its own instantiation (conv_mfma.h: ONEKB)
             static const bool onekb = !(getenv("EIGEN_NO_ONEKB") && atoi(getenv("EIGEN_NO_ONEKB")));  // A/B measurements only
             if (onekb && op.NI == 3 && op.TW == 16 && vec && op.nsrc == 1 && pad4(op.src_C[0]) <= KC) r = launch_inst2<3, 16, EPI_CONVA, true, true>(a, grid, st);
-            else r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st, vec, w8 && (w8_mask & 2));
+            else r = launch_epi<EPI_CONVA>(op.NI, op.TW, a, grid, st, vec, w8);
             break;
         }
-        case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st, vec, w8 && (w8_mask & 4)); break;
-        case EPI_UP4: r = launch_epi<EPI_UP4>(op.NI, op.TW, a, grid, st, vec, w8 && (w8_mask & 8)); break;
+        case EPI_CONVP: r = launch_epi<EPI_CONVP>(op.NI, op.TW, a, grid, st, vec, w8); break;
+        case EPI_UP4: r = launch_epi<EPI_UP4>(op.NI, op.TW, a, grid, st, vec, w8); break;
         case EPI_UP4C: r = launch_inst2<4, 16, EPI_UP4C, true>(a, grid, st); break;  // chosen only for 16-wide tiles and 16-byte staging
-        default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec, w8 && (w8_mask & 16)); break;  // (eigen_test_conv)
+        default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec, w8); break;  // (eigen_test_conv)
     }
 #if EIG_TIMING
     if (tl_dbg) {

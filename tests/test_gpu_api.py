@@ -242,6 +242,7 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
     # round 3: the eight-wave instantiations (chosen by launch size: these small roll-outs take them by default) forced off / on
     # for every operator class, with and without the separate 2x2 pass; ConvP_l forked onto the side stream
     for env in ({"EIGEN_W8": "0"}, {"EIGEN_W8": "31"}, {"EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_W8": "0", "EIGEN_FUSEUP": "0"},
-                {"EIGEN_SIDE_STREAM": "1"}, {"EIGEN_SIDE_STREAM": "1", "EIGEN_W8": "0"}):
+                {"EIGEN_SIDE_STREAM": "1"}, {"EIGEN_SIDE_STREAM": "1", "EIGEN_W8": "0"},
+                {"EIGEN_H4": "1", "EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_H4": "0", "EIGEN_W8": "31"}):  # half blocks forced on / off
         assert run(env) == base, env
     assert run({"EIGEN_FUSEUP": "0"}) == base  # these small roll-outs take the in-kernel chain by default: the separate pass
