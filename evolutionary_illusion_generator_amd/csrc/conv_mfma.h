@@ -173,14 +173,14 @@ __device__ __forceinline__ float relu_f(float v) { return v > 0.0f ? v : 0.0f; }
 //  chunks x0/2-4 ..) and the x2 nearest unpooling happens in the gather address ((py+ky-1)>>1, (px+kx-1)>>1).
 //  !VEC (odd widths): rows of TW+2 floats at output resolution, 4 B/lane DMA, unpooling folded into the DMA source.
 template <int TW, bool VEC, bool HALF = false> struct TileGeom {
-    static constexpr int TH = (TW == 16) ? 16 : 8;
-    static constexpr int NIMG = HALF ? 2 : 256 / (TH * TW);  // HALF (SPLIT == 2, 8-wide tiles): a 128-pixel block of two images
+    static constexpr int TH = (TW == 8) ? 8 : 16;            // 16 x 16 of one image, 8 x 8 or (TW = 4) 4 wide x 16 tall of several
+    static constexpr int NIMG = HALF ? 2 : 256 / (TH * TW);  // HALF (SPLIT == 2, 8- and 4-wide tiles): a 128-pixel block of two images
     // row stride in floats.  VEC: the aligned chunks x0-4 .. x0+TW+3 (TW + 8 floats).  16-wide: S = 24, 2 S = 16 (mod 32): the two
     // window rows x 8 even columns of a class sub-tile cover 16 distinct banks.  8-wide: S = 16 puts the four window rows of a
     // sub-tile on the same banks (4-way conflict on the A gather); one more chunk per row (EIG_S8 = 20: 2 S = 8 mod 32) would
     // make it conflict-free but takes the block from 78 to 88 KB of LDS = ONE block per CU: measured 362 vs 396+ evals/s at
     // 160x120 colour, so the conflicts are the cheaper evil (scripts/ab_bench.sh).
-    static constexpr int S = VEC ? (TW == 16 ? TW + 8 : EIG_S8) : TW + 2;
+    static constexpr int S = VEC ? (TW == 16 ? TW + 8 : (TW == 4 ? 12 : EIG_S8)) : TW + 2;  // 4-wide: chunks x0-4 .. x0+7
     static constexpr int XO = VEC ? 3 : 0;
     static constexpr int PH = TH + 2;
     static constexpr int PLANE = NIMG * PH * S;  // floats per channel in LDS
@@ -263,7 +263,11 @@ conv3x3_mfma(const ConvArgs a)
 {
     constexpr bool W8 = SPLIT != 0;   // two parity classes per wave (SPLIT 1: eight waves on the 256-pixel tile; SPLIT 2: four waves on two images)
     constexpr bool H4 = SPLIT == 2;
-    static_assert(!H4 || TW == 8, "SPLIT 2: 8-wide tiles (one image per wave) only");
+    static_assert(!H4 || TW == 8 || TW == 4, "SPLIT 2: 8- or 4-wide tiles (one image per wave) only");
+    // TW = 4: regions of 4 columns x 16 rows (2 x 8 pooling windows) for maps that 8 x 8 tiles cover badly -- 20 x 15 (the top layer of the
+    // reference's own 160 x 120): five strips = 94 % instead of six 8 x 8 tiles = 78 %.  A lane owns rows 4 q .. 4 q + 3 x the 4 columns, so
+    // every epilogue indexes its accumulators exactly as the 16-wide map does; only as half blocks (the 12-float rows cost LDS).
+    static_assert(TW != 4 || (H4 && VEC && EPI != EPI_LSTM_PACKED && EPI != EPI_UP4C), "4-wide tiles: half blocks with 16-byte staging only");
     static_assert(!FUSE || (EPI == EPI_LSTM && NI == 4 && TW == 16 && VEC && KC == 8 && !ONEKB), "FUSE: the wide ConvLSTM instantiation only");
     static_assert(!W8 || (VEC && !ONEKB && !FUSE && EPI != EPI_UP4C && EPI != EPI_LSTM_PACKED), "W8: 16-byte staging, per-pixel or pooled epilogues");
     constexpr int NT = SPLIT == 1 ? 512 : CONV_THREADS;  // threads per block; a DMA round is NT 16-byte chunks
@@ -534,8 +538,8 @@ conv3x3_mfma(const ConvArgs a)
     // k = 4*step + j, (channel, tap) = divmod(k, 9): period 9 steps = 4 channels -> nine address registers per layout.
     int addrA[9];
     // class-major map: MFMA row r of sub-tile (py, px) is pixel (2 wy + py, 2 wx + px) of the wave's region
-    const int g_wy = (TW == 16) ? (col & 3) >> 1 : col >> 2;
-    const int g_wx = (TW == 16) ? 2 * (col >> 2) + (col & 1) : col & 3;
+    const int g_wy = (TW == 16) ? (col & 3) >> 1 : (TW == 4 ? 2 * (col >> 2) + ((col & 3) >> 1) : col >> 2);
+    const int g_wx = (TW == 16) ? 2 * (col >> 2) + (col & 1) : (TW == 4 ? col & 1 : col & 3);
     const int g_base = ((TW == 16) ? (ws * 4 + 2 * g_wy) * S + 2 * g_wx + XO      // sub-tile of class (py, px) adds py * S + px
                                    : ws * PH * S + 2 * g_wy * S + 2 * g_wx + XO)  // one image per wave
                        + ch2 * S;  // W8: this wave's classes are (ch2, 0) and (ch2, 1) -- the row parity goes into the base register
@@ -577,7 +581,7 @@ conv3x3_mfma(const ConvArgs a)
     // saturate the wave's outstanding vector-memory operations and the CU's address path in front of the first MFMA (round 1:
     // 21K cycles, scripts/timeline.py), so they are SPREAD over the MFMA steps of K-block 0 and land long before the K loop ends.
     constexpr bool HAS_UP = !FUSE && (EPI == EPI_LSTM || EPI == EPI_LSTM_PACKED || EPI == EPI_RAW);  // operators that can be handed an unpooled source's chain
-    constexpr int UPV = (TW == 16) ? 2 : 1;             // loads per (class, N-tile)
+    constexpr int UPV = (TW != 8) ? 2 : 1;              // loads per (class, N-tile)
     constexpr int NUPL = HAS_UP ? MI_N * NI * UPV : 0;  // loads per lane
     f32x4 upc[MI_N][HAS_UP ? NI : 1];
     const bool has_up = HAS_UP && a.acc_init != nullptr;
@@ -592,7 +596,7 @@ conv3x3_mfma(const ConvArgs a)
 #pragma unroll
         for (int v = 0; v < UPV; ++v) {
             // window row / first window column of this load, in pixels of THIS launch's resolution
-            const int gy0 = (TW == 16) ? y0 + 4 * ws + 2 * v : tyi * TH + 2 * q;
+            const int gy0 = (TW == 16) ? y0 + 4 * ws + 2 * v : (TW == 4 ? tyi * TH + 4 * q + 2 * v : tyi * TH + 2 * q);
             const int gx0 = (TW == 16) ? x0 + 4 * q : txi * TW;
             // element offset inside this wave's image block [4][n_nblk*NB][Hs][Ws] (the image is wave-uniform); windows outside
             // the image read element 0 instead -- their accumulators are never stored
@@ -606,7 +610,7 @@ conv3x3_mfma(const ConvArgs a)
     const __amdgpu_buffer_rsrc_t rs_up = __builtin_amdgcn_make_buffer_rsrc((void*)up_base, 0, has_up ? 4 * up_cstride * 4 : 0, 0x00020000);
     auto up_load = [&](int mi, int ni, int v) __attribute__((always_inline)) {
         const int soff = (ni * 16 * up_hw + (W8 ? 2 * ch2 + mi : mi) * up_cstride) * 4;  // plane = parity class of sub-tile mi
-        if constexpr (TW == 16) {
+        if constexpr (TW != 8) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_up, up_off[v], soff, 0));
             upc[mi][ni][2 * v] = t[0]; upc[mi][ni][2 * v + 1] = t[1];
@@ -794,15 +798,15 @@ conv3x3_mfma(const ConvArgs a)
     const int eb = bgrp * NIMG + (TW == 16 ? 0 : ws);          // image of this wave
     const int ey0 = (TW == 16) ? y0 + 4 * ws : tyi * TH;       // first row / column of the wave's region
     const int ex0 = (TW == 16) ? x0 : txi * TW;
-    auto seg_row = [&](int sgi) __attribute__((always_inline)) { return ey0 + ((TW == 16) ? sgi : 2 * q + (sgi >> 1)); };
-    auto seg_col = [&](int sgi) __attribute__((always_inline)) { return ex0 + ((TW == 16) ? 4 * q : 4 * (sgi & 1)); };
+    auto seg_row = [&](int sgi) __attribute__((always_inline)) { return ey0 + ((TW == 16) ? sgi : (TW == 4 ? 4 * q + sgi : 2 * q + (sgi >> 1))); };
+    auto seg_col = [&](int sgi) __attribute__((always_inline)) { return ex0 + ((TW == 16) ? 4 * q : (TW == 4 ? 0 : 4 * (sgi & 1))); };
     // A wave walks its segments sl = 0 .. NSEG-1.  !W8: all four (sgi = sl).  W8: the two whose row parity is this wave's ch2
     // (16-wide: rows ch2, ch2 + 2 of the region; 8-wide: row 2 q + ch2, both column halves); element j of such a segment is
     // register 2 sl + (j >> 1) of the wave's sub-tile j & 1 -- compile-time indices either way.
     constexpr int NSEG = W8 ? 2 : 4;
-#define EIG_SGI(sl) (W8 ? ((TW == 16) ? ch2 + 2 * (sl) : 2 * ch2 + (sl)) : (sl))
-#define EIG_SEG_MI(sl, j) (W8 ? ((j) & 1) : ((TW == 16) ? 2 * ((sl) & 1) + ((j) & 1) : 2 * ((sl) >> 1) + ((j) & 1)))
-#define EIG_SEG_REG(sl, j) (W8 ? 2 * (sl) + ((j) >> 1) : ((TW == 16) ? 2 * ((sl) >> 1) + ((j) >> 1) : 2 * ((sl) & 1) + ((j) >> 1)))
+#define EIG_SGI(sl) (W8 ? ((TW != 8) ? ch2 + 2 * (sl) : 2 * ch2 + (sl)) : (sl))
+#define EIG_SEG_MI(sl, j) (W8 ? ((j) & 1) : ((TW != 8) ? 2 * ((sl) & 1) + ((j) & 1) : 2 * ((sl) >> 1) + ((j) & 1)))
+#define EIG_SEG_REG(sl, j) (W8 ? 2 * (sl) + ((j) >> 1) : ((TW != 8) ? 2 * ((sl) >> 1) + ((j) >> 1) : 2 * ((sl) & 1) + ((j) >> 1)))
     const bool alive = eb < a.B;
     if (!alive && !(W8 && EPI == EPI_CONVA)) { timeline_record(0); return; }  // (W8 ConvA: every wave takes part in the pooling exchange)
 
@@ -935,9 +939,9 @@ conv3x3_mfma(const ConvArgs a)
         // 2 rows x 2 contiguous columns (two 8-byte accesses per tensor), 8-wide tiles 1 row x 4 columns (one 16-byte access).
         const int Ho = a.H >> 1, Wo = a.W >> 1;
         const size_t plane = (size_t)Ho * Wo;
-        constexpr int NPR = (TW == 16) ? 2 : 1, NPC = (TW == 16) ? 2 : 4;  // pooled rows x contiguous pooled columns per lane
-        const int pyo = (ey0 >> 1) + ((TW == 16) ? 0 : q), pxo = (ex0 >> 1) + ((TW == 16) ? 2 * q : 0);
-        const bool vec_ok = VEC && (TW == 16 || (a.W % 8) == 0);  // 16-wide: W % 4 == 0 makes the pooled pairs 8-byte aligned; 8-wide: 16-byte rows need Wo % 4 == 0
+        constexpr int NPR = (TW != 8) ? 2 : 1, NPC = (TW != 8) ? 2 : 4;  // pooled rows x contiguous pooled columns per lane
+        const int pyo = (ey0 >> 1) + ((TW == 16) ? 0 : (TW == 4 ? 2 * q : q)), pxo = (ex0 >> 1) + ((TW == 16) ? 2 * q : 0);
+        const bool vec_ok = VEC && (TW != 8 || (a.W % 8) == 0);  // 16-wide: W % 4 == 0 makes the pooled pairs 8-byte aligned; 8-wide: 16-byte rows need Wo % 4 == 0
         // W8: a pooling window's classes (0, px) and (1, px) sit in the SAME lane of the two waves ws and ws + 4 -- each takes the
         // max over its own two, the pair meets through LDS (free after the K loop), then wave ch2 stores pooled row ch2 (16-wide)
         // or the N-tiles of parity ch2 (8-wide).  max(max(v0, v1), max(v2, v3)) as before.
@@ -959,8 +963,8 @@ conv3x3_mfma(const ConvArgs a)
         for (int ni = 0; ni < NI; ++ni) {
             const int ch = nblk * NB + ni * 16 + col;
             if (ch >= a.Cout) continue;
-            if (W8 && TW != 16 && NI > 1 && (ni & 1) != ch2) continue;   // 8-wide: the pair splits the N-tiles
-            if (W8 && TW != 16 && NI == 1 && ch2 != 0) continue;
+            if (W8 && TW == 8 && NI > 1 && (ni & 1) != ch2) continue;   // 8-wide: the pair splits the N-tiles
+            if (W8 && TW == 8 && NI == 1 && ch2 != 0) continue;
             const float bb = a.bias[ch];
             float A[4];
 #pragma unroll
@@ -979,12 +983,12 @@ conv3x3_mfma(const ConvArgs a)
             float* Ec2 = Ec + (size_t)a.Cout * plane;
 #pragma unroll
             for (int pr = 0; pr < NPR; ++pr) {
-                if (W8 && TW == 16 && pr != ch2) continue;  // 16-wide: wave ch2 of the pair stores pooled row ch2
+                if (W8 && TW != 8 && pr != ch2) continue;  // 16- / 4-wide: wave ch2 of the pair stores pooled row ch2
                 const int yo = pyo + pr;
                 if (yo >= Ho || pxo >= Wo) continue;
                 const size_t o = (size_t)yo * Wo + pxo;
                 if (vec_ok) {
-                    if constexpr (TW == 16) {
+                    if constexpr (TW != 8) {
                         const f32x2 p2 = *reinterpret_cast<const f32x2*>(Pc + o);
                         const float A0 = A[2 * pr], A1 = A[2 * pr + 1];
                         *reinterpret_cast<f32x2*>(Ec + o) = (f32x2){relu_f(A0 - p2[0]), relu_f(A1 - p2[1])};
@@ -999,7 +1003,7 @@ conv3x3_mfma(const ConvArgs a)
 #pragma unroll
                 for (int pc = 0; pc < NPC; ++pc) {
                     if (pxo + pc >= Wo) continue;
-                    const float Av = A[(TW == 16) ? 2 * pr + pc : pc];
+                    const float Av = A[(TW != 8) ? 2 * pr + pc : pc];
                     const float p = Pc[o + pc];
                     Ec[o + pc] = relu_f(Av - p);
                     Ec2[o + pc] = relu_f(p - Av);

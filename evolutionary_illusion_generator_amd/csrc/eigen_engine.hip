@@ -232,14 +232,20 @@ static void choose_ni(int Cout, bool lstm, int* NI, int* n_nblk)
     *NI = best; *n_nblk = (Cout + 16 * best - 1) / (16 * best);
 }
 
-static int choose_tw(int H, int W)
+// Tile shape of an operator: 16 x 16, 8 x 8 or -- allow4: operators that have the half-block instantiations, on maps whose width takes
+// 16-byte staging -- strips of 4 columns x 16 rows, when they cover the map at least 15 % better than the best square tile (20 x 15:
+// 94 % against 78 %; their 12-float LDS rows and the half blocks they come as cost about a tenth, conv_mfma.h).  EIGEN_NO_TW4=1: A/B.
+static int choose_tw(int H, int W, bool allow4 = false)
 {
     auto util = [&](int tw) {
-        const int th = (tw == 16) ? 16 : 8;
+        const int th = (tw == 8) ? 8 : 16;
         const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
         return (double)H * W / ((double)ty * th * tx * tw);
     };
-    return (util(16) + 1e-9 >= util(8)) ? 16 : 8;
+    const int sq = (util(16) + 1e-9 >= util(8)) ? 16 : 8;
+    static const bool no4 = getenv("EIGEN_NO_TW4") && atoi(getenv("EIGEN_NO_TW4"));
+    if (allow4 && !no4 && (W % 4) == 0 && util(4) >= 1.15 * util(sq)) return 4;
+    return sq;
 }
 
 // Pack OIHW weights of one fused conv into [n_nblk][krows][NB]; row = (source, channel (padded to 4), tap).
@@ -376,12 +382,15 @@ template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = fal
 template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec, int split = 0)
 {
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP || EPI == EPI_CONVA || EPI == EPI_UP4 || EPI == EPI_RAW) {
-        if constexpr (TW == 8) {
+        if constexpr (TW == 8 || TW == 4) {
             if (split == 2 && vec) return launch_inst2<NI, TW, EPI, true, false, false, 2>(a, grid, st);
         }
-        if (split && vec) return launch_inst2<NI, TW, EPI, true, false, false, 1>(a, grid, st);
+        if constexpr (TW != 4) {
+            if (split && vec) return launch_inst2<NI, TW, EPI, true, false, false, 1>(a, grid, st);
+        }
     }
-    return vec ? launch_inst2<NI, TW, EPI, true>(a, grid, st) : launch_inst2<NI, TW, EPI, false>(a, grid, st);
+    if constexpr (TW == 4) return hipErrorInvalidConfiguration;  // 4-wide strips: half blocks with 16-byte staging only (choose_tw)
+    else return vec ? launch_inst2<NI, TW, EPI, true>(a, grid, st) : launch_inst2<NI, TW, EPI, false>(a, grid, st);
 }
 
 template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& a, int grid, hipStream_t st, bool vec, int w8 = 0)
@@ -394,6 +403,17 @@ template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& 
             default: return launch_inst<4, 16, EPI>(a, grid, st, vec, w8);
         }
     }
+    if (TW == 4) {
+        if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP || EPI == EPI_CONVA || EPI == EPI_UP4 || EPI == EPI_RAW) {
+            switch (NI) {
+                case 1: return launch_inst<1, 4, EPI>(a, grid, st, vec, w8);
+                case 2: return launch_inst<2, 4, EPI>(a, grid, st, vec, w8);
+                case 3: return launch_inst<3, 4, EPI>(a, grid, st, vec, w8);
+                default: return launch_inst<4, 4, EPI>(a, grid, st, vec, w8);
+            }
+        }
+        return hipErrorInvalidConfiguration;
+    }
     switch (NI) {
         case 1: return launch_inst<1, 8, EPI>(a, grid, st, vec, w8);
         case 2: return launch_inst<2, 8, EPI>(a, grid, st, vec, w8);
@@ -404,8 +424,8 @@ template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& 
 
 static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batch, hipStream_t st)
 {
-    const int TH = (op.TW == 16) ? 16 : 8;
-    const int NIMG = 256 / (TH * op.TW);
+    const int TH = (op.TW == 8) ? 8 : 16;
+    const int NIMG = op.TW == 4 ? 2 : 256 / (TH * op.TW);  // 4-wide strips exist as half blocks (two images) only
     a.H = op.H; a.W = op.W; a.B = batch;
     a.tilesX = (op.W + op.TW - 1) / op.TW;
     a.tilesY = (op.H + TH - 1) / TH;
@@ -441,7 +461,8 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     // Half blocks (conv_mfma.h: SPLIT 2, 8-wide tiles): two images per block instead of four.  A launch of fewer than ~2 blocks per CU
     // takes as long as the CU that received ceil(blocks / 256) of them; twice as many blocks of (a little more than) half the work
     // are chosen when that model says so -- 300 blocks: 2 block times against 3 x 0.55.  EIGEN_H4 = 1 / 0 forces it on / off (A/B).
-    if (w8 && op.TW == 8) {
+    if (op.TW == 4) w8 = 2;  // (choose_tw only hands out 4-wide strips where 16-byte staging and the half-block instantiations exist)
+    else if (w8 && op.TW == 8) {
         static const int h4_env = getenv("EIGEN_H4") ? atoi(getenv("EIGEN_H4")) : -1;
         const int ntile2 = ((batch + 1) / 2) * a.tilesX * a.tilesY;
         const long b1 = (long)per_tile * ntile, b2 = (long)per_tile * ntile2;
@@ -474,7 +495,8 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     switch (op.epi) {
         case EPI_LSTM:
             if (op.fused && a.up_src) r = launch_inst2<4, 16, EPI_LSTM, true, false, true>(a, grid, st);  // chain of the unpooled source in-kernel
-            else r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec, w8) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec, w8);
+            else r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec, w8)
+                                   : (op.TW == 4 ? launch_inst<4, 4, EPI_LSTM>(a, grid, st, vec, w8) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec, w8));
             break;
         case EPI_LSTM_PACKED: r = (op.TW == 16) ? launch_inst<1, 16, EPI_LSTM_PACKED>(a, grid, st, vec) : launch_inst<1, 8, EPI_LSTM_PACKED>(a, grid, st, vec); break;
         case EPI_CONVA: {
@@ -680,7 +702,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             op.epi = EPI_CONVA; op.layer = l; op.nsrc = 1; op.src_C[0] = 2 * e->layer[l - 1].C;
             op.H = e->layer[l - 1].H; op.W = e->layer[l - 1].W; op.Cout = C;
             choose_ni(C, false, &op.NI, &op.n_nblk);
-            op.TW = choose_tw(op.H, op.W);
+            op.TW = choose_tw(op.H, op.W, true);
             op.krows = pad4(op.src_C[0]) * 9;
             op.macs = (double)op.H * op.W * C * op.src_C[0] * 9;
             const float* sw[3][4] = {{convA_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
@@ -704,7 +726,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             choose_ni(C, true, &op.NI, &op.n_nblk);
             if (C <= 4) { op.epi = EPI_LSTM_PACKED; op.NI = 1; op.n_nblk = 1; }  // 4 gates x <=4 channels in one MFMA tile
             const int lstm_mode = (op.epi == EPI_LSTM_PACKED) ? 2 : 1;
-            op.TW = choose_tw(op.H, op.W);
+            op.TW = choose_tw(op.H, op.W, op.epi == EPI_LSTM);
             op.krows = 0; op.macs = 0;
             for (int s = 0; s < op.nsrc; ++s) { op.krows += pad4(op.src_C[s]) * 9; op.macs += (double)y.H * y.W * 4 * C * op.src_C[s] * 9; }
             const float* sw[3][4];
@@ -757,7 +779,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             if (l < L - 1 && !fused) {  // R_{l+1}, at ITS resolution; columns = the ConvLSTM's
                 const Layer& yu = e->layer[l + 1];
                 u.epi = EPI_UP4; u.layer = l; u.nsrc = 1; u.src_C[0] = e->layer[l + 1].C; u.H = yu.H; u.W = yu.W; u.Cout = C;
-                u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W);
+                u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W, lstm_mode == 1);
                 u.krows = pad4(u.src_C[0]) * 4;
                 u.macs = (double)y.H * y.W * 4 * C * u.src_C[0] * 4;  // 4 taps per output pixel and channel instead of 9
                 const size_t need = (size_t)e->B * 4 * u.n_nblk * u.NI * 16 * u.H * u.W;
@@ -783,7 +805,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             op.epi = EPI_CONVP; op.layer = l; op.nsrc = 1; op.src_C[0] = C;
             op.H = y.H; op.W = y.W; op.Cout = C;
             choose_ni(C, false, &op.NI, &op.n_nblk);
-            op.TW = choose_tw(op.H, op.W);
+            op.TW = choose_tw(op.H, op.W, l > 0);
             op.krows = pad4(C) * 9;
             op.macs = (double)y.H * y.W * C * C * 9;
             const float* sw[3][4] = {{convP_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
@@ -1227,7 +1249,7 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
     ConvOp op;
     op.epi = EPI_RAW; op.nsrc = 0; op.H = H; op.W = W; op.Cout = cout;
     choose_ni(cout, false, &op.NI, &op.n_nblk);
-    op.TW = choose_tw(H, W);
+    op.TW = choose_tw(H, W, true);
     op.krows = 0;
     const float* sw[3][4] = {{nullptr}, {nullptr}, {nullptr}};
     ConvArgs a;
@@ -1247,7 +1269,7 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
     float* d_raw4 = nullptr;
     if (n_up) {
         u.epi = EPI_UP4; u.nsrc = 1; u.src_C[0] = cin[i_up]; u.H = H / 2; u.W = W / 2; u.Cout = cout;
-        u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W);
+        u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W, true);
         u.krows = pad4(cin[i_up]) * 4;
         const float* uw[4] = {h_w[i_up], nullptr, nullptr, nullptr};
         std::vector<float> pku = pack_weights_up4(u, uw, 0);

@@ -51,6 +51,11 @@ CONV_CASES = [
     (2, 12, 10, 16, [(8, 0)]),            # W % 4 != 0: 4-byte DMA path (VEC = false)
     (3, 6, 6, 8, [(5, 0), (4, 1)]),       # tiny odd map with an unpooled 3x3 source
     (1, 48, 80, 64, [(16, 0), (16, 1)]),  # W % 8 == 0: unpooled source staged at its own resolution
+    # round 3: strips of 4 columns x 16 rows (conv_mfma.h TW = 4, half blocks of two images) where they cover the map >= 15 % better
+    (5, 15, 20, 64, [(24, 0)]),           # 20 x 15, the top-layer map of 160 x 120: five strips, odd image count, ragged last row
+    (3, 16, 20, 40, [(12, 0), (8, 1)]),   # 4-wide main chain + the chain of an unpooled 10 x 8 source added after the K loop
+    (2, 32, 40, 32, [(8, 0), (16, 1)]),   # the 2x2-form pass itself on 4-wide strips (source 20 x 16), main chain on 8 x 8 tiles
+    (4, 16, 20, 100, [(20, 0)]),          # 4-wide, two N-blocks, a partial last K-block
 ]
 
 
@@ -136,7 +141,9 @@ def test_cppn_render_saturating_bands_byte_exact(cuda, oracle_lib, w, h, structu
                                               (20, 12, [1, 4, 8], False),   # widths 20 / 10 / 5: mixed VEC and 4-byte DMA layers
                                               # the unpooled source's chain INSIDE the ConvLSTM kernel (FUSE): partial last K-block
                                               # (12 channels) with ragged tile rows (layer 1: 80 x 60 = 3.75 tiles), one-K-block source (8)
-                                              (160, 120, [1, 8, 12, 8], False), (64, 96, [1, 8, 12, 8], True)])
+                                              (160, 120, [1, 8, 12, 8], False), (64, 96, [1, 8, 12, 8], True),
+                                              # five layers, 20 x 16 maps at layer 3: ConvA_4 / ConvLSTM_3 / ConvP_3 / the 2x2 pass of layer 2 on 4-wide strips
+                                              (160, 128, [1, 4, 8, 8, 8], False)])
 def test_prednet_rollout_frames_bit_exact(cuda, oracle_lib, w, h, ch, requant, monkeypatch):
     import torch
     if ch == [1, 8, 12, 8]:
