@@ -466,7 +466,8 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         static const int h4_env = getenv("EIGEN_H4") ? atoi(getenv("EIGEN_H4")) : -1;
         const int ntile2 = ((batch + 1) / 2) * a.tilesX * a.tilesY;
         const long b1 = (long)per_tile * ntile, b2 = (long)per_tile * ntile2;
-        const bool pays = ((b2 + 255) / 256) * 0.55 < (double)((b1 + 255) / 256);
+        static const double h4_factor = getenv("EIGEN_H4_FACTOR") ? atof(getenv("EIGEN_H4_FACTOR")) : 0.55;  // cost of a half block in block times (A/B)
+        const bool pays = ((b2 + 255) / 256) * h4_factor < (double)((b1 + 255) / 256);
         if (h4_env >= 0 ? h4_env != 0 : pays) { w8 = 2; ntile = ntile2; grid = per_tile * ((ntile + 7) / 8) * 8; }
     }
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
