@@ -205,7 +205,7 @@ sys.path.insert(0, %(root)r)
 from evolutionary_illusion_generator_amd import weights
 from evolutionary_illusion_generator_amd.engine import Engine
 out = []
-for (w, h, ch) in [(64, 64, [3, 12, 24, 48]), (96, 64, [1, 8, 16])]:
+for (w, h, ch) in [(64, 64, [3, 12, 24, 48]), (96, 64, [1, 8, 16]), (80, 64, [1, 4, 8])]:  # the last one has 20 x 16 maps: 4-wide strips
     rng = np.random.default_rng(7)
     B = 3
     img = rng.integers(0, 256, (B, ch[0], h, w), dtype=np.uint8)
@@ -223,7 +223,7 @@ print("FRAMES", *out)
 
 def test_specialised_operators_equal_the_general_mfma_path(cuda):
     """Every A/B switch of the engine (step-0 operators, single-K-block ConvA, one-block 2x2 pass, the two direct image-layer
-    kernels, the in-kernel chain of the unpooled source) turned off one at a time in a fresh process: all six PredNet frames of two small roll-outs are byte-identical."""
+    kernels, the in-kernel chain of the unpooled source) turned off one at a time in a fresh process: all six PredNet frames of three small roll-outs are byte-identical."""
     import subprocess
     script = _FRAMES_SCRIPT % {"root": ROOT}
 
@@ -241,8 +241,8 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
         assert run({switch: "1"}) == base, switch
     # round 3: the eight-wave instantiations (chosen by launch size: these small roll-outs take them by default) forced off / on
     # for every operator class, with and without the separate 2x2 pass; ConvP_l forked onto the side stream
-    for env in ({"EIGEN_W8": "0"}, {"EIGEN_W8": "31"}, {"EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_W8": "0", "EIGEN_FUSEUP": "0"},
-                {"EIGEN_SIDE_STREAM": "1"}, {"EIGEN_SIDE_STREAM": "1", "EIGEN_W8": "0"},
-                {"EIGEN_H4": "1", "EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_H4": "0", "EIGEN_W8": "31"}):  # half blocks forced on / off
+    for env in ({"EIGEN_W8": "0"}, {"EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_SIDE_STREAM": "1"},
+                {"EIGEN_H4": "1", "EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_H4": "0", "EIGEN_W8": "31"},  # half blocks forced on / off
+                {"EIGEN_NO_TW4": "1"}):                                                                         # 4-column strips off: 8 x 8 tiles on the 20 x 16 maps
         assert run(env) == base, env
     assert run({"EIGEN_FUSEUP": "0"}) == base  # these small roll-outs take the in-kernel chain by default: the separate pass
