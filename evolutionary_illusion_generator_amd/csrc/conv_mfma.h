@@ -43,6 +43,12 @@
 //     2-rows-x-8-columns sub-tiles of round 1: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.34);
 //   - all 16 rows of an MFMA share their class, so the class-dependent 2x2-form weights of an unpooled source are an ordinary
 //     B operand per sub-tile (what lets that chain run inside the ConvLSTM kernel).
+//
+// Block granularity (round 3, template parameter SPLIT): the tile above with four waves x four classes (SPLIT 0) is
+// what launches that fill the chip many times over run.  A launch of a few hundred blocks takes as long as the CU that received
+// ceil(blocks / 256) of them, so small launches get the same arithmetic in finer pieces: SPLIT 1 = EIGHT waves on the same tile (two
+// classes per wave), SPLIT 2 = four-wave HALF blocks of two images (two classes per wave; 8 x 8 tiles, or -- TW = 4 -- strips of
+// 4 columns x 16 rows for maps that square tiles cover badly, e.g. 20 x 15).  Which lane computes a pixel changes, its chain does not.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
