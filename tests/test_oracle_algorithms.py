@@ -225,7 +225,7 @@ def test_fitness_deviation_under_the_reference_element_order_is_explained_genome
         import warnings
         warnings.warn("population seed 5 genome 23 did not deviate on this host: the attribution branch was not exercised")
     for d in s["outside_1e-4_detail"]:
-        assert 1 <= d["flips"] <= 16 and d["single_lsb_effects_max"] >= 0.25 * d["rel"], d
+        assert 1 <= d["flips"] <= 16 and classify.explained(d), d
     assert s["within_1e-4"] >= 0.75 * s["genomes"]  # (measured: 92 % at 256^2 colour, 100 % at 160x120 gray; the property is the line above)
 
 
