@@ -46,6 +46,8 @@ SHAPES = {
     "headline": (256, 256, [3, 48, 96, 192], 3, 1, 20, 3, 256, "neat_configs/circles.txt colour"),
     "ref160": (160, 120, [3, 48, 96, 192], 3, 1, 20, 3, 50, "neat_configs/circles.txt colour"),
     "c2": (160, 120, [1, 16, 32, 64], 1, 1, 20, 1, 50, "neat_configs/circles_bw.txt gray"),
+    # the reference's other real size: `--size big` = 640x480 (generate_illusion.py:742-746); top-layer maps 80x60
+    "ref640": (640, 480, [3, 48, 96, 192], 3, 1, 20, 3, 16, "neat_configs/circles.txt colour, --size big"),
     "c4": (256, 256, [3, 48, 96, 192], 3, 0, 8, 6, 512, "neat_configs/bands.txt colour (first 3 of 6 outputs)"),
     "c5": (512, 512, [3, 48, 96, 192], 3, 2, 20, 6, 1024, "neat_configs/free.txt colour (first 3 of 6 outputs)"),
 }
@@ -77,11 +79,78 @@ def git_head():
         return None
 
 
-def cpu_baseline(cfg, pop, wts, grid, shape, min_genomes=8, seconds_budget=30.0, flops_per_genome=None):
+def _whole_host_worker(idx, threads, cpus, shape_name, n_genomes, ready, go, q):
+    """One worker process of the whole-host CPU figure: its own torch-CPU PredNet on `threads` threads (pinned to `cpus`), the full
+    oracle path on n_genomes genomes of the same population, timed between the common start signal and its own end."""
+    try:
+        if cpus:
+            os.sched_setaffinity(0, cpus)
+    except OSError:
+        pass
+    os.environ["OMP_NUM_THREADS"] = str(threads)
+    import numpy as np
+    import torch
+    torch.set_num_threads(threads)
+    import oracle
+    from oracle import pipeline, scores
+    from oracle.prednet_torch import PredNetTorch
+    from evolutionary_illusion_generator_amd import grids
+    oracle.set_threads(1)
+    W, H, CHANNELS, C_DIM, STRUCTURE = SHAPES[shape_name][:5]
+    cfg, population, wts = make_workload(shape_name, (idx + 1) * n_genomes)
+    grid = grids.create_grid(STRUCTURE, W, H, 10)
+    net = PredNetTorch(wts, CHANNELS, W, H)
+    img = pipeline.render_chw(population[0][1], cfg, grid, C_DIM, W, H)
+    net.rollout(img[None], n_repeat=1, n_ext=0)
+    ready.put(idx)
+    go.wait()
+    t0 = time.time()
+    for k in range(n_genomes):
+        g = population[idx * n_genomes + k][1]
+        img = pipeline.render_chw(g, cfg, grid, C_DIM, W, H)
+        frames, _ = net.rollout(img[None], n_repeat=20, n_ext=1)
+        v = oracle.lucas_kanade(frames[0, 19], frames[0, 20])
+        scores.fitness_from_vectors(STRUCTURE, v.astype(np.float64), W, H)
+    q.put((idx, t0, time.time()))
+
+
+def cpu_whole_host(shape_name, threads, n_genomes=2, max_workers=16, timeout_s=120.0):
+    """floor(host_cpus / threads) worker processes (at most max_workers), each evaluating n_genomes independent genomes of the same
+    population through the full oracle path at the same time: genome evals/s of the BOX, not of one process."""
+    import multiprocessing as mp
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+    except AttributeError:
+        allowed = list(range(os.cpu_count() or 1))
+    workers = max(1, min(max_workers, len(allowed) // threads))
+    ctx = mp.get_context("spawn")
+    ready, q, go = ctx.Queue(), ctx.Queue(), ctx.Event()
+    procs = [ctx.Process(target=_whole_host_worker, args=(i, threads, allowed[i * threads:(i + 1) * threads], shape_name, n_genomes, ready, go, q)) for i in range(workers)]
+    for p in procs:
+        p.start()
+    try:
+        for _ in procs:
+            ready.get(timeout=timeout_s)
+        go.set()
+        res = [q.get(timeout=timeout_s) for _ in procs]
+    finally:
+        go.set()
+        for p in procs:
+            p.join(timeout=10)
+            if p.is_alive():
+                p.kill()
+    t_start, t_end = min(r[1] for r in res), max(r[2] for r in res)
+    return {"value": workers * n_genomes / (t_end - t_start), "unit": "genome evals/s", "workers": workers, "threads_per_worker": threads,
+            "cores": workers * threads, "genomes": workers * n_genomes, "seconds": t_end - t_start,
+            "sample": "%d processes x %d threads (pinned to disjoint CPU blocks), %d genomes each, full oracle path, all at once" % (workers, threads, n_genomes)}
+
+
+def cpu_baseline(cfg, pop, wts, grid, shape, min_genomes=8, seconds_budget=20.0, flops_per_genome=None, shape_name="headline"):
     """The oracle's CPU path on a bounded sample of the same workload (rank 0, N = 1 only), with a per-stage split.
     The PredNet leg (99 % of it) is torch-CPU / oneDNN; its thread count is the best of a small sweep on 2 genomes each
     (batch-1 convolutions on a 256-CPU host are slower on 128 threads than on 32: VERDICT r2), and the >= 8-genome measurement
-    runs at that setting."""
+    runs at that setting.  Two denominators: `value` = ONE process at its best thread count; `whole_host` =
+    as many such processes as the host has CPUs for (cap 16), independent genomes, all at once."""
     import numpy as np
     import torch
     from oracle import pipeline, scores
@@ -94,7 +163,7 @@ def cpu_baseline(cfg, pop, wts, grid, shape, min_genomes=8, seconds_budget=30.0,
     imgs = [pipeline.render_chw(pop[i][1], cfg, grid, C_DIM, W, H) for i in range(2)]
     net.rollout(imgs[0][None], n_repeat=1, n_ext=0)  # primitive creation is not part of anyone's measurement
     sweep = {}
-    for th in sorted({t for t in (8, 32, 128) if t <= ncpu} or {default_threads}):
+    for th in sorted({t for t in (4, 8, 16, 32) if t <= ncpu} or {default_threads}):
         torch.set_num_threads(th)
         t0 = time.time()
         for im in imgs:
@@ -131,15 +200,28 @@ def cpu_baseline(cfg, pop, wts, grid, shape, min_genomes=8, seconds_budget=30.0,
                      % (done, W, H, threads, sorted(sweep), dt)}
     if flops_per_genome:
         out["prednet_gflops"] = flops_per_genome / (split["prednet_s"] / done) / 1e9  # the reference's 9-tap formulation
+    try:
+        wh = cpu_whole_host(shape_name, threads)
+        if flops_per_genome:
+            wh["prednet_gflops"] = flops_per_genome * wh["value"] / 1e9  # (whole path in the denominator: PredNet is 99 % of it)
+        out["whole_host"] = wh
+    except Exception as e:  # noqa: BLE001  (a failed worker pool must not cost the headline line)
+        out["whole_host"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out, fits
 
 
-def classify_population(eng, fitness_mod, genomes, cfg, wts, shape, n_max=256, batch=8):
+def classify_population(eng, fitness_mod, genomes, cfg, wts, shape, n_max=256, batch=8, n_cpu_control=12):
     """north_star's "within 1e-4 relative" as a property checked for EVERY genome of the benchmark population (untimed leg):
     the HIP path's frames / vectors / fitness against the reference's element-wise order (chainer ConvLSTM: separate
     convolution tensors added left to right, un-fused gate products, sigmoid = tanh(x/2)/2 + 1/2, plain unpool -> 9-tap)
     with im2col + rocBLAS matmul convolutions on the GPU; Lucas-Kanade and scores of that side by the C / numpy oracle.
-    oracle/classify.py: a genome outside 1e-4 must be reproduced by ONE +-1 byte flip applied to the HIP path's own frames."""
+    oracle/classify.py: a genome outside 1e-4 must be reproduced by +-1 byte flips applied to the HIP path's own frames.
+
+    CONTROL: the same classification between two NON-HIP implementations of the reference's order that differ
+    only in the summation order inside a convolution -- (A) im2col + rocBLAS matmul vs (B) the library convolution (MIOpen picks the
+    algorithm, as cuDNN does on the reference's `gpu=0` path, generate_illusion.py:485) on all genomes, and (A) vs (C) torch-CPU /
+    oneDNN (the reference's CPU path, north_star) on the first n_cpu_control genomes.  If two reference-order implementations disagree
+    with each other as often as HIP disagrees with one of them, the deviations are the conditioning of the fitness function."""
     import numpy as np
     import torch
     from evolutionary_illusion_generator_amd import genome as genome_mod
@@ -157,10 +239,38 @@ def classify_population(eng, fitness_mod, genomes, cfg, wts, shape, n_max=256, b
     torch.cuda.synchronize()
     imgs, frames = d_img.cpu().numpy(), d_fr.cpu().numpy()
     torch.backends.cuda.matmul.allow_tf32 = False
+    torch.backends.cudnn.allow_tf32 = False
     net = PredNetTorch(wts, CHANNELS, W, H, device="cuda", conv="matmul", order="chainer")
-    summ, _ = classify.population_report(STRUCTURE, W, H, imgs, frames, vecs, fit, net, batch=batch)
+    side_a = classify.rollout_side(STRUCTURE, W, H, imgs, net, batch=batch)
+    summ, _ = classify.population_report(STRUCTURE, W, H, imgs, frames, vecs, fit, None, other=side_a)
     summ["against"] = "reference element-wise order (chainer ConvLSTM.__call__), im2col + rocBLAS fp32 matmul on the GPU; C Lucas-Kanade + numpy scores"
     summ["seconds"] = time.time() - t0
+    t1 = time.time()
+    try:
+        net_b = PredNetTorch(wts, CHANNELS, W, H, device="cuda", conv="library", order="chainer")
+        side_b = classify.rollout_side(STRUCTURE, W, H, imgs, net_b, batch=batch)
+        ctl = classify.control_report(STRUCTURE, W, H, side_a, side_b, "reference order, im2col + rocBLAS matmul (GPU)", "reference order, MIOpen library convolution (GPU)")
+        ctl["control_seconds"] = time.time() - t1
+        summ["control"] = ctl
+        # HIP against the second reference-order implementation as well: the 1e-4 count must not depend on which one is asked
+        s_b, _ = classify.population_report(STRUCTURE, W, H, imgs, frames, vecs, fit, None, other=side_b)
+        summ["vs_second_reference_order_implementation"] = {k: s_b[k] for k in ("within_1e-4", "outside_1e-4", "outside_1e-4_unexplained", "byte_flip_rate", "identical_frames")}
+    except Exception as e:  # noqa: BLE001
+        summ["control"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if n_cpu_control:
+        t2 = time.time()
+        m = min(n, n_cpu_control)
+        threads0 = torch.get_num_threads()
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        net_c = PredNetTorch(wts, CHANNELS, W, H, order="chainer")
+        side_c = classify.rollout_side(STRUCTURE, W, H, imgs[:m], net_c, batch=1)
+        torch.set_num_threads(threads0)
+        cut = lambda sd: (sd[0][:m], sd[1][:m], sd[2][:m])
+        ctl = classify.control_report(STRUCTURE, W, H, cut(side_a), side_c, "reference order, im2col + rocBLAS matmul (GPU)", "reference order, torch-CPU / oneDNN")
+        s_c, _ = classify.population_report(STRUCTURE, W, H, imgs[:m], frames[:m], vecs[:m], fit[:m], None, other=side_c)
+        ctl["hip_vs_cpu_reference_order"] = {k: s_c[k] for k in ("genomes", "within_1e-4", "outside_1e-4", "outside_1e-4_unexplained", "byte_flip_rate", "identical_frames")}
+        ctl["control_seconds"] = time.time() - t2
+        summ["control_cpu"] = ctl
     return summ, fit
 
 
@@ -252,7 +362,11 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the untimed parity legs (C-oracle spot check, whole-population classification)")
     ap.add_argument("--no-supplementary", action="store_true", help="skip the untimed supplementary block (ref160, c2, c4, c5 at a device-batch sample)")
+    ap.add_argument("--strict-parity", action="store_true", help="exit with status 3 when the parity legs flag a failure (parity_fail)")
     args = ap.parse_args()
+    # RCCL / device-tensor sharing across processes needs dmabuf IPC on these hosts; must be in the environment BEFORE the HIP
+    # runtime initialises, whoever launched this process (the respawn path below, the driver's own torchrun, a plain shell)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(args.gpus)
@@ -330,8 +444,19 @@ def main():
         dt = float(tmax.item())
         # what every rank spent inside its shard's evaluate() (rode in the fitness all-gather itself) and what the collective cost here:
         # a straggling GPU shows as max >> min, a slow collective as collective_ms; averaged over the timed steps
+        # proof that the collective saw N ranks: an all-gather of (rank, local device index) on the same backend
+        ids = torch.tensor([rank, torch.cuda.current_device()], dtype=torch.int64, device="cuda" if backend == "nccl" else "cpu")
+        seen = torch.empty(2 * world, dtype=torch.int64, device=ids.device)
+        dist.all_gather_into_tensor(seen, ids)
+        seen = seen.cpu().numpy().reshape(world, 2)
+        try:
+            rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
+        except Exception:  # noqa: BLE001
+            rccl_version = None
         loc = np.asarray([s_["local_ms"] for s_ in shard_stats], dtype=np.float64).mean(axis=0)
-        multi = {"per_rank_device_ms": [round(float(x), 3) for x in loc], "device_ms_max": float(loc.max()), "device_ms_min": float(loc.min()),
+        multi = {"backend": backend, "rccl_version": rccl_version, "world_size": dist.get_world_size(), "ranks_seen": [int(x) for x in seen[:, 0]],
+                 "devices_seen": [int(x) for x in seen[:, 1]], "hsa_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                 "per_rank_device_ms": [round(float(x), 3) for x in loc], "device_ms_max": float(loc.max()), "device_ms_min": float(loc.min()),
                  "collective_ms_rank0": float(np.mean([s_["collective_ms"] for s_ in shard_stats])),
                  "note": "per-rank evaluate() wall time of its shard (flatten/slice + render + roll-out + flow + score + D2H), mean over the timed "
                          "steps; collective_ms = rank 0's all-gather incl. its wait for the slowest rank"}
@@ -430,11 +555,14 @@ def main():
     grid = None
     if world == 1 and not args.no_cpu_baseline:
         grid = grids.create_grid(STRUCTURE, W, H, 10)
-        cb, cpu_fit = cpu_baseline(cfg, population, wts, grid, shape, flops_per_genome=eng.flops_per_step() * N_STEPS_PREDNET)
+        cb, cpu_fit = cpu_baseline(cfg, population, wts, grid, shape, flops_per_genome=eng.flops_per_step() * N_STEPS_PREDNET, shape_name=args.shape)
         out["cpu_baseline"] = cb
-        out["gpu_over_cpu"] = out["value"] / cb["value"]
+        out["gpu_over_cpu"] = out["value"] / cb["value"]  # one CPU process at its best thread count
+        if cb.get("whole_host", {}).get("value"):
+            out["gpu_over_cpu_whole_host"] = out["value"] / cb["whole_host"]["value"]  # every CPU of the box busy
     if world == 1 and not args.no_parity:
         # (a) genome 0 at the FULL size against the bit-exact C oracle (~20 s of CPU): the canonical arithmetic, bit for bit
+        import oracle as oracle_mod
         from oracle import pipeline
         grid = grid or grids.create_grid(STRUCTURE, W, H, 10)
         t1 = time.time()
@@ -446,12 +574,27 @@ def main():
         summ, fit2 = classify_population(eng, fitness, genomes, cfg, wts, shape)
         assert np.array_equal(fit2, fit[:len(fit2)]), "the staged entry points and the fused population path disagree"
         out["parity_check"]["population_vs_reference_order"] = summ
+        out["parity_check"]["gate_order"] = {"hip": eng.lib.eigen_gate_order(), "oracle": oracle_mod.lib().eig_oracle_gate_order()}
+        reasons = []
+        if out["parity_check"]["rel_err"] > 1e-9:
+            reasons.append("genome 0 differs from the bit-exact C oracle by %.3g" % out["parity_check"]["rel_err"])
+        if summ["outside_1e-4_unexplained"]:
+            reasons.append("%d genome(s) outside 1e-4 are not reproduced by +-1 byte flips of the HIP frames" % summ["outside_1e-4_unexplained"])
+        if summ["max_byte_diff"] > 1 or summ["byte_flip_rate"] > 5e-5:
+            reasons.append("frames differ from the reference-order frames by more than a sprinkling of +-1 bytes (max %d, rate %.2g)" % (summ["max_byte_diff"], summ["byte_flip_rate"]))
+        if out["parity_check"]["gate_order"]["hip"] != out["parity_check"]["gate_order"]["oracle"]:
+            reasons.append("HIP library and C oracle were compiled with different gate orders")
+        out["parity_fail"] = bool(reasons)
+        if reasons:
+            out["parity_fail_reasons"] = reasons
+            print("bench.py: PARITY FAILURE: " + "; ".join(reasons), file=sys.stderr)
     if world == 1 and not args.no_supplementary:
         # the other BASELINE.json configurations, same process, a few seconds each (driver-visible numbers)
         sup = {}
         fitness.clear_engines()
         torch.cuda.empty_cache()
         for name, pop_s, steps_s, key in (("ref160", 50, 10, "ref160 (the reference's own default shape, pop 50)"), ("c2", 50, 20, "configs[1]"),
+                                          ("ref640", 16, 4, "ref640 (the reference's `--size big`, 640x480 colour, pop 16)"),
                                           ("c4", 512, 2, "configs[3] (single-GPU: two device batches of 256)"), ("c5", 64, 2, "configs[4] (single-GPU sample: one device batch of 64)")):
             try:
                 r = supplementary_shape(name, pop_s, steps_s)
@@ -463,6 +606,8 @@ def main():
             torch.cuda.empty_cache()
         out["supplementary"] = sup
     print(json.dumps(out))
+    if args.strict_parity and out.get("parity_fail"):
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

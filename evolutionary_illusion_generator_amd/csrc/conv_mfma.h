@@ -151,7 +151,20 @@ __device__ __forceinline__ float det_expf(float x)
     const float s = __int_as_float(((int)n + 127) << 23);
     return y * s;
 }
+// EIG_GATE_ORDER: element-wise order of the ConvLSTM gate epilogue (oracle/eig_oracle.c: lstm_cell states the
+// same thing).  1 (default, round 4): the order chainer_prednet's ConvLSTM.__call__ evaluates, wherever that order is knowable --
+// peephole `c_g(c) = W * c` as a ROUNDED PRODUCT added last, F.sigmoid as chainer's CPU forward computes it,
+// tanh(x * 0.5) * 0.5 + 0.5, the cell update as two rounded products and one addition (cc = tanh(cc) * ii; cc += ff * c).
+// 0: rounds 1-3 (fmaf peepholes and cell update, 1 / (1 + exp(-x))); kept for same-box A/B builds (scripts/ab_gate_order.sh).
+#ifndef EIG_GATE_ORDER
+#define EIG_GATE_ORDER 1
+#endif
+__device__ __forceinline__ float det_tanhf(float x);
+#if EIG_GATE_ORDER
+__device__ __forceinline__ float det_sigmoidf(float x) { return det_tanhf(x * 0.5f) * 0.5f + 0.5f; }
+#else
 __device__ __forceinline__ float det_sigmoidf(float x) { return 1.0f / (1.0f + det_expf(-x)); }
+#endif
 __device__ __forceinline__ float det_tanhf(float x)
 {
     float ax = fabsf(x);
@@ -171,6 +184,35 @@ __device__ __forceinline__ float det_tanhf(float x)
     return x < 0.0f ? -r : r;
 }
 __device__ __forceinline__ float relu_f(float v) { return v > 0.0f ? v : 0.0f; }
+
+// One ConvLSTM cell: z* = the four gates' convolution sums (chain over E_l, h_l + chain of the unpooled R_{l+1}), b* the h_*
+// convolutions' biases, p* the peephole weights, cold the cell state.  -> new cell state, new hidden state.  (This translation
+// unit is compiled with -ffp-contract=off: a * b + c below is a rounded product and an addition.)
+__device__ __forceinline__ void lstm_cell(float zi_, float zf_, float zc_, float zo_, float bi, float bf, float bc, float bo,
+                                          float cold, float pi_, float pf_, float po_, float& cn, float& hn)
+{
+#if EIG_GATE_ORDER
+    const float zi = (zi_ + bi) + pi_ * cold;
+    const float zf = (zf_ + bf) + pf_ * cold;
+    const float zc = zc_ + bc;
+    const float zo = (zo_ + bo) + po_ * cold;
+    const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), oo = det_sigmoidf(zo);
+    float cc = det_tanhf(zc);
+    cc = cc * ii;
+    const float fc = ff * cold;
+    cn = cc + fc;
+    hn = oo * det_tanhf(cn);
+#else
+    float zi = zi_ + bi; zi = fmaf(pi_, cold, zi);
+    float zf = zf_ + bf; zf = fmaf(pf_, cold, zf);
+    const float zc = zc_ + bc;
+    float zo = zo_ + bo; zo = fmaf(po_, cold, zo);
+    const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
+    const float gi = gg * ii;
+    cn = fmaf(ff, cold, gi);
+    hn = oo * det_tanhf(cn);
+#endif
+}
 
 // LDS geometry of the haloed input tile.
 //  VEC (every layer whose width is a multiple of 4 -- all real PredNet shapes): a row holds the ALIGNED 16-byte chunks
@@ -790,7 +832,7 @@ conv3x3_mfma(const ConvArgs a)
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* d = a.dbg + ((size_t)blockIdx.x * 4 + wv) * 8;
+            unsigned long long* d = a.dbg + ((size_t)blockIdx.x * (W8 ? 8 : 4) + wv) * 8;  // (the host sizes the buffer for 8 waves per block)
             d[0] = t_entry; d[1] = t_all0; d[2] = t_loop1; d[3] = __builtin_readcyclecounter();
             d[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32); d[5] = t_mfma; d[6] = t_setup; d[7] = t_prewait; (void)t_mid; (void)t_bar;
         }
@@ -849,15 +891,8 @@ conv3x3_mfma(const ConvArgs a)
             const size_t pbase = (size_t)ch * HW;
             const size_t pstride = (size_t)a.Cout * HW;
             auto cell = [&](float zi_, float zf_, float zc_, float zo_, float cold, float pi_, float pf_, float po_, float& cn, float& hn) __attribute__((always_inline)) {
-                float zi = zi_ + bi; zi = fmaf(pi_, cold, zi);
-                float zf = zf_ + bf; zf = fmaf(pf_, cold, zf);
-                const float zc = zc_ + bc;
-                float zo = zo_ + bo; zo = fmaf(po_, cold, zo);
-                if (EIG_ABLATE == 2) { cn = zi + zf; hn = zc + zo; return; }  // measurement only: gate math removed
-                const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
-                const float gi = gg * ii;
-                cn = fmaf(ff, cold, gi);
-                hn = oo * det_tanhf(cn);
+                if (EIG_ABLATE == 2) { cn = (zi_ + bi) + (zf_ + bf) + pi_ * cold; hn = (zc_ + bc) + (zo_ + bo) + pf_ * po_; return; }  // measurement only: gate math removed
+                lstm_cell(zi_, zf_, zc_, zo_, bi, bf, bc, bo, cold, pi_, pf_, po_, cn, hn);
             };
 #pragma unroll
             for (int sgi = 0; sgi < NSEG; ++sgi) {
@@ -930,15 +965,10 @@ conv3x3_mfma(const ConvArgs a)
             const size_t pstride = (size_t)a.Cout * HW;
             const int pix = gy * a.W + gx;
             const float cold = a.c_state[cbase + pix];
-            float zi = ai + bi; zi = fmaf(a.peep[pbase + pix], cold, zi);
-            float zf = af + bf; zf = fmaf(a.peep[pstride + pbase + pix], cold, zf);
-            const float zc = ac + bc;
-            float zo = ao + bo; zo = fmaf(a.peep[2 * pstride + pbase + pix], cold, zo);
-            const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
-            const float gi = gg * ii;
-            const float cnew = fmaf(ff, cold, gi);
+            float cnew, hnew;
+            lstm_cell(ai, af, ac, ao, bi, bf, bc, bo, cold, a.peep[pbase + pix], a.peep[pstride + pbase + pix], a.peep[2 * pstride + pbase + pix], cnew, hnew);
             a.c_state[cbase + pix] = cnew;
-            a.h_out[cbase + pix] = oo * det_tanhf(cnew);
+            a.h_out[cbase + pix] = hnew;
         }
     } else if constexpr (EPI == EPI_CONVA) {
         // max-pool: window `reg` of the lane = the same register of the four class sub-tiles.  Pooled pixels of a lane: 16-wide tiles
@@ -1183,15 +1213,10 @@ __global__ void __launch_bounds__(L0_TX * L0_TY) lstm0_direct_kernel(const float
         const size_t pbase = (size_t)o * HW;
         const size_t pstride = (size_t)C * HW;
         const float cold = a.c_state[cbase + pix];
-        float zi = z[0] + bi; zi = fmaf(a.peep[pbase + pix], cold, zi);
-        float zf = z[1] + bf; zf = fmaf(a.peep[pstride + pbase + pix], cold, zf);
-        const float zc = z[2] + bc;
-        float zo = z[3] + bo; zo = fmaf(a.peep[2 * pstride + pbase + pix], cold, zo);
-        const float ii = det_sigmoidf(zi), ff = det_sigmoidf(zf), gg = det_tanhf(zc), oo = det_sigmoidf(zo);
-        const float gi = gg * ii;
-        const float cnew = fmaf(ff, cold, gi);
+        float cnew, hnew;
+        lstm_cell(z[0], z[1], z[2], z[3], bi, bf, bc, bo, cold, a.peep[pbase + pix], a.peep[pstride + pbase + pix], a.peep[2 * pstride + pbase + pix], cnew, hnew);
         a.c_state[cbase + pix] = cnew;
-        a.h_out[cbase + pix] = oo * det_tanhf(cnew);
+        a.h_out[cbase + pix] = hnew;
     }
 }
 

@@ -43,6 +43,7 @@ namespace {
 
 struct ConvOp {
     int tl_seen = 0;  // EIG_TIMING builds: launches seen (timeline dump)
+    int last_grid = 0, last_waves = 4;  // geometry of the last launch (launch_conv), for the EIG_TIMING read-back
     int epi = 0, NI = 4, TW = 16, layer = 0;
     int nsrc = 0;
     int src_C[3] = {0, 0, 0};
@@ -129,6 +130,8 @@ struct eigen_engine {
     // same kernels, same arguments: results are untouched).  Worth most where a launch does not fill the chip.
     hipStream_t aux = nullptr;
     hipEvent_t ev_h[EIGEN_MAX_LAYERS] = {nullptr}, ev_p[EIGEN_MAX_LAYERS] = {nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;  // two half-populations on two streams (eigen_prednet_rollout)
+    int n_cu = 256;  // compute units of the device (launch-shape heuristics)
     bool profile_convs = false;
     double ms[6] = {0, 0, 0, 0, 0, 0};
     int hflip = 0;  // which h buffer holds the current R
@@ -136,9 +139,6 @@ struct eigen_engine {
 
 // ------------------------------------------------------------------------------------------------ helpers
 static int pad4(int c) { return (c + 3) & ~3; }
-#ifndef EIGEN_W8_GRID
-#define EIGEN_W8_GRID 2048
-#endif
 
 // ---- Farneback constants (host; the same double-precision recipe as oracle/farneback.c, checked by tests/test_gpu_parity.py) ----
 static int fb_levels_used(int H, int W, int levels)  // calcOpticalFlowFarneback: no level below 32 pixels
@@ -440,8 +440,8 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
 #if EIG_TIMING
     unsigned long long* tl_dbg = nullptr;
     if (getenv("EIGEN_TIMELINE") && (op.epi == EPI_LSTM || (op.epi == EPI_UP4 && op.NI == 4)) && ++op.tl_seen == 6) {  // a steady-state launch of every ConvLSTM op and 2x2-form pass
-        (void)hipMalloc((void**)&tl_dbg, (size_t)grid * 32 * 8);
-        (void)hipMemset(tl_dbg, 0, (size_t)grid * 32 * 8);
+        (void)hipMalloc((void**)&tl_dbg, (size_t)grid * 2 * 64 * 8);  // half blocks double the grid, W8 blocks have 8 waves
+        (void)hipMemset(tl_dbg, 0, (size_t)grid * 2 * 64 * 8);
         a.dbg = tl_dbg;
     }
 #endif
@@ -455,7 +455,12 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     // the 512 block slots).  EIGEN_W8 = bit mask forces it for operator classes whatever the grid (1 ConvLSTM, 2 ConvA, 4 ConvP,
     // 8 the 2x2-form pass, 16 raw test convolutions), EIGEN_W8=0 switches it off: A/B measurements and the parity tests.
     static const int w8_env = getenv("EIGEN_W8") ? atoi(getenv("EIGEN_W8")) : -1;
-    const int w8_mask = w8_env >= 0 ? w8_env : (grid <= EIGEN_W8_GRID ? 15 : 0);
+#ifdef EIGEN_W8_GRID
+    const int w8_grid = EIGEN_W8_GRID;  // measurement builds
+#else
+    const int w8_grid = 8 * e->n_cu;    // four rounds of the device's block slots (two blocks per CU): 2048 on MI355X
+#endif
+    const int w8_mask = w8_env >= 0 ? w8_env : (grid <= w8_grid ? 15 : 0);
     const int cls_bit = op.epi == EPI_LSTM ? 1 : (op.epi == EPI_CONVA ? 2 : (op.epi == EPI_CONVP ? 4 : (op.epi == EPI_UP4 ? 8 : (op.epi == EPI_RAW ? 16 : 0))));
     int w8 = (vec && (w8_mask & cls_bit)) ? 1 : 0;  // 0: four waves x four classes, 1: eight waves, 2: half blocks (below)
     // Half blocks (conv_mfma.h: SPLIT 2, 8-wide tiles): two images per block instead of four.  A launch of fewer than ~2 blocks per CU
@@ -467,9 +472,11 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         const int ntile2 = ((batch + 1) / 2) * a.tilesX * a.tilesY;
         const long b1 = (long)per_tile * ntile, b2 = (long)per_tile * ntile2;
         static const double h4_factor = getenv("EIGEN_H4_FACTOR") ? atof(getenv("EIGEN_H4_FACTOR")) : 0.55;  // cost of a half block in block times (A/B)
-        const bool pays = ((b2 + 255) / 256) * h4_factor < (double)((b1 + 255) / 256);
+        const long ncu = e->n_cu;
+        const bool pays = ((b2 + ncu - 1) / ncu) * h4_factor < (double)((b1 + ncu - 1) / ncu);
         if (h4_env >= 0 ? h4_env != 0 : pays) { w8 = 2; ntile = ntile2; grid = per_tile * ((ntile + 7) / 8) * 8; }
     }
+    op.last_grid = grid; op.last_waves = (w8 == 1) ? 8 : 4;
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
     static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
@@ -515,7 +522,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
 #if EIG_TIMING
     if (tl_dbg) {
         (void)hipStreamSynchronize(st);
-        std::vector<unsigned long long> h((size_t)grid * 32);
+        std::vector<unsigned long long> h((size_t)op.last_grid * op.last_waves * 8);
         (void)hipMemcpy(h.data(), tl_dbg, h.size() * 8, hipMemcpyDeviceToHost);
         char name[256];
         snprintf(name, sizeof(name), "%s/timeline_H%d_C%d%s.bin", getenv("EIGEN_TIMELINE"), op.H, op.Cout, op.epi == EPI_UP4 ? "_up4" : "");
@@ -534,10 +541,19 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     return r;
 }
 
+// Two half-populations on two streams: worth it where the top of the network cannot fill the chip by itself.  (Filled in from
+// same-box A/Bs: profiles/r04_*.)
+static bool pipe2_pays(const eigen_engine* e, int batch)
+{
+    (void)e; (void)batch;
+    return false;
+}
+
 // ------------------------------------------------------------------------------------------------ ABI
 extern "C" {
 
 int eigen_abi_version(void) { return EIGEN_ABI_VERSION; }
+int eigen_gate_order(void) { return EIG_GATE_ORDER; }
 const char* eigen_last_error(void) { return g_err.c_str(); }
 
 void eigen_config_defaults(eigen_config* c)
@@ -573,6 +589,7 @@ int eigen_destroy(eigen_engine* e)
     if (e->pev1) (void)hipEventDestroy(e->pev1);
     for (auto& ev : e->ev_h) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev_p) if (ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : {e->ev_fork, e->ev_join, e->ev_mid}) if (ev) (void)hipEventDestroy(ev);
     if (e->aux) (void)hipStreamDestroy(e->aux);
     delete e;
     return EIGEN_OK;
@@ -612,6 +629,7 @@ int eigen_create(const eigen_config* cfg, eigen_engine** out)
 
     eigen_engine* e = new eigen_engine();
     e->cfg = *cfg;
+    e->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     e->L = L; e->B = cfg->max_batch; e->C0 = cfg->channels[0]; e->H = cfg->height; e->W = cfg->width; e->K = cfg->lk_max_corners;
     const size_t B = (size_t)e->B;
 #define ALLOC(ptr, n)                                                                              \
@@ -656,6 +674,7 @@ int eigen_create(const eigen_config* cfg, eigen_engine** out)
     HIPCHK(hipEventCreate(&e->pev0));
     HIPCHK(hipEventCreate(&e->pev1));
     HIPCHK(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));  // no implicit ordering against the caller's (possibly NULL) stream: events only
+    for (hipEvent_t* ev : {&e->ev_fork, &e->ev_join, &e->ev_mid}) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
     for (int l = 0; l < L; ++l) {
         HIPCHK(hipEventCreateWithFlags(&e->ev_h[l], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&e->ev_p[l], hipEventDisableTiming));
@@ -954,21 +973,32 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
     // (160x120 colour 430.6 vs 435.2, gray 2452 vs 2472): a launch's blocks occupy the CUs in dispatch order, and the time of an
     // under-filled launch is the CU that holds two of its blocks -- a second queue adds blocks to CUs, it does not balance them.
     static const bool side_env = getenv("EIGEN_SIDE_STREAM") && atoi(getenv("EIGEN_SIDE_STREAM"));
-    const bool side = side_env && !e->profile_convs && L > 1;
+    // Two half-populations on two streams (round 4): genomes [0, nA) run on the caller's stream, [nA, batch) on
+    // the side stream, the second half started half a step late (it waits for the first half's top-layer ConvLSTM of step 0), so
+    // that the under-filled top-layer launches of one half co-run with the chip-filling layer-0/1 launches of the other.  Same
+    // kernels on disjoint genomes: every frame is the byte it was.  EIGEN_PIPE2 = 1 / 0 forces it on / off; default: pipe2_pays().
+    static const int pipe_env = getenv("EIGEN_PIPE2") ? atoi(getenv("EIGEN_PIPE2")) : -1;
+    static const bool pipe_sync = getenv("EIGEN_PIPE2_SYNC") && atoi(getenv("EIGEN_PIPE2_SYNC"));  // A/B: re-impose the half-step offset at every step
+    const bool pipe = !e->profile_convs && batch >= 2 && L > 1 && (pipe_env >= 0 ? pipe_env != 0 : pipe2_pays(e, batch));
+    const bool side = side_env && !e->profile_convs && L > 1 && !pipe;
     bool p_pending[EIGEN_MAX_LAYERS] = {false};  // ConvP_l of the previous step is in flight on the side stream
     static const bool skip_zero_sources = !(getenv("EIGEN_NO_T0") && atoi(getenv("EIGEN_NO_T0")));  // A/B measurements only
     hipLaunchKernelGGL(e0_init_kernel, dim3(1024), dim3(256), 0, st, d_images, e->layer[0].E, e->C0, (int)HW, batch);
     HIPCHK(hipGetLastError());
-    for (int t = 0; t < n_steps; ++t) {
+    // One PredNet step of genomes [b0, b0 + nb) on stream s; raw4: that range's partial-chain scratch.  mid: recorded on s after the
+    // top-layer ConvLSTM launch (the other half's phase reference); wait: waited for before the first launch.
+    auto run_step = [&](int t, int b0, int nb, hipStream_t s, float* raw4, hipEvent_t mid, hipEvent_t wait) -> int {
+        if (wait) HIPCHK(hipStreamWaitEvent(s, wait, 0));
+        auto off = [&](float* p, const Layer& y, int mult = 1) { return p + (size_t)b0 * mult * y.C * y.H * y.W; };
         // bottom-up: E_l from E_{l-1} and the previous prediction P_l
         for (int l = 1; l < L; ++l) {
             Layer& y = e->layer[l];
             ConvArgs a;
             memset(&a, 0, sizeof(a));
-            a.src[0].ptr = e->layer[l - 1].E;
-            a.bias = y.biasA; a.P = y.P; a.E = y.E;
-            if (p_pending[l]) { HIPCHK(hipStreamWaitEvent(st, e->ev_p[l], 0)); p_pending[l] = false; }  // join: P_l of the previous step
-            HIPCHK(launch_conv(e, (t == 0 && skip_zero_sources) ? y.convA_t0 : y.convA, a, batch, st));
+            a.src[0].ptr = off(e->layer[l - 1].E, e->layer[l - 1], 2);
+            a.bias = y.biasA; a.P = off(y.P, y); a.E = off(y.E, y, 2);
+            if (p_pending[l]) { HIPCHK(hipStreamWaitEvent(s, e->ev_p[l], 0)); p_pending[l] = false; }  // join: P_l of the previous step
+            HIPCHK(launch_conv(e, (t == 0 && skip_zero_sources) ? y.convA_t0 : y.convA, a, nb, s));
         }
         // top-down: R_l, then P_l
         for (int l = L - 1; l >= 0; --l) {
@@ -976,53 +1006,75 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
             {
                 ConvArgs a;
                 memset(&a, 0, sizeof(a));
-                int s = 0;
+                int k = 0;
                 if (l < L - 1 && y.lstm.fused) {  // R_{l+1} of THIS step: its chain runs inside the ConvLSTM launch
-                    a.up_src = e->layer[l + 1].h[cur ^ 1];
+                    a.up_src = off(e->layer[l + 1].h[cur ^ 1], e->layer[l + 1]);
                     a.up_C = y.lstm.up_C; a.up_kb = y.lstm.up_kb; a.up_wpk = y.d_upw;
                 } else if (l < L - 1) {  // R_{l+1} of THIS step, 2x2 form -> partial chains
                     ConvArgs u;
                     memset(&u, 0, sizeof(u));
-                    u.src[0].ptr = e->layer[l + 1].h[cur ^ 1];
-                    u.raw = e->d_raw4;
-                    HIPCHK(launch_conv(e, y.up4, u, batch, st));
-                    a.acc_init = e->d_raw4;
+                    u.src[0].ptr = off(e->layer[l + 1].h[cur ^ 1], e->layer[l + 1]);
+                    u.raw = raw4;
+                    HIPCHK(launch_conv(e, y.up4, u, nb, s));
+                    a.acc_init = raw4;
                 }
-                a.src[s++].ptr = y.E;
+                a.src[k++].ptr = off(y.E, y, 2);
                 const bool t0 = (t == 0 && skip_zero_sources);
-                if (!t0) a.src[s++].ptr = y.h[cur];
-                a.bias = y.bias_lstm; a.c_state = y.c; a.h_out = y.h[cur ^ 1]; a.peep = y.peep;
-                HIPCHK(launch_conv(e, t0 ? y.lstm_t0 : y.lstm, a, batch, st));
+                if (!t0) a.src[k++].ptr = off(y.h[cur], y);
+                a.bias = y.bias_lstm; a.c_state = off(y.c, y); a.h_out = off(y.h[cur ^ 1], y); a.peep = y.peep;
+                HIPCHK(launch_conv(e, t0 ? y.lstm_t0 : y.lstm, a, nb, s));
+                if (l == L - 1 && mid) HIPCHK(hipEventRecord(mid, s));
             }
             // P_l (l > 0) is only read by ConvA_l of the NEXT step: nothing reads it after the last one
             if (l == 0 || t + 1 < n_steps) {
                 ConvArgs a;
                 memset(&a, 0, sizeof(a));
-                a.src[0].ptr = y.h[cur ^ 1];
-                a.bias = y.biasP; a.Pout = y.P; a.clip = (l == 0) ? 1 : 0;
+                a.src[0].ptr = off(y.h[cur ^ 1], y);
+                a.bias = y.biasP; a.Pout = off(y.P, y); a.clip = (l == 0) ? 1 : 0;
                 if (side && l > 0) {  // fork: ConvP_l beside the ConvLSTMs below it
-                    HIPCHK(hipEventRecord(e->ev_h[l], st));
+                    HIPCHK(hipEventRecord(e->ev_h[l], s));
                     HIPCHK(hipStreamWaitEvent(e->aux, e->ev_h[l], 0));
-                    HIPCHK(launch_conv(e, y.convP, a, batch, e->aux));
+                    HIPCHK(launch_conv(e, y.convP, a, nb, e->aux));
                     HIPCHK(hipEventRecord(e->ev_p[l], e->aux));
                     p_pending[l] = true;
                     continue;
                 }
                 if (l == 0) {
                     if (t + 1 < n_steps) {  // error units of the next step
-                        a.E0 = y.E;
-                        a.img = (t + 1 < e->cfg.n_repeat) ? d_images : nullptr;
+                        a.E0 = off(y.E, y, 2);
+                        a.img = (t + 1 < e->cfg.n_repeat) ? d_images + (size_t)b0 * e->C0 * HW : nullptr;
                         a.requant = e->cfg.requant_feedback;
                     }
                     if (t >= first_out_step) {
-                        a.frame = d_frames + (size_t)(t - first_out_step) * e->C0 * HW;
                         a.frame_bstride = (long long)n_out * e->C0 * HW;
+                        a.frame = d_frames + (size_t)b0 * a.frame_bstride + (size_t)(t - first_out_step) * e->C0 * HW;
                     }
                 }
-                HIPCHK(launch_conv(e, y.convP, a, batch, st));
+                HIPCHK(launch_conv(e, y.convP, a, nb, s));
             }
         }
-        cur ^= 1;
+        return EIGEN_OK;
+    };
+    if (!pipe) {
+        for (int t = 0; t < n_steps; ++t) {
+            const int rc = run_step(t, 0, batch, st, e->d_raw4, nullptr, nullptr);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+    } else {
+        const int nA = (batch + 1) / 2, nB = batch - nA;
+        float* raw4B = e->d_raw4 ? e->d_raw4 + (size_t)nA * (e->raw4_floats / (size_t)e->B) : nullptr;  // (per-image stride of the widest layer)
+        HIPCHK(hipEventRecord(e->ev_fork, st));           // reset_state() and E_0 of step 0 are on the caller's stream
+        HIPCHK(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
+        for (int t = 0; t < n_steps; ++t) {
+            int rc = run_step(t, 0, nA, st, e->d_raw4, (t == 0 || pipe_sync) ? e->ev_mid : nullptr, nullptr);
+            if (rc) return rc;
+            rc = run_step(t, nA, nB, e->aux, raw4B, nullptr, (t == 0 || pipe_sync) ? e->ev_mid : nullptr);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+        HIPCHK(hipEventRecord(e->ev_join, e->aux));
+        HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
     }
     for (int l = 1; l < L; ++l)  // (nothing is pending after the last step -- its ConvP_l are not launched -- but keep the join explicit)
         if (p_pending[l]) HIPCHK(hipStreamWaitEvent(st, e->ev_p[l], 0));
@@ -1290,20 +1342,21 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
     hipError_t r = launch_both();  // also the warm-up of a timed run
 #if EIG_TIMING
     {
-        const int TH_ = (op.TW == 16) ? 16 : 8, NIMG_ = 256 / (TH_ * op.TW);
-        const int grid_ = op.n_nblk * (((((batch + NIMG_ - 1) / NIMG_) * ((W + op.TW - 1) / op.TW) * ((H + TH_ - 1) / TH_)) + 7) / 8) * 8;
+        // geometry of THIS operator's launches as launch_conv chose it for the warm-up above (tile shape, half blocks, eight-wave
+        // blocks): ADVICE r3 -- the round-2 formula here no longer described the round-3 launches
+        const int grid_ = op.last_grid, waves_ = op.last_waves;
         unsigned long long* dbg = nullptr;
-        (void)hipMalloc((void**)&dbg, (size_t)grid_ * 32 * 8);
-        (void)hipMemset(dbg, 0, (size_t)grid_ * 32 * 8);
+        (void)hipMalloc((void**)&dbg, (size_t)grid_ * waves_ * 8 * 8);
+        (void)hipMemset(dbg, 0, (size_t)grid_ * waves_ * 8 * 8);
         a.dbg = dbg;
         (void)launch_conv(e, op, a, batch, (hipStream_t)stream);
         (void)hipStreamSynchronize((hipStream_t)stream);
-        std::vector<unsigned long long> h((size_t)grid_ * 32);
+        std::vector<unsigned long long> h((size_t)grid_ * waves_ * 8);
         (void)hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
         double s4[4] = {0, 0, 0, 0};
         for (size_t i = 0; i < h.size(); i += 8) { s4[0] += (double)h[i + 5]; s4[1] += (double)h[i + 6]; s4[2] += (double)h[i + 7]; s4[3] += (double)(h[i + 2] - h[i + 1]); }
-        const double n = (double)grid_ * 4;
-        fprintf(stderr, "[EIG_TIMING] blocks=%d per-wave cycles: mfma+dma-issue %.0f  vmcnt-wait %.0f  barrier %.0f  loop-total %.0f\n", grid_, s4[0] / n, s4[1] / n, s4[2] / n, s4[3] / n);
+        const double n = (double)grid_ * waves_;
+        fprintf(stderr, "[EIG_TIMING] blocks=%d waves/block=%d per-wave cycles: mfma+dma-issue %.0f  vmcnt-wait %.0f  barrier %.0f  loop-total %.0f\n", grid_, waves_, s4[0] / n, s4[1] / n, s4[2] / n, s4[3] / n);
         a.dbg = nullptr;
         (void)hipFree(dbg);
     }

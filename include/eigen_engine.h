@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define EIGEN_MAX_LAYERS 8
-#define EIGEN_ABI_VERSION 2 /* 2: eigen_config grew (flow_method, fb_*), eigen_debug_dense_flow, gradient = 2 */
+#define EIGEN_ABI_VERSION 3 /* 2: eigen_config grew (flow_method, fb_*), eigen_debug_dense_flow, gradient = 2; 3: eigen_gate_order */
 
 typedef enum {
     EIGEN_OK = 0,
@@ -215,6 +215,11 @@ int eigen_flatten_genomes(int32_t n_genomes, int32_t n_inputs, const int32_t* in
                           int32_t cap_nodes, int32_t cap_edges, int32_t* o_node_off, int32_t* o_edge_off, uint8_t* o_act,
                           double* o_bias, double* o_resp, int32_t* o_edge_src, double* o_edge_w, int32_t* o_out_node,
                           uint8_t* o_status);
+
+/* Element-wise order of the ConvLSTM gate epilogue this library was compiled with (csrc/conv_mfma.h: EIG_GATE_ORDER):
+ * 1 = chainer_prednet's ConvLSTM.__call__ where it is knowable (rounded peephole products, sigmoid = tanh(x/2)/2 + 1/2, un-fused
+ * cell update), 0 = rounds 1-3.  The CPU oracle (oracle/eig_oracle.c: eig_oracle_gate_order) must report the same value. */
+int eigen_gate_order(void);
 
 /* Deterministic fp32 exp / sigmoid / tanh used by the gate epilogue. */
 int eigen_test_det_math(eigen_engine* e, const float* d_x, int32_t n, float* d_exp, float* d_sig, float* d_tanh,

@@ -55,10 +55,14 @@ class LKParams(ctypes.Structure):
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libeig_oracle.so")
+        so = os.environ.get("EIG_ORACLE_LIB") or os.path.join(_HERE, "libeig_oracle.so")  # EIG_ORACLE_LIB: A/B builds (scripts/)
         if not os.path.exists(so):
             build()
         _LIB = ctypes.CDLL(so)
+        _LIB.eig_oracle_gate_order.restype = ctypes.c_int
+        _LIB.eig_oracle_get_threads.restype = ctypes.c_int
+        # the C loops run one item per (output channel, row): beyond ~64 threads they only add fork/join cost (GPU boxes: 256 CPUs)
+        set_threads(int(os.environ.get("EIG_ORACLE_THREADS", min(os.cpu_count() or 1, 64))))
         _LIB.eig_oracle_prednet_rollout.restype = ctypes.c_int
         _LIB.eig_oracle_prednet_rollout_order.restype = ctypes.c_int
         _LIB.eig_oracle_lucas_kanade.restype = ctypes.c_int
@@ -67,6 +71,11 @@ def lib():
         for f in ("eig_oracle_farneback", "eig_oracle_fb_vectors", "eig_oracle_fb_levels", "eig_oracle_fb_grid_step"):
             getattr(_LIB, f).restype = ctypes.c_int
     return _LIB
+
+
+def set_threads(n):
+    """OpenMP threads of the C oracle's convolution loops (results do not depend on it)."""
+    (_LIB or lib()).eig_oracle_set_threads(ctypes.c_int(int(n)))
 
 
 def _p(a, t):

@@ -43,6 +43,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
  */
 #include <math.h>
+#include <omp.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -73,7 +74,24 @@ static inline float det_expf(float x)
     return y * s.f;
 }
 
+/* EIG_GATE_ORDER: element-wise order of the canonical ConvLSTM gate epilogue (the HIP side's conv_mfma.h has the same switch and the
+ * same default).  1 (round 4): what chainer_prednet's ConvLSTM.__call__ does wherever that is knowable -- the peephole c_g(c) = W * c
+ * as a rounded product added last, F.sigmoid = tanh(x * 0.5) * 0.5 + 0.5 (chainer/functions/activation/sigmoid.py forward_cpu; on
+ * the deterministic tanh below instead of the host's libm), cc = tanh(cc) * ii; cc += ff * c as two rounded products and one
+ * addition.  0: rounds 1-3 (fmaf peepholes / cell update, 1 / (1 + exp(-x))), kept for A/B builds. */
+#ifndef EIG_GATE_ORDER
+#define EIG_GATE_ORDER 1
+#endif
+int eig_oracle_gate_order(void) { return EIG_GATE_ORDER; }
+/* Threads of the OpenMP loops (oracle/__init__.py caps them: one item per (channel, row) does not feed 256 threads well). */
+void eig_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int eig_oracle_get_threads(void) { return omp_get_max_threads(); }
+static inline float det_tanhf(float x);
+#if EIG_GATE_ORDER
+static inline float det_sigmoidf(float x) { return det_tanhf(x * 0.5f) * 0.5f + 0.5f; }
+#else
 static inline float det_sigmoidf(float x) { return 1.0f / (1.0f + det_expf(-x)); }
+#endif
 
 static inline float det_tanhf(float x)
 {
@@ -179,11 +197,14 @@ static void conv3x3_chain(float* acc, const float* pad, const float* w, int Cout
 {
     const int PW = W + 2;
     const size_t PP = (size_t)PW * (H + 2);
+    /* one work item per (output channel, row): every output pixel is its own chain, so the split changes no bit (a 3-channel
+     * layer keeps a many-core host busy too; tests/test_oracle_algorithms.py compares a 1-thread run) */
 #pragma omp parallel for schedule(static)
-    for (int o = 0; o < Cout; o++) {
+    for (int oy = 0; oy < Cout * H; oy++) {
+        const int o = oy / H, y = oy - o * H;
         const float* wo = w + (size_t)o * Cin * 9;
         float* ao = acc + (size_t)o * H * W;
-        for (int y = 0; y < H; y++) {
+        {
             for (int x0 = 0; x0 < W; x0 += XB) {
                 const int nb = (W - x0 < XB) ? (W - x0) : XB;
                 float a[XB];
@@ -250,9 +271,10 @@ static void conv_up2x2_chain(float* acc, const float* src, const float* w, int C
     for (size_t oc = 0; oc < (size_t)Cout * Cin; oc++)
         for (int cls = 0; cls < 4; cls++) presum_up_weights(w + oc * 9, cls >> 1, cls & 1, w4 + oc * 16 + cls * 4);
 #pragma omp parallel for schedule(static)
-    for (int o = 0; o < Cout; o++) {
+    for (int oy = 0; oy < Cout * H; oy++) {
+        const int o = oy / H, y = oy - o * H;
         float* ao = acc + (size_t)o * H * W;
-        for (int y = 0; y < H; y++) {
+        {
             const int py = y & 1, Y = y >> 1;
             for (int x = 0; x < W; x++) {
                 const int px = x & 1, X = x >> 1;
@@ -441,6 +463,19 @@ static void prednet_step(prednet_t* n, const float* x)
             for (size_t p = 0; p < hw; p++) {
                 const size_t idx = (size_t)o * hw + p;
                 const float cold = n->c[l][idx];
+#if EIG_GATE_ORDER
+                const float zi = (gi[idx] + bi) + n->peep[l][0][idx] * cold;   /* (-ffp-contract=off: rounded product, then add) */
+                const float zf = (gf[idx] + bf) + n->peep[l][1][idx] * cold;
+                const float zc = gc[idx] + bc;
+                const float zo = (go[idx] + bo) + n->peep[l][2][idx] * cold;
+                const float ii = det_sigmoidf(zi);
+                const float ff = det_sigmoidf(zf);
+                const float oo = det_sigmoidf(zo);
+                float cc = det_tanhf(zc);
+                cc = cc * ii;
+                const float fc = ff * cold;
+                const float cnew = cc + fc;
+#else
                 float zi = gi[idx] + bi; zi = fmaf(n->peep[l][0][idx], cold, zi);
                 float zf = gf[idx] + bf; zf = fmaf(n->peep[l][1][idx], cold, zf);
                 float zc = gc[idx] + bc;
@@ -451,6 +486,7 @@ static void prednet_step(prednet_t* n, const float* x)
                 const float oo = det_sigmoidf(zo);
                 const float gi_ = gg * ii;
                 const float cnew = fmaf(ff, cold, gi_);
+#endif
                 n->c[l][idx] = cnew;
                 n->hn[l][idx] = oo * det_tanhf(cnew);
             }

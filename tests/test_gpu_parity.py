@@ -381,6 +381,39 @@ def test_largest_config_512_colour_one_step_window(cuda, oracle_lib):
     assert int(dc[0]) == len(v) and np.array_equal(dv[0, :len(v)].cpu().numpy(), v)
 
 
+def test_reference_big_size_640x480_colour_window(cuda, oracle_lib):
+    """The reference's other real size, `--size big` = 640x480 (generate_illusion.py:742-746), colour 3,48,96,192: maps of
+    640x480 / 320x240 / 160x120 / 80x60 -- 80x60 is a tiling case no other configuration has (60 rows: 16-row tiles cover 94 %,
+    8-row tiles 100 %).  3 repeats + 1 extension of three genomes against the C oracle (every layer shape, step-0 operators,
+    steady-state operators, the extension feedback; one genome through the oracle: 0.8 TFLOP of scalar C) and Lucas-Kanade on
+    the last pair; the other genomes through batch-position invariance."""
+    import torch
+    from oracle import pipeline
+    w, h, ch = 640, 480, [3, 48, 96, 192]
+    cfg, pop, grid = _render_setup(w, h, 3, 3, seed=6, structure=1)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=2)
+    imgs = np.stack([pipeline.render_chw(g, cfg, grid, 3, w, h) for _, g in pop])
+    e = _eng(w, h, ch, 3, n_repeat=3, n_ext=1)
+    e.set_weights(wts)
+    d_img = torch.from_numpy(imgs).to(cuda)
+    d_fr = torch.zeros((3, 4, 3, h, w), dtype=torch.uint8, device=cuda)
+    e.prednet_rollout(d_img, 3, 4, 0, d_fr)
+    torch.cuda.synchronize()
+    got = d_fr.cpu().numpy()
+    ref = oracle_lib.prednet_rollout(wts, ch, w, h, imgs[2], n_repeat=3, n_ext=1)
+    assert np.array_equal(got[2], ref)
+    d_rev = torch.zeros((3, 4, 3, h, w), dtype=torch.uint8, device=cuda)   # the same genomes at other batch positions
+    e.prednet_rollout(torch.from_numpy(np.ascontiguousarray(imgs[::-1])).to(cuda), 3, 4, 0, d_rev)
+    torch.cuda.synchronize()
+    assert np.array_equal(d_rev.cpu().numpy()[::-1], got)
+    v = oracle_lib.lucas_kanade(ref[2], ref[3])
+    dv = torch.zeros((3, e.K, 4), device=cuda); dc = torch.zeros(3, dtype=torch.int32, device=cuda)
+    e.flow(d_fr[:, 2].contiguous(), 3 * h * w, d_fr[:, 3].contiguous(), 3 * h * w, 3, dv, dc)
+    torch.cuda.synchronize()
+    assert int(dc[2]) == len(v) and np.array_equal(dv[2, :len(v)].cpu().numpy(), v)
+    e.close()
+
+
 def test_default_config_four_inputs_six_outputs(cuda, oracle_lib):
     """neat_configs/default.txt (num_inputs = 4, num_outputs = 6; BASELINE.json configs[0], 64x64 gray): the reference
     asserts here; build-defined: leaves x, y, r = sqrt(x^2 + y^2), bias = 1 and the first c_dim outputs."""

@@ -48,21 +48,33 @@ def _hip_population(cuda, w, h, ch, structure, genomes, cfg, wts):
     return imgs, frames, vecs, hip, grid
 
 
-def _assert_explained(s, min_nonzero, max_flips=64):
-    """The north-star tolerance as a property that holds for EVERY genome (oracle/classify.py)."""
+def _assert_explained(s, min_nonzero, floor_all, floor_nonzero):
+    """The north-star tolerance as a property that holds for EVERY genome (oracle/classify.py), with the floors at what was
+    measured: `floor_all` over all genomes, `floor_nonzero` over the genomes that score non-zero on
+    both sides (a genome that scores 0 on both sides is trivially 'within 1e-4' and must not pad the count)."""
     from oracle import classify
     assert s["nonzero_both"] >= min_nonzero, "only %d non-zero genomes: vacuous" % s["nonzero_both"]
-    assert s["max_byte_diff"] <= 1 and s["byte_flip_rate"] < 1e-4
+    assert s["max_byte_diff"] <= 1 and s["byte_flip_rate"] < 5e-5  # (measured 1.2e-5 at 256^2 colour, 2e-6 at 160x120 gray)
     assert s["max_rel_identical"] <= 1e-9            # same frames -> same vectors -> same fitness (float64 sum order only)
     assert s["outside_1e-4_unexplained"] == 0, s["outside_1e-4_detail"]
-    for d in s["outside_1e-4_detail"]:               # a genome outside 1e-4: a handful of +-1 bytes, ONE of which reproduces it
-        assert 1 <= d["flips"] <= max_flips and classify.explained(d), d
-    assert s["within_1e-4"] >= 0.75 * s["genomes"]  # (measured: 92 % at 256^2 colour, 100 % at 160x120 gray; the property is the line above)
+    for d in s["outside_1e-4_detail"]:               # a genome outside 1e-4: a handful of +-1 bytes that reproduce it on OUR frames
+        assert 1 <= d["flips"] <= classify.MAX_FLIPS and d["explained"], d
+    assert s["max_rel"] <= 2e-2, s["max_rel"]        # absolute cap on any finite deviation (measured max 4.5e-3)
+    assert s["within_1e-4"] >= floor_all * s["genomes"], (s["within_1e-4"], s["genomes"])
+    assert s["within_1e-4_of_nonzero_both"] >= floor_nonzero * s["nonzero_both"], (s["within_1e-4_of_nonzero_both"], s["nonzero_both"])
+
+
+def _few_cpu_threads():
+    """torch-CPU convolutions at batch 1 are fastest on ~16 threads; the GPU boxes default to 128 of their 256 CPUs (5x slower)."""
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 def test_hip_fitness_vs_reference_element_order_c2(cuda, oracle_lib):
     """BASELINE.json configs[1]: circles_bw, 160x120 gray, channels 1,16,32,64, 40 genomes.  HIP path against the reference's
-    element-wise order on torch-CPU (oneDNN convolutions): every genome classified, none unexplained."""
+    element-wise order twice: on torch-CPU (oneDNN convolutions) every genome is classified with the measured floors; against the
+    torch-free C statement of that order (oracle.PredNetC, host-independent) the north-star bar holds as a HARD assert: every
+    genome within 1e-4 (measured max 3.7e-5)."""
     from oracle import classify, pipeline
     from oracle.prednet_torch import PredNetTorch
     w, h, ch, structure = 160, 120, [1, 16, 32, 64], 1
@@ -72,24 +84,30 @@ def test_hip_fitness_vs_reference_element_order_c2(cuda, oracle_lib):
     imgs, frames, vecs, hip, grid = _hip_population(cuda, w, h, ch, structure, genomes, cfg, wts)
     for i in (0, 7, 23):
         assert np.array_equal(imgs[i], pipeline.render_chw(genomes[i], cfg, grid, 1, w, h))  # same stimulus on both sides
+    _few_cpu_threads()
     s, _ = classify.population_report(structure, w, h, imgs, frames, vecs, hip, PredNetTorch(wts, ch, w, h, order="chainer"))
     print("\nC2 160x120 gray vs chainer element order (torch-CPU): %s" % s)
-    _assert_explained(s, 8)
+    _assert_explained(s, 8, 0.97, 0.95)
+    sc, _ = classify.population_report(structure, w, h, imgs, frames, vecs, hip, oracle_lib.PredNetC(wts, ch, w, h, order="chainer"))
+    print("C2 vs chainer element order (C oracle): %s" % sc)
+    assert sc["outside_1e-4"] == 0 and sc["max_rel"] <= 1e-4 and sc["zero_on_one_side_only"] == 0, sc   # north_star, hard
+    assert sc["nonzero_both"] >= 8 and sc["max_byte_diff"] <= 1
 
 
 def test_hip_fitness_vs_reference_element_order_c3(cuda, oracle_lib):
-    """BASELINE.json configs[2], the headline shape (256x256 colour, 3,48,96,192), 12 genomes against torch-CPU / oneDNN in the
+    """BASELINE.json configs[2], the headline shape (256x256 colour, 3,48,96,192), 8 genomes against torch-CPU / oneDNN in the
     reference's element-wise order."""
     from oracle import classify
     from oracle.prednet_torch import PredNetTorch
     w, h, ch, structure = 256, 256, [3, 48, 96, 192], 1
     cfg = synth.make_config(2, 3)
-    genomes = [g for _, g in synth.make_population(12, cfg, seed=0)]
+    genomes = [g for _, g in synth.make_population(8, cfg, seed=0)]
     wts = weights.synthetic_prednet_weights(ch, w, h, seed=0)
     imgs, frames, vecs, hip, _ = _hip_population(cuda, w, h, ch, structure, genomes, cfg, wts)
-    s, _ = classify.population_report(structure, w, h, imgs, frames, vecs, hip, PredNetTorch(wts, ch, w, h, order="chainer"), batch=2)
+    _few_cpu_threads()
+    s, _ = classify.population_report(structure, w, h, imgs, frames, vecs, hip, PredNetTorch(wts, ch, w, h, order="chainer"), batch=1)
     print("\nC3 256x256 colour vs chainer element order (torch-CPU): %s" % s)
-    _assert_explained(s, 4)
+    _assert_explained(s, 3, 0.75, 0.6)   # (8 genomes: one outlier is 12 %)
 
 
 def test_every_genome_outside_1e4_is_a_single_lsb_case_128_genomes(cuda, oracle_lib):
@@ -99,9 +117,11 @@ def test_every_genome_outside_1e4_is_a_single_lsb_case_128_genomes(cuda, oracle_
     cuDNN vs CPU paths included).  128 genomes against the reference's element-wise order with im2col + rocBLAS matmul
     convolutions on the GPU (oracle/prednet_torch.py order="chainer", conv="matmul"; oracle C Lucas-Kanade and numpy scores on
     its frames).  Checked for EVERY genome: byte differences are +-1; identical frames give identical fitness; a genome
-    outside 1e-4 has a handful of flipped bytes and ONE of them, applied to the HIP path's own frames, reproduces at least a
-    quarter of the deviation (usually all of it) -- the deviation is the conditioning of the reference's fitness function.
-    bench.py's parity_check leg repeats this on all 256 genomes of the headline population."""
+    outside 1e-4 has a handful of flipped bytes which, applied to the HIP path's own frames, reproduce the deviation
+    (classify.explained) -- the deviation is the conditioning of the reference's fitness function.
+    CONTROL: the same classification between two NON-HIP implementations of the reference's order (matmul vs
+    the MIOpen library convolution): they must disagree with each other the way HIP disagrees with either of them.
+    bench.py's parity_check leg repeats both on all 256 genomes of the headline population."""
     import torch
     from oracle import classify
     from oracle.prednet_torch import PredNetTorch
@@ -111,11 +131,18 @@ def test_every_genome_outside_1e4_is_a_single_lsb_case_128_genomes(cuda, oracle_
     wts = weights.synthetic_prednet_weights(ch, w, h, seed=0)
     imgs, frames, vecs, hip, _ = _hip_population(cuda, w, h, ch, structure, genomes, cfg, wts)
     torch.backends.cuda.matmul.allow_tf32 = False
-    net = PredNetTorch(wts, ch, w, h, device="cuda", conv="matmul", order="chainer")
-    s, rows = classify.population_report(structure, w, h, imgs, frames, vecs, hip, net, batch=8)
+    torch.backends.cudnn.allow_tf32 = False
+    side_a = classify.rollout_side(structure, w, h, imgs, PredNetTorch(wts, ch, w, h, device="cuda", conv="matmul", order="chainer"), batch=8)
+    s, rows = classify.population_report(structure, w, h, imgs, frames, vecs, hip, None, other=side_a)
     print("\n128 genomes 256x256 colour vs chainer element order (torch-GPU matmul): %s" % s)
-    _assert_explained(s, 48)
+    _assert_explained(s, 48, 0.88, 0.80)
     assert s["zero_on_one_side_only"] <= 2  # (len(good) > 24 is one more cliff; such a genome is in outside_1e-4_detail, explained)
+    side_b = classify.rollout_side(structure, w, h, imgs, PredNetTorch(wts, ch, w, h, device="cuda", conv="library", order="chainer"), batch=8)
+    ctl = classify.control_report(structure, w, h, side_a, side_b, "chainer order, matmul (GPU)", "chainer order, MIOpen (GPU)")
+    print("CONTROL reference-order A vs reference-order B: %s" % ctl)
+    assert ctl["control_max_byte_diff"] <= 1 and ctl["control_byte_flip_rate"] < 5e-5
+    # two implementations of the reference's OWN order are no closer to each other than HIP is to one of them (factor 2 either way)
+    assert ctl["control_outside_1e-4"] >= 0.5 * s["outside_1e-4"] - 2, (ctl, s["outside_1e-4"])
 
 
 def test_config3_bands_256_colour_end_to_end(cuda, oracle_lib):

@@ -22,7 +22,9 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libeigen_hip.so does not export %s" % name
     assert set(engine.EXPORTS) == set(declared)
-    assert lib.eigen_abi_version() == 2
+    assert lib.eigen_abi_version() == 3
+    import oracle
+    assert lib.eigen_gate_order() == oracle.lib().eig_oracle_gate_order() == 1  # library and checker spell the gate epilogue alike
     cfg = engine.EigenConfig()
     lib.eigen_config_defaults(ctypes.byref(cfg))
     assert (cfg.n_repeat, cfg.n_ext, cfg.lk_max_corners, cfg.lk_win, cfg.lk_max_level, cfg.lk_block_size) == (20, 2, 100, 15, 2, 7)
@@ -535,4 +537,4 @@ def test_bench_refuses_what_it_cannot_launch():
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
     import bench as B
     assert len(B.kernel_sources_sha()) == 16 and B.kernel_sources_sha() == B.kernel_sources_sha()
-    assert set(B.SHAPES) == {"headline", "ref160", "c2", "c4", "c5"} and B.SHAPES["headline"][:2] == (256, 256) and B.SHAPES["headline"][7] == 256
+    assert set(B.SHAPES) == {"headline", "ref160", "ref640", "c2", "c4", "c5"} and B.SHAPES["ref640"][:2] == (640, 480) and B.SHAPES["headline"][:2] == (256, 256) and B.SHAPES["headline"][7] == 256
