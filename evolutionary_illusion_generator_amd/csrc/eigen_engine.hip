@@ -242,7 +242,11 @@ static int choose_tw(int H, int W, bool allow4 = false)
         const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
         return (double)H * W / ((double)ty * th * tx * tw);
     };
-    const int sq = (util(16) + 1e-9 >= util(8)) ? 16 : 8;
+    // 16 x 16 tiles unless 8 x 8 tiles cover the map at least 15 % better: the 8-wide instantiations have no branch-free staging path
+    // and a conflicted LDS row stride (conv_mfma.h) -- measured at 160 x 120 maps (640x480 colour, layer 2: profiles/r04_c_perop_shapes.txt):
+    // 8 x 8 tiles at 100 % cover ran at 0.78 of peak, 16 x 16 tiles at 93.75 % cover at 0.86.  EIGEN_TW8_FACTOR for A/Bs.
+    static const double tw8_factor = getenv("EIGEN_TW8_FACTOR") ? atof(getenv("EIGEN_TW8_FACTOR")) : 1.15;
+    const int sq = (util(16) * tw8_factor + 1e-9 >= util(8)) ? 16 : 8;
     static const bool no4 = getenv("EIGEN_NO_TW4") && atoi(getenv("EIGEN_NO_TW4"));
     if (allow4 && !no4 && (W % 4) == 0 && util(4) >= 1.15 * util(sq)) return 4;
     return sq;

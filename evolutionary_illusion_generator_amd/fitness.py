@@ -42,14 +42,22 @@ def _weights_key(model_name):
     if isinstance(model_name, dict):
         # content digest, computed once per dict OBJECT (the table keeps the dict alive, so its id cannot be reused): two equal
         # weight dicts resolve to ONE engine instead of two 9.5 GB ones
+        # A dict that was MUTATED after its first use must not keep resolving to the engine holding the old weights: a
+        # cheap fingerprint -- per array: buffer address, shape and a strided sample of 64 elements -- is checked on every lookup
+        # and the full digest recomputed when it moved.  (Weight dicts are best treated as immutable)
+        def probe(a):
+            a = np.asarray(a)
+            flat = a.reshape(-1)
+            return (a.__array_interface__["data"][0], a.shape, flat[::max(1, flat.size // 64)][:64].tobytes())
+        fp = tuple((k, probe(model_name[k])) for k in sorted(model_name))
         ent = _dict_digests.get(id(model_name))
-        if ent is None or ent[0] is not model_name:
+        if ent is None or ent[0] is not model_name or ent[2] != fp:
             import hashlib
             hsh = hashlib.sha1()
             for k in sorted(model_name):
                 a = np.ascontiguousarray(model_name[k])
                 hsh.update(k.encode()); hsh.update(str(a.shape).encode()); hsh.update(a.tobytes())
-            ent = _dict_digests[id(model_name)] = (model_name, hsh.hexdigest())
+            ent = _dict_digests[id(model_name)] = (model_name, hsh.hexdigest(), fp)
         return ("dict", ent[1])
     name = str(model_name)
     if name.startswith("synthetic"):

@@ -21,11 +21,41 @@ def _conv_matmul(x, w, b, padding=1):
     return y if b is None else y + b.view(1, -1, 1, 1)
 
 
+_WINO = {}
+
+
+def _conv_winograd(x, w, b, padding=1):
+    """3x3 'same' convolution as Winograd F(2x2, 3x3) in fp32 throughout (a STUDY of what 2.25x fewer
+    multiply-adds would do to the results; nothing in the product uses it).  Fixed transform order: V = B^T d B per 4x4 input tile
+    (rows first, then columns), U = G g G^T per filter, M = sum_c U * V as one fp32 matmul per tile position (16 of them),
+    Y = A^T M A (rows first).  Needs even H and W."""
+    B, C, H, W = x.shape
+    assert padding == 1 and H % 2 == 0 and W % 2 == 0
+    key = (x.device, "m")
+    if key not in _WINO:
+        _WINO[key] = (torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32, device=x.device),
+                      torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float32, device=x.device),
+                      torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32, device=x.device))
+    Bt, G, At = _WINO[key]
+    O = w.shape[0]
+    U = torch.matmul(torch.matmul(G, w), G.t())                               # [O, C, 4, 4]
+    xp = F.pad(x, (1, 1, 1, 1))
+    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                    # [B, C, H/2, W/2, 4, 4]
+    V = torch.matmul(torch.matmul(Bt, d), Bt.t())                             # [B, C, th, tw, 4, 4]
+    th, tw = H // 2, W // 2
+    Vm = V.permute(4, 5, 1, 0, 2, 3).reshape(16, C, B * th * tw)              # [16, C, tiles]
+    Um = U.permute(2, 3, 0, 1).reshape(16, O, C)                              # [16, O, C]
+    M = torch.bmm(Um, Vm).view(4, 4, O, B, th, tw).permute(3, 2, 4, 5, 0, 1)  # [B, O, th, tw, 4, 4]
+    Y = torch.matmul(torch.matmul(At, M), At.t())                             # [B, O, th, tw, 2, 2]
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(B, O, H, W)
+    return y if b is None else y + b.view(1, -1, 1, 1)
+
+
 class PredNetTorch:
     def __init__(self, weights, channels, w, h, device="cpu", conv="library", order="stacked"):
         """device: "cpu" (oneDNN) or a cuda device (rocBLAS): two more fp32 summation orders, both independent of the build's
         canonical chain.  conv: "library" = F.conv2d, "matmul" = im2col + matmul (what chainer's CPU Convolution2D does:
-        im2col + tensordot -> BLAS sgemm).
+        im2col + tensordot -> BLAS sgemm), "winograd" = F(2x2, 3x3) in fp32 (a study, scripts/winograd_study.py).
         order: "stacked" = the sources' convolutions summed, bias, then library sigmoid / tanh (round 1-2 cross-check);
                "chainer" = the element-wise order of the reference's own ConvLSTM, as far as it is knowable without its BLAS
                (see _lstm_chainer)."""
@@ -34,7 +64,7 @@ class PredNetTorch:
         self.order = order
         self.ch, self.w, self.h, self.L = list(channels), w, h, len(channels)
         self.dev = torch.device(device)
-        self.conv = F.conv2d if conv == "library" else _conv_matmul
+        self.conv = {"library": F.conv2d, "matmul": _conv_matmul, "winograd": _conv_winograd}[conv]
         self.p = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(self.dev) for k, v in weights.items()}
         # one conv per (layer, source): the 4 gates stacked along the output channels
         self.lstm = []

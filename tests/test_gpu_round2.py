@@ -399,6 +399,8 @@ def test_bench_gpus_flag_launches_ranks(cuda):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert "RCCL" in line["config"]["parallelism"] and len(line["multi_gpu"]["per_rank_device_ms"]) == 1 and line["multi_gpu"]["device_ms_max"] > 0
+    assert line["multi_gpu"]["ranks_seen"] == [0] and line["multi_gpu"]["backend"] == "nccl" and line["multi_gpu"]["rccl_version"]
+    assert line["multi_gpu"]["hsa_ipc_mode_legacy"] == "0"
     assert line["roofline"]["all_conv_kernels"]["launches"] > 0   # rank 0's roofline pass ran after the group was left
     # TWO ranks for real (sharding, broadcast, all-gather with per-rank times, rank 1 leaving while rank 0 profiles) -- on a 1-GPU
     # box they share the device and gloo carries the collectives (RCCL refuses two ranks on one device): control flow, not a number
@@ -411,6 +413,21 @@ def test_bench_gpus_flag_launches_ranks(cuda):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["genomes_per_gpu"] == 4 and len(line["multi_gpu"]["per_rank_device_ms"]) == 2
     assert min(line["multi_gpu"]["per_rank_device_ms"]) > 0 and line["roofline"]["all_conv_kernels"]["launches"] > 0 and line["nonzero_fitness"] >= 0
+    assert line["multi_gpu"]["ranks_seen"] == [0, 1] and line["multi_gpu"]["world_size"] == 2 and line["multi_gpu"]["backend"] == "gloo"
+    # EIGHT ranks at the HEADLINE shape: pop 256 -> 32 genomes per rank, engines at max_batch 32, the broadcast of
+    # the 256-genome wire arrays, the all-gather, all ranks leaving the group together -- what the driver's `--gpus 8` run does,
+    # executed once on a GPU box (the eight ranks share its one device over gloo: control flow, not a measurement)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-parity", "--no-supplementary"],
+                       env=dict(env, EIGEN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["config"]["global_pop"] == 256 and line["config"]["genomes_per_gpu"] == 32 and line["config"]["device_batch"] == 32
+    assert line["multi_gpu"]["ranks_seen"] == list(range(8)) and len(line["multi_gpu"]["per_rank_device_ms"]) == 8
+    assert line["scaling"] == "strong" and line["nonzero_fitness"] >= 100 and line["roofline"]["all_conv_kernels"]["launches"] > 0
     n = 2
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + small, env=env, capture_output=True, text=True, timeout=900)
     if torch.cuda.device_count() >= n:

@@ -491,6 +491,13 @@ def test_equal_weight_dicts_share_one_engine_key():
     c = weights.synthetic_prednet_weights([1, 4, 8], 16, 8, seed=2)
     assert fitness._weights_key(a) == fitness._weights_key(b) != fitness._weights_key(c)
     assert fitness._dict_digests[id(a)][0] is a      # memoised per object (and kept alive, so the id cannot be recycled)
+    # a dict mutated in place after its first use must not keep its old key (array replaced, or elements overwritten)
+    k0 = fitness._weights_key(a)
+    name = sorted(a)[0]
+    a[name] = a[name] + 1.0
+    k1 = fitness._weights_key(a)
+    a[name][...] = 0.25
+    assert k0 != k1 != fitness._weights_key(a) and fitness._weights_key(b) == k0
     fitness._dict_digests.clear()
 
 
