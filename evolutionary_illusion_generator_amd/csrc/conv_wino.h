@@ -1,0 +1,366 @@
+// conv_wino.h -- the ConvLSTM's chain over its full-resolution sources (E_l, h_l) as Winograd F(2x2, 3x3) on the fp32 matrix pipe.
+//
+// Why: the direct implicit-GEMM kernel (conv_mfma.h) runs at 0.91 of the fp32 MFMA peak; at fp32 only FEWER multiply-adds make the
+// roll-out faster.  F(2x2, 3x3) needs 16 multiply-adds per channel and 2x2 output pixels instead of 36 (2.25x fewer).  The parity
+// half of the question was answered first (profiles/r04_c_winograd_study.json): the reference's element-wise order with Winograd
+// convolutions is indistinguishable from any other fp32 re-order of it.  OPT-IN (EIGEN_WINOGRAD = bit mask of layers) until it has
+// earned the default; the canonical arithmetic of a layer that takes it is stated in oracle/eig_oracle.c (wino_*), operation by
+// operation, and this kernel executes exactly those operations:
+//   input transform   t = B^T d (rows), V = t B (columns)        -- fp32 additions / subtractions, fixed order
+//   16 chains         M_pos[o][T] = fmaf(V_pos[c][T], U_pos[o][c], .) over (source, channel) ascending -- v_mfma_f32_16x16x4_f32
+//   output transform  c = M A (columns), y = A^T c (rows)        -- fixed order
+// then the unpooled source's 2x2-form chain is added (one fp32 addition) and the gate epilogue runs: lstm_cell of conv_mfma.h.
+//
+// Block = 16 x 16 output pixels of one image (64 tiles of 2x2 = the 64 pooling windows of the class-major map) x 16 channels x 4
+// gates; 8 waves.  K-block = 8 channels of one source.  Per K-block and block: 512 MFMAs (direct kernel: 1152).
+//   wave w, lane l TRANSFORMS channel w of the K-block for tile l: 12 global loads (the 4x4 patch; rows / columns outside the image
+//     are out of the buffer descriptor's range = zeros), 32 additions, 16 ds_write_b32 into V[pos][channel][tile];
+//   wave w COMPUTES region rg = w & 3 (tiles 16 rg .. 16 rg + 15 = rows 4 rg .. 4 rg + 3 of the tile) for positions (xi, nu) with
+//     xi in {2 h, 2 h + 1}, h = w >> 2: 8 positions x 4 gates = 32 accumulator tiles; per k-step 8 ds_read_b32 (A) + 8 ds_read_b128
+//     (B: a lane's 4 gates of one channel are contiguous) for 32 MFMAs.
+//   U (32 KB per K-block) travels global -> LDS by LDS-DMA, double-buffered; V is double-buffered too: the transform of K-block k+1
+//     is written while K-block k is being multiplied -- ONE barrier per K-block.
+//   Output transform: columns in-lane; the row transform needs xi = 0..3, so the two waves of a region exchange one c-row each
+//     through LDS (free after the K loop); wave (rg, h) then owns output row parity py = h of its region -- exactly the pixel
+//     ownership of the eight-wave direct kernel (conv_mfma.h: W8), whose epilogue indexing is reused.
+#pragma once
+#include "conv_mfma.h"
+
+namespace eig {
+
+constexpr int WINO_THREADS = 512;
+constexpr int WINO_VS = 80;                          // floats per (position, channel) row of V: 64 tiles + 16 (k-slots q, q+1 on disjoint banks)
+constexpr int WINO_V_FLOATS = 16 * KC * WINO_VS;     // 10240
+constexpr int WINO_U_FLOATS = 16 * KC * 64;          // 8192: [16 pos][8 ch][16 cols][4 gates]
+constexpr int WINO_LDS_BYTES = 2 * (WINO_V_FLOATS + WINO_U_FLOATS) * 4;  // 147456
+static_assert(KC == 8, "conv_wino.h: 8-channel K-blocks");
+
+// MODE (same operations on the same data in every mode -- results are identical; A/B'd in profiles/r04_f_wino_modes.txt):
+//   0  every wave transforms K-block k + 1, then multiplies K-block k
+//   1  waves 4..7 multiply first and transform afterwards (waves w and w + 4 were ASSUMED to share a SIMD: measured slower)
+//   2  the same, keyed on w & 1
+//   3  one basic block per K-block whose issue order is dictated with sched_group_barrier: after every MFMA two instructions of the
+//      staging work (patch loads, transform arithmetic, V writes, operand reads) -- a wave fills its own matrix-pipe shadows
+//   4  the same idea written out by hand: 8 chunks of 8 MFMAs, each with the operand reads of the next chunk and a slice of the
+//      staging work, separated by scheduling fences
+template <int MODE>
+__global__ void __launch_bounds__(WINO_THREADS, 1) lstm_wino_kernel(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Vb = lds;                              // [2][16][8][WINO_VS]
+    float* const Ub = lds + 2 * WINO_V_FLOATS;          // [2][16][8][16][4]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wv & 3, half = wv >> 2;
+    const int q = lane >> 4, col = lane & 15;
+
+    // ---- block -> (N-block, image, tile): the XCD-aware order of conv_mfma.h (speed only)
+    const int tiles = a.tilesX * a.tilesY;
+    const int ntile = a.B * tiles;
+    const int xcd = blockIdx.x & 7, xi_ = blockIdx.x >> 3;
+    const int nblk = xi_ % a.n_nblk;
+    const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + xi_ / a.n_nblk : (xi_ / a.n_nblk) * 8 + xcd;
+    if (tlin >= ntile) return;
+    const int eb = tlin / tiles;
+    const int t_ = tlin - eb * tiles;
+    const int tyi = t_ / a.tilesX, txi = t_ - tyi * a.tilesX;
+    const int y0 = tyi * 16, x0 = txi * 16;
+    const int HW = a.H * a.W;
+
+    // ---- the transform side of this thread: channel wv of every K-block, tile `lane` of the block.  Tile l = 16 rg' + r,
+    // r = 4 q' + reg  <->  window (wy, wx) = (reg >> 1, 2 q' + (reg & 1)) of region rg' (the class-major map), so that MFMA row r of a
+    // region is the window the direct kernel's epilogue expects in accumulator register `reg` of lane group q'.
+    const int t_rg = lane >> 4, t_r = lane & 15;
+    const int t_ty = 2 * t_rg + ((t_r & 3) >> 1), t_tx = 2 * (t_r >> 2) + (t_r & 1);
+    const int py0 = y0 + 2 * t_ty - 1, px0 = x0 + 2 * t_tx;   // patch rows py0 .. py0 + 3, columns px0 - 1 .. px0 + 2
+    // byte offsets inside ONE channel plane; -1 = outside the image (a saturating add keeps it out of the descriptor's range)
+    int off_c[4], off_l[4], off_r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int y = py0 + i;
+        const bool rok = y >= 0 && y < a.H && px0 < a.W;
+        off_c[i] = rok ? (y * a.W + px0) * 4 : -1;
+        off_l[i] = (rok && px0 >= 1) ? (y * a.W + px0 - 1) * 4 : -1;
+        off_r[i] = (rok && px0 + 2 < a.W) ? (y * a.W + px0 + 2) * 4 : -1;
+    }
+    // K-blocks: 8 channels of one source, sources in list order (every source here has a multiple of 8 channels)
+    const int nkb0 = a.src[0].C >> 3;
+    const int nkb = nkb0 + (a.nsrc > 1 ? (a.src[1].C >> 3) : 0);
+    const bool has1 = a.nsrc > 1;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb * WINO_U_FLOATS), 0, nkb * WINO_U_FLOATS * 4, 0x00020000);
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float d[4][4];
+    // descriptor of the source a K-block reads, from SCALAR selects of base pointer and size (no branch, no descriptor table); a K-block
+    // past the last one gets a channel offset of 2^31: every lane's saturating add lands out of range and the loads return zeros
+    const unsigned long long sb0 = (unsigned long long)(a.src[0].ptr + (size_t)eb * a.src[0].Ct * HW);
+    const unsigned long long sb1 = has1 ? (unsigned long long)(a.src[1].ptr + (size_t)eb * a.src[1].Ct * HW) : sb0;
+    const int sz0 = a.src[0].C * HW * 4, sz1 = has1 ? a.src[1].C * HW * 4 : sz0;
+    auto load_patch = [&](int kb) __attribute__((always_inline)) {
+        const bool s1 = kb >= nkb0;
+        const unsigned long long u = s1 ? sb1 : sb0;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(s1 ? sz1 : sz0), 0x00020000);
+        const unsigned in_range = (unsigned)((kb - nkb) >> 31);   // all ones while kb < nkb (bit arithmetic: a ternary here became a branch
+        const unsigned coff = ((unsigned)(((kb - (s1 ? nkb0 : 0)) * KC + wv) * HW * 4) & in_range) | (0x80000000u & ~in_range);  // that split the K-block's basic block)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned vl = __builtin_elementwise_add_sat((unsigned)off_l[i], coff), vc = __builtin_elementwise_add_sat((unsigned)off_c[i], coff),
+                           vr = __builtin_elementwise_add_sat((unsigned)off_r[i], coff);
+            d[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vl, 0, 0));
+            const f32x2 m = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vc, 0, 0));
+            d[i][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vr, 0, 0));
+            d[i][1] = m[0]; d[i][2] = m[1];
+        }
+    };
+    // B^T d B of the patch in d -> V[buf][pos][wv][lane]  (oracle/eig_oracle.c: wino_accumulate, same operations in the same order)
+    auto transform = [&](float* vbuf) __attribute__((always_inline)) {
+        float t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+        }
+        float* dst = vbuf + wv * WINO_VS + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dst[(i * 4 + 0) * KC * WINO_VS] = t[i][0] - t[i][2];
+            dst[(i * 4 + 1) * KC * WINO_VS] = t[i][1] + t[i][2];
+            dst[(i * 4 + 2) * KC * WINO_VS] = t[i][2] - t[i][1];
+            dst[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
+        }
+    };
+    // the U slab of K-block kb: 2048 chunks of 16 B, lane-linear (four rounds of 512)
+    auto dma_u = [&](int kb, float* ubuf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ubuf + (j * WINO_THREADS + wv * 64) * 4), 16,
+                                                     (int)((unsigned)(tid * 16 + j * WINO_THREADS * 16) + (unsigned)kb * (WINO_U_FLOATS * 4)), 0, 0, 0);
+    };
+
+    // accumulators: position p = 4 xl + nu (xl = 0, 1: xi = 2 half + xl), gate ni
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int p = 0; p < 8; ++p)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int a_off = (half * 8 * KC + q) * WINO_VS + rg * 16 + col;   // V[pos = 8 half + p][ch = 4 ks + q][tile 16 rg + col]
+    const int b_off = ((half * 8 * KC + q) * 16 + col) * 4;            // U[pos][ch][col][0..3]
+
+    // ---- prologue: K-block 0 transformed and staged, the patch of K-block 1 in flight
+    load_patch(0);
+    dma_u(0, Ub);
+    transform(Vb);
+    load_patch(1);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    // the chain of the unpooled source (EPI_UP4 launch at half this resolution): loaded during the LAST K-block
+    const bool has_up = a.acc_init != nullptr;
+    f32x4 upc[2][4];
+    const int Hs = a.H >> 1, Ws = a.W >> 1, up_hw = Hs * Ws, up_cstride = a.n_nblk * 64 * up_hw;
+    const __amdgpu_buffer_rsrc_t rs_up = __builtin_amdgcn_make_buffer_rsrc((void*)(has_up ? a.acc_init + (size_t)eb * 4 * up_cstride : a.zeros), 0, has_up ? 4 * up_cstride * 4 : 0, 0x00020000);
+    int up_off[2];
+#pragma unroll
+    for (int v = 0; v < 2; ++v) {
+        const int gy0 = y0 + 4 * rg + 2 * v, gx0 = x0 + 4 * q;
+        up_off[v] = (gy0 < a.H && gx0 < a.W) ? ((nblk * 64 + col) * up_hw + (gy0 >> 1) * Ws + (gx0 >> 1)) * 4 : 0;
+    }
+    auto up_loads = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int v = 0; v < 2; ++v) {
+                    const int soff = (ni * 16 * up_hw + (2 * half + mi) * up_cstride) * 4;  // plane = parity class (py = half, px = mi)
+                    const f32x2 t = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs_up, up_off[v], soff, 0));
+                    upc[mi][ni][2 * v] = t[0]; upc[mi][ni][2 * v + 1] = t[1];
+                }
+    };
+
+    const bool late = MODE == 1 ? half != 0 : (MODE == 2 ? (wv & 1) != 0 : false);   // this wave multiplies first (stagger modes)
+    auto kiter = [&](const int kb, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        const float* const vcur = Vb + (kb & 1) * WINO_V_FLOATS;
+        const float* const ucur = Ub + (kb & 1) * WINO_U_FLOATS;
+        auto stage_next = [&]() __attribute__((always_inline)) {   // K-block kb + 1: transform its patch (in d), then fetch the patch of kb + 2
+            if constexpr (!LAST) {
+                transform(Vb + ((kb + 1) & 1) * WINO_V_FLOATS);
+                load_patch(kb + 2);                                   // (past the end: out of range, zeros, never used)
+            }
+        };
+        auto multiply = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float av[8];
+                f32x4 bv[8];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    av[p] = vcur[a_off + (p * KC + ks * 4) * WINO_VS];
+                    bv[p] = *reinterpret_cast<const f32x4*>(ucur + b_off + (p * KC + ks * 4) * 64);
+                }
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) acc[p][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p][ni], acc[p][ni], 0, 0, 0);
+            }
+        };
+        // the U slab of K-block kb + 1 first: every vector-memory instruction issued after it (the 12 patch loads) may still be in
+        // flight at the barrier, the DMA may not
+        if constexpr (!LAST) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS);
+        else if (has_up) up_loads();
+        if constexpr (MODE == 1 || MODE == 2) {
+            if (!late) stage_next();
+            multiply();
+            if (late) stage_next();
+        } else if constexpr (MODE == 4 && !LAST) {
+            // software pipeline written out: 8 chunks of 8 MFMAs (k-step ks = c >> 2, positions 2 pp, 2 pp + 1 with pp = c & 3); each
+            // chunk carries the operand reads of the NEXT chunk and a slice of the staging work, fenced so that the slices stay in
+            // the matrix-pipe shadow of their chunk: c = 0, 1 the column pass of B^T d, c = 2..5 one row of V each (4 subtractions +
+            // 4 LDS writes), c = 6, 7 the twelve loads of the patch after next.
+            float* const vnext = Vb + ((kb + 1) & 1) * WINO_V_FLOATS + wv * WINO_VS + lane;
+            float t[4][4];
+            float av[2][2];
+            f32x4 bv[2][2];
+            auto fetch = [&](int c, int slot) __attribute__((always_inline)) {
+                const int ks = c >> 2, pp = c & 3;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    av[slot][u] = vcur[a_off + ((2 * pp + u) * KC + ks * 4) * WINO_VS];
+                    bv[slot][u] = *reinterpret_cast<const f32x4*>(ucur + b_off + ((2 * pp + u) * KC + ks * 4) * 64);
+                }
+            };
+            // (the source-select scalars of load_patch, once)
+            const int kb2 = kb + 2;
+            const bool s1 = kb2 >= nkb0;
+            const unsigned long long ub = s1 ? sb1 : sb0;
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)ub), hi = __builtin_amdgcn_readfirstlane((unsigned)(ub >> 32));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(s1 ? sz1 : sz0), 0x00020000);
+            const unsigned in_range = (unsigned)((kb2 - nkb) >> 31);
+            const unsigned coff = ((unsigned)(((kb2 - (s1 ? nkb0 : 0)) * KC + wv) * HW * 4) & in_range) | (0x80000000u & ~in_range);
+            fetch(0, 0);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int pp = c & 3;
+                if (c + 1 < 8) fetch(c + 1, (c + 1) & 1);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni)
+                        acc[2 * pp + u][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u][ni], acc[2 * pp + u][ni], 0, 0, 0);
+                if (c < 2) {
+#pragma unroll
+                    for (int j = 2 * c; j < 2 * c + 2; ++j) {
+                        t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+                    }
+                } else if (c < 6) {
+                    const int i = c - 2;
+                    vnext[(i * 4 + 0) * KC * WINO_VS] = t[i][0] - t[i][2];
+                    vnext[(i * 4 + 1) * KC * WINO_VS] = t[i][1] + t[i][2];
+                    vnext[(i * 4 + 2) * KC * WINO_VS] = t[i][2] - t[i][1];
+                    vnext[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
+                } else {
+#pragma unroll
+                    for (int i = 2 * (c - 6); i < 2 * (c - 6) + 2; ++i) {
+                        const unsigned vl = __builtin_elementwise_add_sat((unsigned)off_l[i], coff), vc = __builtin_elementwise_add_sat((unsigned)off_c[i], coff),
+                                       vr = __builtin_elementwise_add_sat((unsigned)off_r[i], coff);
+                        d[i][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vl, 0, 0));
+                        const f32x2 m = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)vc, 0, 0));
+                        d[i][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (int)vr, 0, 0));
+                        d[i][1] = m[0]; d[i][2] = m[1];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+            stage_next();
+            multiply();
+            if constexpr (MODE == 3 && !LAST) {
+                // issue order of this block: [MFMA][2 of: vector-memory read / VALU / LDS read / LDS write] x 64 -- the 108 staging
+                // instructions ride in the shadows of the 64 MFMAs (8 passes each) instead of running in front of them
+#pragma unroll
+                for (int i = 0; i < 64; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x322, 2, 0);
+                }
+            }
+        }
+        if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // (12 = the loads of load_patch)
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    for (int kb = 0; kb + 1 < nkb; ++kb) kiter(kb, std::false_type{});
+    kiter(nkb - 1, std::true_type{});
+
+    // ---- output transform.  Columns in-lane: c_xi0 = (M_xi0 + M_xi1) + M_xi2, c_xi1 = (M_xi1 - M_xi2) - M_xi3.
+    f32x4 cc[2][2][4];  // [xl][b][ni]
+#pragma unroll
+    for (int xl = 0; xl < 2; ++xl)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            cc[xl][0][ni] = (acc[xl * 4 + 0][ni] + acc[xl * 4 + 1][ni]) + acc[xl * 4 + 2][ni];
+            cc[xl][1][ni] = (acc[xl * 4 + 1][ni] - acc[xl * 4 + 2][ni]) - acc[xl * 4 + 3][ni];
+        }
+    // Rows: y_0b = (c_0b + c_1b) + c_2b,  y_1b = c_1b - (c_2b + c_3b).  Wave (rg, 0) holds c_0, c_1 and finishes row parity 0: it needs
+    // c_2 of wave (rg, 1), which holds c_2, c_3, finishes row parity 1 and needs c_1.  One c-row each way through LDS.
+    float* const xb = lds;  // [8 waves][32][64 lanes]; V / U are dead (every wave is past the last barrier)
+    {
+        const int mine = half ? 0 : 1;  // half 0 sends c_1 (its xl = 1), half 1 sends c_2 (its xl = 0)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xb[(wv * 32 + (b * 4 + ni) * 4 + r) * 64 + lane] = cc[mine][b][ni][r];
+    }
+    __syncthreads();
+    f32x4 y[2][4];  // [mi = px][ni]: the accumulators of the eight-wave direct kernel (classes (py = half, px))
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+            f32x4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = xb[((wv ^ 4) * 32 + (b * 4 + ni) * 4 + r) * 64 + lane];
+            if (half == 0) y[b][ni] = (cc[0][b][ni] + cc[1][b][ni]) + o;
+            else y[b][ni] = o - (cc[0][b][ni] + cc[1][b][ni]);
+        }
+    if (has_up) {  // + the chain of the unpooled source: one fp32 addition, as in the direct kernel
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) y[mi][ni] = y[mi][ni] + upc[mi][ni];
+    }
+
+    // ---- gate epilogue: the eight-wave (W8), 16-wide, 16-byte-access path of conv_mfma.h's EPI_LSTM.  Segment sl = row
+    // 4 rg + half + 2 sl of the tile, columns 4 q .. 4 q + 3; element j = register 2 sl + (j >> 1) of sub-tile j & 1.
+    const int ch = nblk * 16 + col;
+    if (ch >= a.Cout) return;
+    const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
+    const size_t cbase = ((size_t)eb * a.Cout + ch) * HW;
+    const size_t pbase = (size_t)ch * HW;
+    const size_t pstride = (size_t)a.Cout * HW;
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+        const int gy = y0 + 4 * rg + half + 2 * sl, gx = x0 + 4 * q;
+        if (gy >= a.H || gx >= a.W) continue;
+        const int pix = gy * a.W + gx;
+        const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
+        const f32x4 pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
+        const f32x4 pf4 = *reinterpret_cast<const f32x4*>(a.peep + pstride + pbase + pix);
+        const f32x4 po4 = *reinterpret_cast<const f32x4*>(a.peep + 2 * pstride + pbase + pix);
+        f32x4 cn4, hn4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float cn, hn;
+            lstm_cell(y[j & 1][0][2 * sl + (j >> 1)], y[j & 1][1][2 * sl + (j >> 1)], y[j & 1][2][2 * sl + (j >> 1)], y[j & 1][3][2 * sl + (j >> 1)],
+                      bi, bf, bc, bo, cold4[j], pi4[j], pf4[j], po4[j], cn, hn);
+            cn4[j] = cn; hn4[j] = hn;
+        }
+        *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
+        *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
+    }
+}
+
+}  // namespace eig

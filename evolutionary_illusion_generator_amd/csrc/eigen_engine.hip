@@ -15,6 +15,7 @@
 
 #include "../../include/eigen_engine.h"
 #include "conv_mfma.h"
+#include "conv_wino.h"
 #include "cppn_kernel.h"
 #include "farneback_kernels.h"
 #include "flow_kernels.h"
@@ -368,6 +369,56 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
     return out;
 }
 
+// ---- Winograd F(2x2, 3x3) form of the ConvLSTM's E_l / h_l chain (conv_wino.h; oracle/eig_oracle.c: wino_weights states the same rule)
+static bool wino_eligible(int l, int C, int H, int W) { return l >= 1 && (C % 16) == 0 && (H % 2) == 0 && (W % 4) == 0; }
+// bit l of the mask = layer l may take the Winograd form (if eligible).  Default: every layer -- measured faster at every shape tried,
+// 256^2 / 512^2 / 640x480 / 160x120, colour and gray, incl. 40 x 30 maps that 16 x 16 tiles cover to 78 % (profiles/r04_h_wino_shapes.txt).
+// Eligibility is a property of the layer's shape only, never of the batch: results must not depend on the device batch of a genome.
+#ifndef EIGEN_WINO_DEFAULT
+#define EIGEN_WINO_DEFAULT 0xFE
+#endif
+static bool wino_layer(int mask, int l, int C, int H, int W) { return ((mask >> l) & 1) && wino_eligible(l, C, H, W); }
+static void wino_weight(const float* g, float* U)  // U = G g G^T: rows first, then columns; fp32, one rounding per operation
+{
+    volatile float s[4][3];
+    for (int j = 0; j < 3; ++j) {
+        s[0][j] = g[j];
+        { volatile float t = g[j] + g[3 + j]; t = t + g[6 + j]; s[1][j] = t * 0.5f; }
+        { volatile float t = g[j] - g[3 + j]; t = t + g[6 + j]; s[2][j] = t * 0.5f; }
+        s[3][j] = g[6 + j];
+    }
+    for (int i = 0; i < 4; ++i) {
+        U[i * 4 + 0] = s[i][0];
+        { volatile float t = s[i][0] + s[i][1]; t = t + s[i][2]; U[i * 4 + 1] = t * 0.5f; }
+        { volatile float t = s[i][0] - s[i][1]; t = t + s[i][2]; U[i * 4 + 2] = t * 0.5f; }
+        U[i * 4 + 3] = s[i][2];
+    }
+}
+// [n_nblk][K-blocks: 8 channels of one source, sources in order][16 positions][8 channels][16 columns][4 gates]
+static std::vector<float> pack_weights_wino(int C, int n_nblk, int nsrc, const int* src_C, const int* src_Cw, const float* const srcw[3][4])
+{
+    int nkb = 0;
+    for (int s = 0; s < nsrc; ++s) nkb += src_C[s] / KC;
+    std::vector<float> out((size_t)n_nblk * nkb * WINO_U_FLOATS, 0.0f);
+    float U[16];
+    for (int nb = 0; nb < n_nblk; ++nb) {
+        int kb0 = 0;
+        for (int s = 0; s < nsrc; ++s) {
+            for (int c = 0; c < src_C[s]; ++c)
+                for (int g = 0; g < 4; ++g)
+                    for (int n = 0; n < 16; ++n) {
+                        const int o = nb * 16 + n;
+                        if (o >= C) continue;
+                        wino_weight(srcw[s][g] + ((size_t)o * src_Cw[s] + c) * 9, U);
+                        float* dst = &out[((size_t)nb * nkb + kb0 + c / KC) * WINO_U_FLOATS];
+                        for (int pos = 0; pos < 16; ++pos) dst[((pos * KC + (c % KC)) * 16 + n) * 4 + g] = U[pos];
+                    }
+            kb0 += src_C[s] / KC;
+        }
+    }
+    return out;
+}
+
 template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false, int SPLIT = 0> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
     constexpr int NT = SPLIT == 1 ? 512 : CONV_THREADS;
@@ -483,6 +534,27 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     op.last_grid = grid; op.last_waves = (w8 == 1) ? 8 : 4;
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
+    if (op.epi == EPI_LSTM_WINO) {  // ConvLSTM chain in its Winograd form: 16 x 16-pixel blocks of one image, eight waves (conv_wino.h)
+        static const int mode = getenv("EIGEN_WINO_MODE") ? atoi(getenv("EIGEN_WINO_MODE")) : 4;  // conv_wino.h: MODE (A/B; same results)
+        static bool attr_done = false;
+        if (!attr_done) {
+            for (const void* k : {(const void*)lstm_wino_kernel<0>, (const void*)lstm_wino_kernel<1>, (const void*)lstm_wino_kernel<2>, (const void*)lstm_wino_kernel<3>, (const void*)lstm_wino_kernel<4>})
+                (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES);
+            attr_done = true;
+        }
+        a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
+        const int nt = batch * a.tilesX * a.tilesY;
+        const int g = op.n_nblk * ((nt + 7) / 8) * 8;
+        op.last_grid = g; op.last_waves = 8;
+        switch (mode) {
+            case 1: hipLaunchKernelGGL(lstm_wino_kernel<1>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
+            case 2: hipLaunchKernelGGL(lstm_wino_kernel<2>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
+            case 3: hipLaunchKernelGGL(lstm_wino_kernel<3>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
+            case 4: hipLaunchKernelGGL(lstm_wino_kernel<4>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
+            default: hipLaunchKernelGGL(lstm_wino_kernel<0>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
+        }
+        r = hipGetLastError();
+    } else {
     static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
     if (op.epi == EPI_CONVP && op.d_wraw && direct_p0) {  // image layer: HBM-bound, one thread per pixel (conv_mfma.h)
         const dim3 g((op.W + P0_TX - 1) / P0_TX, (op.H + P0_TY - 1) / P0_TY, batch);
@@ -522,6 +594,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         case EPI_UP4: r = launch_epi<EPI_UP4>(op.NI, op.TW, a, grid, st, vec, w8); break;
         case EPI_UP4C: r = launch_inst2<4, 16, EPI_UP4C, true>(a, grid, st); break;  // chosen only for 16-wide tiles and 16-byte staging
         default: r = launch_epi<EPI_RAW>(op.NI, op.TW, a, grid, st, vec, w8); break;  // (eigen_test_conv)
+    }
     }
 #if EIG_TIMING
     if (tl_dbg) {
@@ -786,6 +859,21 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             // the pass's prologue / epilogue and its round trip save); where the pass is a SHORT kernel its fixed costs dominate and
             // the in-kernel form wins: 160x120 colour pop 50 +2.3 %, 160x120 gray +5 %.  Hence: in-kernel iff the pass would
             // execute < 2.5e10 multiply-adds per launch at this engine's device batch (~0.35 ms); EIGEN_FUSEUP=0 / 1 force it.
+            // EIGEN_WINOGRAD = bit mask of layers whose chain over E_l / h_l runs in its Winograd F(2x2, 3x3) form (conv_wino.h): 2.25x fewer
+            // multiply-adds, ANOTHER canonical summation order (oracle: wino_mask) -- opt-in.  Such a layer keeps the separate 2x2 pass.
+            static const int wino_env = getenv("EIGEN_WINOGRAD") && *getenv("EIGEN_WINOGRAD") ? atoi(getenv("EIGEN_WINOGRAD")) : EIGEN_WINO_DEFAULT;
+            const bool wino = op.epi == EPI_LSTM && wino_layer(wino_env, l, C, y.H, y.W);
+            if (wino) {
+                const int sc[2] = {2 * C, C}, sw[2] = {2 * C, C}, sc0[1] = {C}, sw0[1] = {2 * C};
+                const float* w2[3][4];
+                for (int g = 0; g < 4; ++g) { w2[0][g] = wx0[g]; w2[1][g] = wh[g]; w2[2][g] = nullptr; }
+                std::vector<float> pw = pack_weights_wino(C, op.n_nblk, 2, sc, sw, w2);
+                std::vector<float> pw0 = pack_weights_wino(C, op.n_nblk, 1, sc0, sw0, w2);
+                if (upload(&op.d_wpk, pw.data(), pw.size()) || upload(&t0.d_wpk, pw0.data(), pw0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, Winograd form)", l);
+                op.epi = t0.epi = EPI_LSTM_WINO; op.TW = t0.TW = 16;
+                op.macs = (double)y.H * y.W / 4 * 16 * 4 * C * (3.0 * C);   // executed: 16 multiply-adds per channel and 2x2 outputs
+                t0.macs = (double)y.H * y.W / 4 * 16 * 4 * C * (1.0 * C);
+            }
             static const int fuse_env = getenv("EIGEN_FUSEUP") ? atoi(getenv("EIGEN_FUSEUP")) : -1;
             static const int fuse_mask = getenv("EIGEN_FUSEUP_MASK") ? atoi(getenv("EIGEN_FUSEUP_MASK")) : -1;  // bit l: layer l in-kernel (A/B)
             const double pass_macs = l < L - 1 ? (double)e->B * y.H * y.W * 4 * C * e->layer[l + 1].C * 4 : 0;

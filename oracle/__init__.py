@@ -68,6 +68,7 @@ def lib():
         _LIB.eig_oracle_lucas_kanade.restype = ctypes.c_int
         _LIB.eig_oracle_good_features.restype = ctypes.c_int
         _LIB.eig_oracle_conv_chain.restype = ctypes.c_int
+        _LIB.eig_oracle_wino_chain.restype = ctypes.c_int
         for f in ("eig_oracle_farneback", "eig_oracle_fb_vectors", "eig_oracle_fb_levels", "eig_oracle_fb_grid_step"):
             getattr(_LIB, f).restype = ctypes.c_int
     return _LIB
@@ -101,7 +102,18 @@ def tensor_names(n_layers):
     return names
 
 
-def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=False, return_float=False, order="canonical"):
+# EIGEN_WINOGRAD unset: every eligible layer (eig_oracle.c: eig_wino_eligible; the engine's default is the same mask)
+WINO_AUTO = 0xFE
+
+
+def wino_mask_default():
+    """Which ConvLSTM layers run their E_l / h_l chain as Winograd F(2x2, 3x3): the engine's switch EIGEN_WINOGRAD (bit l = layer
+    l), so that checker and library follow the same setting by default."""
+    v = os.environ.get("EIGEN_WINOGRAD")
+    return WINO_AUTO if v is None or v == "" else int(v)
+
+
+def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=False, return_float=False, order="canonical", wino_mask=None):
     """Roll ``img`` (uint8 [C0,H,W]) through PredNet; returns uint8 frames [n_repeat+n_ext, C0, H, W].
     order: "canonical" = the build's arithmetic (what the HIP kernels reproduce bit for bit); "chainer" = the reference's
     element-wise order (eig_oracle.c: lstm_reference_order) -- separate convolution tensors added left to right, plain unpool ->
@@ -119,7 +131,8 @@ def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=
     rc = lib().eig_oracle_prednet_rollout_order(
         ctypes.c_int(L), _p(ch, ctypes.c_int), ctypes.c_int(w), ctypes.c_int(h), tab, _p(img, ctypes.c_uint8),
         ctypes.c_int(n_repeat), ctypes.c_int(n_ext), ctypes.c_int(int(requant)), _p(out, ctypes.c_uint8),
-        _p(p0, ctypes.c_float) if return_float else None, ctypes.c_int({"canonical": 0, "chainer": 1}[order]))
+        _p(p0, ctypes.c_float) if return_float else None,
+        ctypes.c_int({"canonical": 0, "chainer": 1}[order] | ((((wino_mask_default() if wino_mask is None else int(wino_mask)) & 0xff) << 8) if order == "canonical" else 0)))
     if rc != 0:
         raise ValueError("eig_oracle_prednet_rollout failed (size must be divisible by 2^(L-1))")
     return (out, p0) if return_float else out
@@ -153,6 +166,22 @@ def conv_chain(sources, ups, weights, H, W):
     out = np.zeros((cout, H, W), dtype=np.float32)
     lib().eig_oracle_conv_chain(ctypes.c_int(ns), st, _p(cin, ctypes.c_int), _p(up, ctypes.c_int), wt,
                                 ctypes.c_int(cout), ctypes.c_int(H), ctypes.c_int(W), _p(out, ctypes.c_float))
+    return out
+
+
+def wino_chain(sources, weights, H, W):
+    """out[o,y,x] = the canonical Winograd F(2x2, 3x3) chain over the listed full-resolution sources (eig_oracle.c: wino_*)."""
+    ns = len(sources)
+    srcs = [np.ascontiguousarray(s, dtype=np.float32) for s in sources]
+    ws = [np.ascontiguousarray(x, dtype=np.float32) for x in weights]
+    cout = ws[0].shape[0]
+    st = (ctypes.POINTER(ctypes.c_float) * ns)(*[_p(a, ctypes.c_float) for a in srcs])
+    wt = (ctypes.POINTER(ctypes.c_float) * ns)(*[_p(a, ctypes.c_float) for a in ws])
+    cin = np.asarray([s.shape[0] for s in srcs], dtype=np.int32)
+    out = np.zeros((cout, H, W), dtype=np.float32)
+    rc = lib().eig_oracle_wino_chain(ctypes.c_int(ns), st, _p(cin, ctypes.c_int), wt, ctypes.c_int(cout), ctypes.c_int(H), ctypes.c_int(W), _p(out, ctypes.c_float))
+    if rc != 0:
+        raise ValueError("wino_chain needs even H and W")
     return out
 
 

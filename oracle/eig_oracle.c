@@ -149,6 +149,7 @@ typedef struct {
     float* up;   /* chain of the unpooled source scratch */
     float* tmp;  /* ConvA full-resolution scratch */
     int order;   /* 0: the build's canonical arithmetic; 1: the reference's element-wise order (lstm_reference_order) */
+    int wino_mask; /* canonical order only: bit l = ConvLSTM_l runs its E_l / h_l chain as Winograd F(2x2, 3x3) (wino_* below) */
 } prednet_t;
 
 /* Tensor table order shared with the Python wrapper (oracle/__init__.py: tensor_table()). */
@@ -299,6 +300,127 @@ static void conv_up2x2_chain(float* acc, const float* src, const float* w, int C
     free(w4);
 }
 
+/* ---- Winograd F(2x2, 3x3) form of a 3x3 'same' convolution, fp32, ONE fixed order of operations (the HIP kernel conv_wino.h runs
+ * exactly these; eligibility and switch: see eig_wino_eligible).  Per 2x2 output tile T = (ty, tx), input patch d[4][4] =
+ * in[c][2ty-1+i][2tx-1+j] (zeros outside the image):
+ *   input transform   t_ij = rows:  t0j = d0j - d2j, t1j = d1j + d2j, t2j = d2j - d1j, t3j = d1j - d3j   (B^T d)
+ *                     V_ij = cols:  Vi0 = ti0 - ti2, Vi1 = ti1 + ti2, Vi2 = ti2 - ti1, Vi3 = ti1 - ti3   ((B^T d) B)
+ *   weight transform  s_ij = rows:  s0j = g0j, s1j = ((g0j + g1j) + g2j) * 0.5, s2j = ((g0j - g1j) + g2j) * 0.5, s3j = g2j   (G g)
+ *                     U_ij = cols:  Ui0 = si0, Ui1 = ((si0 + si1) + si2) * 0.5, Ui2 = ((si0 - si1) + si2) * 0.5, Ui3 = si2   ((G g) G^T)
+ *   16 independent chains  M_ij[o][T] = fmaf(V_ij[c][T], U_ij[o][c], M_ij[o][T]) over the sources in list order, channels ascending
+ *   output transform  c_i0 = (M_i0 + M_i1) + M_i2,  c_i1 = (M_i1 - M_i2) - M_i3                       (M A)
+ *                     y_0b = (c_0b + c_1b) + c_2b,  y_1b = c_1b - (c_2b + c_3b)                        (A^T (M A))
+ * 16 multiply-adds per channel and 2x2 outputs instead of 36.  Algebraically the same convolution; numerically one more summation
+ * order (profiles/r04_c_winograd_study.json: indistinguishable from any other fp32 re-order of the reference's arithmetic). */
+static void wino_weights(const float* g /*[3][3]*/, float* U /*[16]*/)
+{
+    float s[4][3];
+    for (int j = 0; j < 3; j++) {
+        s[0][j] = g[j];
+        s[1][j] = ((g[j] + g[3 + j]) + g[6 + j]) * 0.5f;
+        s[2][j] = ((g[j] - g[3 + j]) + g[6 + j]) * 0.5f;
+        s[3][j] = g[6 + j];
+    }
+    for (int i = 0; i < 4; i++) {
+        U[i * 4 + 0] = s[i][0];
+        U[i * 4 + 1] = ((s[i][0] + s[i][1]) + s[i][2]) * 0.5f;
+        U[i * 4 + 2] = ((s[i][0] - s[i][1]) + s[i][2]) * 0.5f;
+        U[i * 4 + 3] = s[i][2];
+    }
+}
+
+/* M[16][Cout][TH*TW] += chains over the Cin channels of one source (pad: [Cin][H+2][W+2], zero border) */
+static void wino_accumulate(float* M, const float* pad, const float* w, int Cout, int Cin, int H, int W)
+{
+    const int TH = H / 2, TW = W / 2, NT = TH * TW, PW = W + 2;
+    const size_t PP = (size_t)PW * (H + 2);
+    float* V = (float*)malloc(sizeof(float) * (size_t)Cin * 16 * NT);
+    float* U = (float*)malloc(sizeof(float) * (size_t)Cout * Cin * 16);
+#pragma omp parallel for schedule(static)
+    for (int c = 0; c < Cin; c++) {
+        const float* pc = pad + (size_t)c * PP;
+        float* vc = V + (size_t)c * 16 * NT;
+        for (int ty = 0; ty < TH; ty++)
+            for (int tx = 0; tx < TW; tx++) {
+                float d[4][4], t[4][4];
+                for (int i = 0; i < 4; i++)
+                    for (int j = 0; j < 4; j++) d[i][j] = pc[(size_t)(2 * ty + i) * PW + 2 * tx + j];  /* pad offset +1 absorbs the -1 */
+                for (int j = 0; j < 4; j++) {
+                    t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+                }
+                const int T = ty * TW + tx;
+                for (int i = 0; i < 4; i++) {
+                    vc[(size_t)(i * 4 + 0) * NT + T] = t[i][0] - t[i][2];
+                    vc[(size_t)(i * 4 + 1) * NT + T] = t[i][1] + t[i][2];
+                    vc[(size_t)(i * 4 + 2) * NT + T] = t[i][2] - t[i][1];
+                    vc[(size_t)(i * 4 + 3) * NT + T] = t[i][1] - t[i][3];
+                }
+            }
+    }
+    for (size_t oc = 0; oc < (size_t)Cout * Cin; oc++) wino_weights(w + oc * 9, U + oc * 16);
+#pragma omp parallel for schedule(static)
+    for (int op = 0; op < Cout * 16; op++) {
+        const int o = op / 16, pos = op - o * 16;
+        float* m = M + ((size_t)pos * Cout + o) * NT;
+        for (int c = 0; c < Cin; c++) {
+            const float u = U[((size_t)o * Cin + c) * 16 + pos];
+            const float* v = V + ((size_t)c * 16 + pos) * NT;
+            for (int T = 0; T < NT; T++) m[T] = fmaf(v[T], u, m[T]);
+        }
+    }
+    free(V); free(U);
+}
+
+/* out[o][2ty+a][2tx+b] = y_ab of the output transform (overwrites out) */
+static void wino_finish(float* out, const float* M, int Cout, int H, int W)
+{
+    const int TH = H / 2, TW = W / 2, NT = TH * TW;
+#pragma omp parallel for schedule(static)
+    for (int o = 0; o < Cout; o++)
+        for (int ty = 0; ty < TH; ty++)
+            for (int tx = 0; tx < TW; tx++) {
+                const int T = ty * TW + tx;
+                float m[16], c[4][2];
+                for (int p = 0; p < 16; p++) m[p] = M[((size_t)p * Cout + o) * NT + T];
+                for (int i = 0; i < 4; i++) {
+                    c[i][0] = (m[i * 4 + 0] + m[i * 4 + 1]) + m[i * 4 + 2];
+                    c[i][1] = (m[i * 4 + 1] - m[i * 4 + 2]) - m[i * 4 + 3];
+                }
+                float* po = out + (size_t)o * H * W;
+                for (int b = 0; b < 2; b++) {
+                    po[(size_t)(2 * ty) * W + 2 * tx + b] = (c[0][b] + c[1][b]) + c[2][b];
+                    po[(size_t)(2 * ty + 1) * W + 2 * tx + b] = c[1][b] - (c[2][b] + c[3][b]);
+                }
+            }
+}
+
+/* Which ConvLSTM layers the Winograd form exists for (the HIP engine applies the same rule, eigen_engine.hip: wino_eligible):
+ * 16-channel gate groups, even maps, 16-byte rows. */
+static int eig_wino_eligible(int l, int C, int H, int W) { return l >= 1 && (C % 16) == 0 && (H % 2) == 0 && (W % 4) == 0; }
+/* The switch: bit l of wino_mask = layer l may take the Winograd form (if eligible).  Eligibility is a property of the layer's shape
+ * only, never of the batch: results must not depend on how a population is split into device batches. */
+static int eig_wino_layer(int wino_mask, int l, int C, int H, int W) { return ((wino_mask >> l) & 1) && eig_wino_eligible(l, C, H, W); }
+
+/* exported for kernel-level tests: out[Cout][H][W] = Winograd chain over the listed full-resolution sources (canonical order) */
+int eig_oracle_wino_chain(int ns, const float* const* src, const int* cin, const float* const* w, int Cout, int H, int W, float* out)
+{
+    if ((H & 1) || (W & 1)) return -1;
+    size_t maxc = 0;
+    for (int s = 0; s < ns; s++) if ((size_t)cin[s] > maxc) maxc = (size_t)cin[s];
+    float* pad = (float*)malloc(sizeof(float) * maxc * (H + 2) * (W + 2));
+    float* M = (float*)calloc((size_t)16 * Cout * (H / 2) * (W / 2), sizeof(float));
+    for (int s = 0; s < ns; s++) {
+        const int PW = W + 2;
+        memset(pad, 0, sizeof(float) * (size_t)cin[s] * PW * (H + 2));
+        for (int c = 0; c < cin[s]; c++)
+            for (int y = 0; y < H; y++) memcpy(pad + ((size_t)c * (H + 2) + y + 1) * PW + 1, src[s] + ((size_t)c * H + y) * W, sizeof(float) * W);
+        wino_accumulate(M, pad, w[s], Cout, cin[s], H, W);
+    }
+    wino_finish(out, M, Cout, H, W);
+    free(pad); free(M);
+    return 0;
+}
+
 static inline float relu(float v) { return v > 0.0f ? v : 0.0f; }
 
 /* E = concat(relu(A - P), relu(P - A))  -- net.py PredNet.__call__ */
@@ -443,10 +565,23 @@ static void prednet_step(prednet_t* n, const float* x)
         if (n->order == 1) { lstm_reference_order(n, l); goto predict; }
         memset(n->gate, 0, sizeof(float) * 4 * C * hw);
         /* one chain over the full-resolution sources E_l, h_l (ConvLSTM.__call__: x_*0, h_*) ... */
+        if (eig_wino_layer(n->wino_mask, l, C, H, W)) {  /* ... in its Winograd form: 16 chains per 2x2 tile */
+            float* M = (float*)calloc((size_t)16 * C * (hw / 4), sizeof(float));
+            for (int g = 0; g < 4; g++) {
+                memset(M, 0, sizeof(float) * (size_t)16 * C * (hw / 4));
+                fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
+                wino_accumulate(M, n->pad, n->wx0[l][g], C, 2 * C, H, W);
+                fill_padded(n->pad, n->h[l], C, H, W, 0);
+                wino_accumulate(M, n->pad, n->wh[l][g], C, C, H, W);
+                wino_finish(n->gate + (size_t)g * C * hw, M, C, H, W);
+            }
+            free(M);
+        } else {
         fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
         for (int g = 0; g < 4; g++) conv3x3_chain(n->gate + (size_t)g * C * hw, n->pad, n->wx0[l][g], C, 2 * C, H, W);
         fill_padded(n->pad, n->h[l], C, H, W, 0);
         for (int g = 0; g < 4; g++) conv3x3_chain(n->gate + (size_t)g * C * hw, n->pad, n->wh[l][g], C, C, H, W);
+        }
         /* ... plus the chain of the unpooled R_{l+1} (x_*1; 2x2 form, see the header): one fp32 addition */
         if (l < L - 1) { /* h[l+1] already holds R_{l+1} of this step */
             memset(n->up, 0, sizeof(float) * 4 * C * hw);
@@ -530,17 +665,20 @@ int eig_oracle_prednet_rollout(int L, const int* channels, int W, int H, const f
     return eig_oracle_prednet_rollout_order(L, channels, W, H, tensors, img, n_repeat, n_ext, requant, out_frames, out_p0, 0);
 }
 
-/* order: 0 = the build's canonical arithmetic, 1 = the reference's element-wise order (lstm_reference_order) */
+/* order: 0 = the build's canonical arithmetic, 1 = the reference's element-wise order (lstm_reference_order); bits 8..15: wino_mask */
 int eig_oracle_prednet_rollout_order(int L, const int* channels, int W, int H, const float* const* tensors,
                                      const uint8_t* img, int n_repeat, int n_ext, int requant,
                                      uint8_t* out_frames, float* out_p0, int order)
 {
+    const int wino_mask = (order >> 8) & 0xff;  /* order = base | (wino_mask << 8) */
+    order &= 0xff;
     if (L < 1 || L > EIG_MAX_LAYERS || order < 0 || order > 1) return -1;
     if ((W % (1 << (L - 1))) || (H % (1 << (L - 1)))) return -1;
     prednet_t n;
     memset(&n, 0, sizeof(n));
     n.L = L;
     n.order = order;
+    n.wino_mask = wino_mask;
     for (int l = 0; l < L; l++) { n.ch[l] = channels[l]; n.W[l] = W >> l; n.H[l] = H >> l; }
     bind_tensors(&n, tensors);
     prednet_alloc(&n);

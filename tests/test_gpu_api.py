@@ -246,6 +246,9 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
                 {"EIGEN_NO_TW4": "1"},                                                                          # 4-column strips off: 8 x 8 tiles on the 20 x 16 maps
                 # round 4: the population as two halves on two streams (B = 3: halves of 2 and 1 genomes), forced on / off, with the
                 # half-step offset re-imposed at every step, and with the separate 2x2 pass (the halves' partial-chain scratch is disjoint)
-                {"EIGEN_PIPE2": "1"}, {"EIGEN_PIPE2": "0"}, {"EIGEN_PIPE2": "1", "EIGEN_PIPE2_SYNC": "1"}, {"EIGEN_PIPE2": "1", "EIGEN_FUSEUP": "0", "EIGEN_W8": "0"}):
+                {"EIGEN_PIPE2": "1"}, {"EIGEN_PIPE2": "0"}, {"EIGEN_PIPE2": "1", "EIGEN_PIPE2_SYNC": "1"}, {"EIGEN_PIPE2": "1", "EIGEN_FUSEUP": "0", "EIGEN_W8": "0"},
+                # the schedules of the Winograd ConvLSTM kernel (conv_wino.h: MODE; the 48- and 16-channel top layers of the first two
+                # roll-outs take it): which wave issues what when -- never which operations
+                {"EIGEN_WINO_MODE": "0"}, {"EIGEN_WINO_MODE": "1"}, {"EIGEN_WINO_MODE": "2"}, {"EIGEN_WINO_MODE": "3"}):
         assert run(env) == base, env
     assert run({"EIGEN_FUSEUP": "0"}) == base  # these small roll-outs take the in-kernel chain by default: the separate pass

@@ -5,8 +5,13 @@ lists, vector counts); fp32 conv accumulators and gate math bit-exact against th
 chain; flow vectors bit-exact (same integer window sums, same fp32 solve); fitness within 1e-9 relative
 (float64 sums in a different order), far inside north_star's 1e-4.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -412,6 +417,50 @@ def test_reference_big_size_640x480_colour_window(cuda, oracle_lib):
     torch.cuda.synchronize()
     assert int(dc[2]) == len(v) and np.array_equal(dv[2, :len(v)].cpu().numpy(), v)
     e.close()
+
+
+_WINO_SCRIPT = r"""
+import sys
+import numpy as np, torch
+sys.path.insert(0, %(root)r)
+import oracle
+from evolutionary_illusion_generator_amd import weights
+from evolutionary_illusion_generator_amd.engine import Engine
+assert oracle.wino_mask_default() == 14
+ok = True
+# (w, h, channels, batch): 16-channel gate groups at layers >= 1; ragged 16 x 16 tiles (40 x 24, 20 x 12 maps), a 4-layer net, a
+# top layer without an unpooled source, colour and gray image layers (which keep the direct operators)
+for (w, h, ch, B) in [(64, 64, [3, 16, 32], 3), (80, 48, [1, 16, 32, 48], 2), (96, 64, [3, 48, 96], 2)]:
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, (B, ch[0], h, w), dtype=np.uint8)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=5)
+    e = Engine(w, h, ch, B, n_repeat=4, n_ext=2)
+    e.set_weights(wts)
+    fr = torch.zeros((B, 6, ch[0], h, w), dtype=torch.uint8, device="cuda")
+    e.prednet_rollout(torch.from_numpy(img).cuda(), B, 6, 0, fr)
+    torch.cuda.synchronize()
+    got = fr.cpu().numpy()
+    rows = [r for r in e.conv_profile(False) if r["epi"] == "lstm"]
+    for b in range(B):
+        ref = oracle.prednet_rollout(wts, ch, w, h, img[b], n_repeat=4, n_ext=2)            # wino_mask from EIGEN_WINOGRAD
+        direct = oracle.prednet_rollout(wts, ch, w, h, img[b], n_repeat=4, n_ext=2, wino_mask=0)
+        same = np.array_equal(got[b], ref)
+        print("WINO", (w, h, ch), b, "bit-exact" if same else "MISMATCH %%d bytes" %% int((got[b] != ref).sum()), "differs from the direct order in", int((ref != direct).sum()), "bytes")
+        ok = ok and same
+    e.close()
+print("WINO_OK" if ok else "WINO_FAIL")
+"""
+
+
+def test_winograd_convlstm_frames_bit_exact(cuda, oracle_lib):
+    """EIGEN_WINOGRAD=14 (layers 1-3): the ConvLSTM's chain over E_l / h_l in its Winograd F(2x2, 3x3) form (csrc/conv_wino.h) against
+    the oracle's statement of exactly that arithmetic (eig_oracle.c: wino_*; the oracle follows the same environment switch).  All
+    frames of three small roll-outs, bit for bit -- incl. step-0 operators (one source), ragged tiles and a top layer without an
+    unpooled source.  Opt-in path: the default engine never takes it."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", _WINO_SCRIPT % {"root": ROOT}], env=dict(os.environ, EIGEN_WINOGRAD="14"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "WINO_OK" in r.stdout, r.stdout[-3000:]
 
 
 def test_default_config_four_inputs_six_outputs(cuda, oracle_lib):
