@@ -79,7 +79,7 @@ namespace eig {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { EPI_RAW = 0, EPI_LSTM = 1, EPI_CONVA = 2, EPI_CONVP = 3, EPI_LSTM_PACKED = 4, EPI_UP4 = 5, EPI_UP4C = 6, EPI_LSTM_WINO = 7 /* conv_wino.h */ };
+enum { EPI_RAW = 0, EPI_LSTM = 1, EPI_CONVA = 2, EPI_CONVP = 3, EPI_LSTM_PACKED = 4, EPI_UP4 = 5, EPI_UP4C = 6 };
 constexpr int epi_taps(int epi) { return (epi == EPI_UP4 || epi == EPI_UP4C) ? 4 : 9; }
 
 struct ConvSrc {

@@ -31,21 +31,27 @@ namespace eig {
 constexpr int WINO_THREADS = 512;
 constexpr int WINO_VS = 80;                          // floats per (position, channel) row of V: 64 tiles + 16 (k-slots q, q+1 on disjoint banks)
 constexpr int WINO_V_FLOATS = 16 * KC * WINO_VS;     // 10240
-constexpr int WINO_U_FLOATS = 16 * KC * 64;          // 8192: [16 pos][8 ch][16 cols][4 gates]
-constexpr int WINO_LDS_BYTES = 2 * (WINO_V_FLOATS + WINO_U_FLOATS) * 4;  // 147456
+constexpr int wino_u_floats(int NI) { return 16 * KC * 16 * NI; }   // [16 pos][8 ch][16 cols][NI]: 8192 for NI = 4
+constexpr int wino_lds_bytes(int NI) { return 2 * (WINO_V_FLOATS + wino_u_floats(NI)) * 4 + 16; }  // 147472 for NI = 4
 static_assert(KC == 8, "conv_wino.h: 8-channel K-blocks");
 
-// MODE (same operations on the same data in every mode -- results are identical; A/B'd in profiles/r04_f_wino_modes.txt):
+// NI 16-column N-tiles per block.  EPI_LSTM (NI = 4): N-tile = gate, column = channel 16 nblk + col; the wave pair of a region splits the
+// OUTPUT ROWS (each wave needs all four gates of its pixels).  EPI_CONVA / EPI_CONVP (NI = 3, 4): column = channel 16 (NI nblk + ni) +
+// col; the pair splits the N-TILES instead, so that each wave ends up with all four parity classes of its channels -- the 2x2 tile
+// IS ConvA's pooling window (max in-lane), and ConvP stores whole 4 x 4-pixel patches.
+// MODE (same operations on the same data in every mode -- results are identical; A/B'd in profiles/r04_g_wino_modes.txt):
 //   0  every wave transforms K-block k + 1, then multiplies K-block k
-//   1  waves 4..7 multiply first and transform afterwards (waves w and w + 4 were ASSUMED to share a SIMD: measured slower)
-//   2  the same, keyed on w & 1
-//   3  one basic block per K-block whose issue order is dictated with sched_group_barrier: after every MFMA two instructions of the
-//      staging work (patch loads, transform arithmetic, V writes, operand reads) -- a wave fills its own matrix-pipe shadows
-//   4  the same idea written out by hand: 8 chunks of 8 MFMAs, each with the operand reads of the next chunk and a slice of the
-//      staging work, separated by scheduling fences
-template <int MODE>
-__global__ void __launch_bounds__(WINO_THREADS, 1) lstm_wino_kernel(const ConvArgs a)
+//   4  software pipeline written out: 8 chunks of 8 MFMAs, each with the operand reads of the next chunk and a slice of the staging
+//      work, separated by scheduling fences (a wave fills its own matrix-pipe shadows): +3.6 % on the headline
+//   (tried and dropped: the waves of one half / of one parity multiplying first and transforming afterwards, -3 ... -6 %; the same
+//    interleave dictated with sched_group_barrier, -1.5 %)
+template <int NI, int EPI, int MODE>
+__global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
 {
+    static_assert(EPI == EPI_LSTM || EPI == EPI_CONVA || EPI == EPI_CONVP, "conv_wino.h: ConvLSTM, ConvA, ConvP");
+    static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
+    static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
+    constexpr int WINO_U_FLOATS = wino_u_floats(NI);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const Vb = lds;                              // [2][16][8][WINO_VS]
     float* const Ub = lds + 2 * WINO_V_FLOATS;          // [2][16][8][16][4]
@@ -130,22 +136,32 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) lstm_wino_kernel(const ConvAr
             dst[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
         }
     };
-    // the U slab of K-block kb: 2048 chunks of 16 B, lane-linear (four rounds of 512)
+    // the U slab of K-block kb
     auto dma_u = [&](int kb, float* ubuf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NI; ++j)   // 512 NI chunks of 16 B, lane-linear
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ubuf + (j * WINO_THREADS + wv * 64) * 4), 16,
                                                      (int)((unsigned)(tid * 16 + j * WINO_THREADS * 16) + (unsigned)kb * (WINO_U_FLOATS * 4)), 0, 0, 0);
     };
 
-    // accumulators: position p = 4 xl + nu (xl = 0, 1: xi = 2 half + xl), gate ni
-    f32x4 acc[8][4];
+    // accumulators: position p = 4 xl + nu (xl = 0, 1: xi = 2 half + xl), N-tile ni
+    f32x4 acc[8][NI];
 #pragma unroll
     for (int p = 0; p < 8; ++p)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NI; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int a_off = (half * 8 * KC + q) * WINO_VS + rg * 16 + col;   // V[pos = 8 half + p][ch = 4 ks + q][tile 16 rg + col]
-    const int b_off = ((half * 8 * KC + q) * 16 + col) * 4;            // U[pos][ch][col][0..3]
+    const int b_off = ((half * 8 * KC + q) * 16 + col) * NI;           // U[pos][ch][col][0..NI-1]
+    auto read_b = [&](const float* ucur, int p, int ks, float (&bv)[NI]) __attribute__((always_inline)) {
+        const float* src = ucur + b_off + (p * KC + ks * 4) * 16 * NI;
+        if constexpr (NI == 4) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(src);
+            bv[0] = b4[0]; bv[1] = b4[1]; bv[2] = b4[2]; bv[3] = b4[3];
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) bv[ni] = src[ni];
+        }
+    };
 
     // ---- prologue: K-block 0 transformed and staged, the patch of K-block 1 in flight
     load_patch(0);
@@ -155,8 +171,8 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) lstm_wino_kernel(const ConvAr
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
-    // the chain of the unpooled source (EPI_UP4 launch at half this resolution): loaded during the LAST K-block
-    const bool has_up = a.acc_init != nullptr;
+    // the chain of the unpooled source (EPI_UP4 launch at half this resolution): loaded during the LAST K-block (ConvLSTM only)
+    const bool has_up = EPI == EPI_LSTM && a.acc_init != nullptr;
     f32x4 upc[2][4];
     const int Hs = a.H >> 1, Ws = a.W >> 1, up_hw = Hs * Ws, up_cstride = a.n_nblk * 64 * up_hw;
     const __amdgpu_buffer_rsrc_t rs_up = __builtin_amdgcn_make_buffer_rsrc((void*)(has_up ? a.acc_init + (size_t)eb * 4 * up_cstride : a.zeros), 0, has_up ? 4 * up_cstride * 4 : 0, 0x00020000);
@@ -179,56 +195,29 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) lstm_wino_kernel(const ConvAr
                 }
     };
 
-    const bool late = MODE == 1 ? half != 0 : (MODE == 2 ? (wv & 1) != 0 : false);   // this wave multiplies first (stagger modes)
     auto kiter = [&](const int kb, auto last_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
         const float* const vcur = Vb + (kb & 1) * WINO_V_FLOATS;
         const float* const ucur = Ub + (kb & 1) * WINO_U_FLOATS;
-        auto stage_next = [&]() __attribute__((always_inline)) {   // K-block kb + 1: transform its patch (in d), then fetch the patch of kb + 2
-            if constexpr (!LAST) {
-                transform(Vb + ((kb + 1) & 1) * WINO_V_FLOATS);
-                load_patch(kb + 2);                                   // (past the end: out of range, zeros, never used)
-            }
-        };
-        auto multiply = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                float av[8];
-                f32x4 bv[8];
-#pragma unroll
-                for (int p = 0; p < 8; ++p) {
-                    av[p] = vcur[a_off + (p * KC + ks * 4) * WINO_VS];
-                    bv[p] = *reinterpret_cast<const f32x4*>(ucur + b_off + (p * KC + ks * 4) * 64);
-                }
-#pragma unroll
-                for (int p = 0; p < 8; ++p)
-#pragma unroll
-                    for (int ni = 0; ni < 4; ++ni) acc[p][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p][ni], acc[p][ni], 0, 0, 0);
-            }
-        };
         // the U slab of K-block kb + 1 first: every vector-memory instruction issued after it (the 12 patch loads) may still be in
         // flight at the barrier, the DMA may not
         if constexpr (!LAST) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS);
         else if (has_up) up_loads();
-        if constexpr (MODE == 1 || MODE == 2) {
-            if (!late) stage_next();
-            multiply();
-            if (late) stage_next();
-        } else if constexpr (MODE == 4 && !LAST) {
-            // software pipeline written out: 8 chunks of 8 MFMAs (k-step ks = c >> 2, positions 2 pp, 2 pp + 1 with pp = c & 3); each
+        if constexpr (MODE == 4 && !LAST) {
+            // software pipeline written out: 8 chunks of 2 NI MFMAs (k-step ks = c >> 2, positions 2 pp, 2 pp + 1 with pp = c & 3); each
             // chunk carries the operand reads of the NEXT chunk and a slice of the staging work, fenced so that the slices stay in
             // the matrix-pipe shadow of their chunk: c = 0, 1 the column pass of B^T d, c = 2..5 one row of V each (4 subtractions +
             // 4 LDS writes), c = 6, 7 the twelve loads of the patch after next.
             float* const vnext = Vb + ((kb + 1) & 1) * WINO_V_FLOATS + wv * WINO_VS + lane;
             float t[4][4];
             float av[2][2];
-            f32x4 bv[2][2];
+            float bv[2][2][NI];
             auto fetch = [&](int c, int slot) __attribute__((always_inline)) {
                 const int ks = c >> 2, pp = c & 3;
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     av[slot][u] = vcur[a_off + ((2 * pp + u) * KC + ks * 4) * WINO_VS];
-                    bv[slot][u] = *reinterpret_cast<const f32x4*>(ucur + b_off + ((2 * pp + u) * KC + ks * 4) * 64);
+                    read_b(ucur, 2 * pp + u, ks, bv[slot][u]);
                 }
             };
             // (the source-select scalars of load_patch, once)
@@ -247,7 +236,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) lstm_wino_kernel(const ConvAr
 #pragma unroll
                 for (int u = 0; u < 2; ++u)
 #pragma unroll
-                    for (int ni = 0; ni < 4; ++ni)
+                    for (int ni = 0; ni < NI; ++ni)
                         acc[2 * pp + u][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u][ni], acc[2 * pp + u][ni], 0, 0, 0);
                 if (c < 2) {
 #pragma unroll
@@ -274,16 +263,23 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) lstm_wino_kernel(const ConvAr
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-            stage_next();
-            multiply();
-            if constexpr (MODE == 3 && !LAST) {
-                // issue order of this block: [MFMA][2 of: vector-memory read / VALU / LDS read / LDS write] x 64 -- the 108 staging
-                // instructions ride in the shadows of the 64 MFMAs (8 passes each) instead of running in front of them
+            if constexpr (!LAST) {   // K-block kb + 1: transform its patch (in d), then fetch the patch of kb + 2
+                transform(Vb + ((kb + 1) & 1) * WINO_V_FLOATS);
+                load_patch(kb + 2);  // (past the end: out of range, zeros, never used)
+            }
 #pragma unroll
-                for (int i = 0; i < 64; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x322, 2, 0);
+            for (int ks = 0; ks < 2; ++ks) {
+                float av[8];
+                float bv[8][NI];
+#pragma unroll
+                for (int p = 0; p < 8; ++p) {
+                    av[p] = vcur[a_off + (p * KC + ks * 4) * WINO_VS];
+                    read_b(ucur, p, ks, bv[p]);
                 }
+#pragma unroll
+                for (int p = 0; p < 8; ++p)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[p][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p][ni], acc[p][ni], 0, 0, 0);
             }
         }
         if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // (12 = the loads of load_patch)
@@ -294,72 +290,162 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) lstm_wino_kernel(const ConvAr
     kiter(nkb - 1, std::true_type{});
 
     // ---- output transform.  Columns in-lane: c_xi0 = (M_xi0 + M_xi1) + M_xi2, c_xi1 = (M_xi1 - M_xi2) - M_xi3.
-    f32x4 cc[2][2][4];  // [xl][b][ni]
+    f32x4 cc[2][2][NI];  // [xl][b][ni]
 #pragma unroll
     for (int xl = 0; xl < 2; ++xl)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             cc[xl][0][ni] = (acc[xl * 4 + 0][ni] + acc[xl * 4 + 1][ni]) + acc[xl * 4 + 2][ni];
             cc[xl][1][ni] = (acc[xl * 4 + 1][ni] - acc[xl * 4 + 2][ni]) - acc[xl * 4 + 3][ni];
         }
-    // Rows: y_0b = (c_0b + c_1b) + c_2b,  y_1b = c_1b - (c_2b + c_3b).  Wave (rg, 0) holds c_0, c_1 and finishes row parity 0: it needs
-    // c_2 of wave (rg, 1), which holds c_2, c_3, finishes row parity 1 and needs c_1.  One c-row each way through LDS.
+    // Rows: y_0b = (c_0b + c_1b) + c_2b,  y_1b = c_1b - (c_2b + c_3b).  Wave (rg, 0) holds c_0, c_1, wave (rg, 1) c_2, c_3 of the region.
     float* const xb = lds;  // [8 waves][32][64 lanes]; V / U are dead (every wave is past the last barrier)
-    {
-        const int mine = half ? 0 : 1;  // half 0 sends c_1 (its xl = 1), half 1 sends c_2 (its xl = 0)
+    const int ch0 = (EPI == EPI_LSTM) ? nblk * 16 + col : nblk * NI * 16 + col;   // channel of N-tile 0 (LSTM: of every gate)
+    const size_t cHW = (size_t)HW;
+    if constexpr (EPI == EPI_LSTM) {
+        // ROW split: wave (rg, 0) finishes row parity 0 and needs c_2 of its partner, wave (rg, 1) row parity 1 and needs c_1.
+        {
+            const int mine = half ? 0 : 1;  // half 0 sends c_1 (its xl = 1), half 1 sends c_2 (its xl = 0)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) xb[(wv * 32 + (b * 4 + ni) * 4 + r) * 64 + lane] = cc[mine][b][ni][r];
+        }
+        __syncthreads();
+        f32x4 y[2][4];  // [mi = px][ni]: the accumulators of the eight-wave direct kernel (classes (py = half, px))
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
+            for (int ni = 0; ni < 4; ++ni) {
+                f32x4 o;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) xb[(wv * 32 + (b * 4 + ni) * 4 + r) * 64 + lane] = cc[mine][b][ni][r];
-    }
-    __syncthreads();
-    f32x4 y[2][4];  // [mi = px][ni]: the accumulators of the eight-wave direct kernel (classes (py = half, px))
+                for (int r = 0; r < 4; ++r) o[r] = xb[((wv ^ 4) * 32 + (b * 4 + ni) * 4 + r) * 64 + lane];
+                if (half == 0) y[b][ni] = (cc[0][b][ni] + cc[1][b][ni]) + o;
+                else y[b][ni] = o - (cc[0][b][ni] + cc[1][b][ni]);
+            }
+        if (has_up) {  // + the chain of the unpooled source: one fp32 addition, as in the direct kernel
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+            for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
-            f32x4 o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = xb[((wv ^ 4) * 32 + (b * 4 + ni) * 4 + r) * 64 + lane];
-            if (half == 0) y[b][ni] = (cc[0][b][ni] + cc[1][b][ni]) + o;
-            else y[b][ni] = o - (cc[0][b][ni] + cc[1][b][ni]);
+                for (int ni = 0; ni < 4; ++ni) y[mi][ni] = y[mi][ni] + upc[mi][ni];
         }
-    if (has_up) {  // + the chain of the unpooled source: one fp32 addition, as in the direct kernel
+        // gate epilogue: the eight-wave (W8), 16-wide, 16-byte-access path of conv_mfma.h's EPI_LSTM.  Segment sl = row
+        // 4 rg + half + 2 sl of the tile, columns 4 q .. 4 q + 3; element j = register 2 sl + (j >> 1) of sub-tile j & 1.
+        const int ch = ch0;
+        if (ch >= a.Cout) return;
+        const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
+        const size_t cbase = ((size_t)eb * a.Cout + ch) * cHW;
+        const size_t pbase = (size_t)ch * cHW;
+        const size_t pstride = (size_t)a.Cout * cHW;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int sl = 0; sl < 2; ++sl) {
+            const int gy = y0 + 4 * rg + half + 2 * sl, gx = x0 + 4 * q;
+            if (gy >= a.H || gx >= a.W) continue;
+            const int pix = gy * a.W + gx;
+            const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
+            const f32x4 pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
+            const f32x4 pf4 = *reinterpret_cast<const f32x4*>(a.peep + pstride + pbase + pix);
+            const f32x4 po4 = *reinterpret_cast<const f32x4*>(a.peep + 2 * pstride + pbase + pix);
+            f32x4 cn4, hn4;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) y[mi][ni] = y[mi][ni] + upc[mi][ni];
-    }
-
-    // ---- gate epilogue: the eight-wave (W8), 16-wide, 16-byte-access path of conv_mfma.h's EPI_LSTM.  Segment sl = row
-    // 4 rg + half + 2 sl of the tile, columns 4 q .. 4 q + 3; element j = register 2 sl + (j >> 1) of sub-tile j & 1.
-    const int ch = nblk * 16 + col;
-    if (ch >= a.Cout) return;
-    const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
-    const size_t cbase = ((size_t)eb * a.Cout + ch) * HW;
-    const size_t pbase = (size_t)ch * HW;
-    const size_t pstride = (size_t)a.Cout * HW;
-#pragma unroll
-    for (int sl = 0; sl < 2; ++sl) {
-        const int gy = y0 + 4 * rg + half + 2 * sl, gx = x0 + 4 * q;
-        if (gy >= a.H || gx >= a.W) continue;
-        const int pix = gy * a.W + gx;
-        const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
-        const f32x4 pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
-        const f32x4 pf4 = *reinterpret_cast<const f32x4*>(a.peep + pstride + pbase + pix);
-        const f32x4 po4 = *reinterpret_cast<const f32x4*>(a.peep + 2 * pstride + pbase + pix);
-        f32x4 cn4, hn4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float cn, hn;
-            lstm_cell(y[j & 1][0][2 * sl + (j >> 1)], y[j & 1][1][2 * sl + (j >> 1)], y[j & 1][2][2 * sl + (j >> 1)], y[j & 1][3][2 * sl + (j >> 1)],
-                      bi, bf, bc, bo, cold4[j], pi4[j], pf4[j], po4[j], cn, hn);
-            cn4[j] = cn; hn4[j] = hn;
+            for (int j = 0; j < 4; ++j) {
+                float cn, hn;
+                lstm_cell(y[j & 1][0][2 * sl + (j >> 1)], y[j & 1][1][2 * sl + (j >> 1)], y[j & 1][2][2 * sl + (j >> 1)], y[j & 1][3][2 * sl + (j >> 1)],
+                          bi, bf, bc, bo, cold4[j], pi4[j], pf4[j], po4[j], cn, hn);
+                cn4[j] = cn; hn4[j] = hn;
+            }
+            *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
+            *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
         }
-        *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
-        *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
+    } else {
+        // N-TILE split: wave (rg, 0) finishes N-tiles 0, 1, wave (rg, 1) N-tiles 2 (, 3) -- for BOTH row parities, so each wave needs the
+        // partner's two c rows of its own N-tiles: 2 (xl) x 2 (b) x 2 (ni) x 4 floats per lane each way.
+        constexpr int N0 = 2;                      // N-tiles of half 0; half 1 owns NI - 2
+        const int my0 = half ? N0 : 0;             // first own N-tile
+        const int nmine = half ? NI - N0 : N0;     // own N-tiles (1 or 2)
+        {
+            const int their0 = half ? 0 : N0;
+#pragma unroll
+            for (int xl = 0; xl < 2; ++xl)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        // (compile-time register indices: select between the two candidate N-tiles)
+                        const f32x4 v = half ? cc[xl][b][k] : cc[xl][b][(N0 + k < NI) ? N0 + k : NI - 1];
+                        (void)their0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) xb[(wv * 32 + ((xl * 2 + b) * 2 + k) * 4 + r) * 64 + lane] = v[r];
+                    }
+        }
+        __syncthreads();
+        // y[py][px][k] of own N-tile k (register r = window (wy, wx) = (r >> 1, 2 q + (r & 1)))
+        f32x4 y[2][2][2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                f32x4 o0, o1;  // the partner's c rows (its xl = 0, 1) of my N-tile k
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    o0[r] = xb[((wv ^ 4) * 32 + ((0 * 2 + b) * 2 + k) * 4 + r) * 64 + lane];
+                    o1[r] = xb[((wv ^ 4) * 32 + ((1 * 2 + b) * 2 + k) * 4 + r) * 64 + lane];
+                }
+                const f32x4 m0 = half ? cc[0][b][(N0 + k < NI) ? N0 + k : NI - 1] : cc[0][b][k];   // my own rows of N-tile k
+                const f32x4 m1 = half ? cc[1][b][(N0 + k < NI) ? N0 + k : NI - 1] : cc[1][b][k];
+                // half 0 holds c_0, c_1 (partner: c_2, c_3); half 1 holds c_2, c_3 (partner: c_0, c_1)
+                const f32x4 c0 = half ? o0 : m0, c1 = half ? o1 : m1, c2 = half ? m0 : o0, c3 = half ? m1 : o1;
+                y[0][b][k] = (c0 + c1) + c2;
+                y[1][b][k] = c1 - (c2 + c3);
+            }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k >= nmine) continue;
+            const int ch = ch0 + (my0 + k) * 16;
+            if (ch >= a.Cout) continue;
+            const float bb = a.bias[ch];
+            if constexpr (EPI == EPI_CONVP) {
+                // P = relu(y + b): the lane's 4 x 4 pixels (rows 4 rg + 2 wy + py, columns 4 q + 2 (r & 1) + px), one 16-byte store per row
+                const size_t base = ((size_t)eb * a.Cout + ch) * cHW;
+#pragma unroll
+                for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+                    for (int py = 0; py < 2; ++py) {
+                        const int gy = y0 + 4 * rg + 2 * wy + py, gx = x0 + 4 * q;
+                        if (gy >= a.H || gx >= a.W) continue;
+                        f32x4 v4;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v4[j] = relu_f(y[py][j & 1][k][2 * wy + (j >> 1)] + bb);
+                        *reinterpret_cast<f32x4*>(a.Pout + base + gy * a.W + gx) = v4;
+                    }
+            } else {
+                // A = max-pool of relu(y + b) over the tile = over the four classes; E = [relu(A - P), relu(P - A)] at half resolution:
+                // pooled rows (y0 >> 1) + 2 rg + wy, pooled columns (x0 >> 1) + 2 q, + 1 (registers 2 wy, 2 wy + 1): 8-byte accesses
+                const int Ho = a.H >> 1, Wo = a.W >> 1;
+                const size_t plane = (size_t)Ho * Wo;
+                const size_t pb = ((size_t)eb * a.Cout + ch) * plane;
+                const size_t e0 = ((size_t)eb * 2 * a.Cout + ch) * plane, e1 = e0 + (size_t)a.Cout * plane;
+#pragma unroll
+                for (int wy = 0; wy < 2; ++wy) {
+                    const int oy = (y0 >> 1) + 2 * rg + wy, ox = (x0 >> 1) + 2 * q;
+                    if (oy >= Ho || ox >= Wo) continue;
+                    const f32x2 p2 = *reinterpret_cast<const f32x2*>(a.P + pb + oy * Wo + ox);
+                    f32x2 ea, eb2;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int r = 2 * wy + j;
+                        const float v00 = relu_f(y[0][0][k][r] + bb), v01 = relu_f(y[0][1][k][r] + bb), v10 = relu_f(y[1][0][k][r] + bb), v11 = relu_f(y[1][1][k][r] + bb);
+                        const float A = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+                        ea[j] = relu_f(A - p2[j]);
+                        eb2[j] = relu_f(p2[j] - A);
+                    }
+                    *reinterpret_cast<f32x2*>(a.E + e0 + oy * Wo + ox) = ea;
+                    *reinterpret_cast<f32x2*>(a.E + e1 + oy * Wo + ox) = eb2;
+                }
+            }
+        }
     }
 }
 

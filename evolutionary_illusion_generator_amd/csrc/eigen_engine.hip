@@ -58,6 +58,7 @@ struct ConvOp {
     // ConvLSTM with the chain of its unpooled source computed in-kernel (conv_mfma.h: FUSE); the weights live in Layer::d_upw
     bool fused = false;
     int up_C = 0, up_kb = 0;
+    bool wino = false;  // Winograd F(2x2, 3x3) form (conv_wino.h); epi stays the operator's epilogue
 };
 
 struct Layer {
@@ -370,14 +371,23 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
 }
 
 // ---- Winograd F(2x2, 3x3) form of the ConvLSTM's E_l / h_l chain (conv_wino.h; oracle/eig_oracle.c: wino_weights states the same rule)
-static bool wino_eligible(int l, int C, int H, int W) { return l >= 1 && (C % 16) == 0 && (H % 2) == 0 && (W % 4) == 0; }
-// bit l of the mask = layer l may take the Winograd form (if eligible).  Default: every layer -- measured faster at every shape tried,
-// 256^2 / 512^2 / 640x480 / 160x120, colour and gray, incl. 40 x 30 maps that 16 x 16 tiles cover to 78 % (profiles/r04_h_wino_shapes.txt).
-// Eligibility is a property of the layer's shape only, never of the batch: results must not depend on the device batch of a genome.
+// EIGEN_WINOGRAD: bit l = ConvLSTM_l, bit 8 + l = ConvA_l, bit 16 + l = ConvP_l may take the Winograd form (if eligible).  Default: all
+// of them -- measured faster at every shape tried, 256^2 / 512^2 / 640x480 / 160x120, colour and gray, incl. 40 x 30 maps that 16 x 16
+// tiles cover to 78 % (profiles/r04_h_wino_shapes.txt).  Eligibility (the same rule in oracle/eig_oracle.c: eig_wino_op) is a property
+// of the operator's shape only, never of the batch: results must not depend on the device batch a genome lands in.
+//   kind 0 ConvLSTM_l, 1 ConvA_l, 2 ConvP_l; Cin = channels of the full-resolution sources (multiples of 8 each), Cout per gate;
+//   H x W = the resolution the convolution runs at; odd H only for an operator of the TOP layer (nothing is pooled / unpooled from it)
 #ifndef EIGEN_WINO_DEFAULT
-#define EIGEN_WINO_DEFAULT 0xFE
+#define EIGEN_WINO_DEFAULT 0x00FFFFFE
 #endif
-static bool wino_layer(int mask, int l, int C, int H, int W) { return ((mask >> l) & 1) && wino_eligible(l, C, H, W); }
+static bool wino_op(int mask, int kind, int l, int Cin, int Cout, int H, int W, bool top)
+{
+    if (!((mask >> (8 * kind + l)) & 1) || l < 1) return false;
+    if ((Cin % 8) || (Cout % 16) || (W % 4)) return false;
+    if ((H % 2) && !(top && kind != 1)) return false;
+    if (kind != 0 && (Cout % 48) && (Cout % 64)) return false;  // plain convolutions: N-blocks of 48 or 64 columns without padding
+    return true;
+}
 static void wino_weight(const float* g, float* U)  // U = G g G^T: rows first, then columns; fp32, one rounding per operation
 {
     volatile float s[4][3];
@@ -394,24 +404,26 @@ static void wino_weight(const float* g, float* U)  // U = G g G^T: rows first, t
         U[i * 4 + 3] = s[i][2];
     }
 }
-// [n_nblk][K-blocks: 8 channels of one source, sources in order][16 positions][8 channels][16 columns][4 gates]
-static std::vector<float> pack_weights_wino(int C, int n_nblk, int nsrc, const int* src_C, const int* src_Cw, const float* const srcw[3][4])
+// [n_nblk][K-blocks: 8 channels of one source, sources in order][16 positions][8 channels][16 columns][NI N-tiles]
+// lstm: N-tile = gate, output channel = 16 nb + column (srcw[s][gate]); plain convolution: output channel = 16 (NI nb + N-tile) + column (srcw[s][0])
+static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm, int nsrc, const int* src_C, const int* src_Cw, const float* const srcw[3][4])
 {
     int nkb = 0;
     for (int s = 0; s < nsrc; ++s) nkb += src_C[s] / KC;
-    std::vector<float> out((size_t)n_nblk * nkb * WINO_U_FLOATS, 0.0f);
+    const int uf = wino_u_floats(NI);
+    std::vector<float> out((size_t)n_nblk * nkb * uf, 0.0f);
     float U[16];
     for (int nb = 0; nb < n_nblk; ++nb) {
         int kb0 = 0;
         for (int s = 0; s < nsrc; ++s) {
             for (int c = 0; c < src_C[s]; ++c)
-                for (int g = 0; g < 4; ++g)
+                for (int ni = 0; ni < NI; ++ni)
                     for (int n = 0; n < 16; ++n) {
-                        const int o = nb * 16 + n;
+                        const int o = lstm ? nb * 16 + n : (nb * NI + ni) * 16 + n;
                         if (o >= C) continue;
-                        wino_weight(srcw[s][g] + ((size_t)o * src_Cw[s] + c) * 9, U);
-                        float* dst = &out[((size_t)nb * nkb + kb0 + c / KC) * WINO_U_FLOATS];
-                        for (int pos = 0; pos < 16; ++pos) dst[((pos * KC + (c % KC)) * 16 + n) * 4 + g] = U[pos];
+                        wino_weight(srcw[s][lstm ? ni : 0] + ((size_t)o * src_Cw[s] + c) * 9, U);
+                        float* dst = &out[((size_t)nb * nkb + kb0 + c / KC) * uf];
+                        for (int pos = 0; pos < 16; ++pos) dst[((pos * KC + (c % KC)) * 16 + n) * NI + ni] = U[pos];
                     }
             kb0 += src_C[s] / KC;
         }
@@ -534,25 +546,23 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     op.last_grid = grid; op.last_waves = (w8 == 1) ? 8 : 4;
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
-    if (op.epi == EPI_LSTM_WINO) {  // ConvLSTM chain in its Winograd form: 16 x 16-pixel blocks of one image, eight waves (conv_wino.h)
+    if (op.wino) {  // Winograd form (conv_wino.h): 16 x 16-pixel blocks of one image, eight waves, one block per CU
         static const int mode = getenv("EIGEN_WINO_MODE") ? atoi(getenv("EIGEN_WINO_MODE")) : 4;  // conv_wino.h: MODE (A/B; same results)
-        static bool attr_done = false;
-        if (!attr_done) {
-            for (const void* k : {(const void*)lstm_wino_kernel<0>, (const void*)lstm_wino_kernel<1>, (const void*)lstm_wino_kernel<2>, (const void*)lstm_wino_kernel<3>, (const void*)lstm_wino_kernel<4>})
-                (void)hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, WINO_LDS_BYTES);
-            attr_done = true;
-        }
         a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
         const int nt = batch * a.tilesX * a.tilesY;
         const int g = op.n_nblk * ((nt + 7) / 8) * 8;
         op.last_grid = g; op.last_waves = 8;
-        switch (mode) {
-            case 1: hipLaunchKernelGGL(lstm_wino_kernel<1>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
-            case 2: hipLaunchKernelGGL(lstm_wino_kernel<2>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
-            case 3: hipLaunchKernelGGL(lstm_wino_kernel<3>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
-            case 4: hipLaunchKernelGGL(lstm_wino_kernel<4>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
-            default: hipLaunchKernelGGL(lstm_wino_kernel<0>, dim3(g), dim3(WINO_THREADS), WINO_LDS_BYTES, st, a); break;
-        }
+        auto go = [&](auto kern, int ni) {
+            const int lds = wino_lds_bytes(ni);
+            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL(kern, dim3(g), dim3(WINO_THREADS), lds, st, a);
+        };
+        const bool m4 = mode != 0;
+        if (op.epi == EPI_LSTM) { if (m4) go(wino_kernel<4, EPI_LSTM, 4>, 4); else go(wino_kernel<4, EPI_LSTM, 0>, 4); }
+        else if (op.epi == EPI_CONVA && op.NI == 4) { if (m4) go(wino_kernel<4, EPI_CONVA, 4>, 4); else go(wino_kernel<4, EPI_CONVA, 0>, 4); }
+        else if (op.epi == EPI_CONVA) { if (m4) go(wino_kernel<3, EPI_CONVA, 4>, 3); else go(wino_kernel<3, EPI_CONVA, 0>, 3); }
+        else if (op.NI == 4) { if (m4) go(wino_kernel<4, EPI_CONVP, 4>, 4); else go(wino_kernel<4, EPI_CONVP, 0>, 4); }
+        else { if (m4) go(wino_kernel<3, EPI_CONVP, 4>, 3); else go(wino_kernel<3, EPI_CONVP, 0>, 3); }
         r = hipGetLastError();
     } else {
     static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
@@ -769,6 +779,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
     for (int l = 0; l < L; ++l) expect += (l > 0 ? 2 : 0) + 2 + 4 * (l < L - 1 ? 4 : 3) + 3;
     if (n_tensors != expect) return fail(EIGEN_ERR_INVALID, "expected %d weight tensors for %d layers, got %d", expect, L, n_tensors);
     int k = 0;
+    static const int wino_env = getenv("EIGEN_WINOGRAD") && *getenv("EIGEN_WINOGRAD") ? (int)strtol(getenv("EIGEN_WINOGRAD"), nullptr, 0) : EIGEN_WINO_DEFAULT;
     auto upload = [&](float** dst, const float* src, size_t n) -> int {
         if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
         if (hipMalloc((void**)dst, n * sizeof(float)) != hipSuccess) return -1;
@@ -812,6 +823,16 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             t0.macs = (double)op.H * op.W * C * t0.src_C[0] * 9;
             std::vector<float> pk0 = pack_weights(t0, sw, 0);
             if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d, step 0)", l);
+            if (wino_op(wino_env, 1, l, e->layer[l - 1].C, C, op.H, op.W, false)) {  // (the step-0 operator reads C_{l-1} channels: multiples of 8 too)
+                const int ni = (C % 64) ? 3 : 4, nb = C / (16 * ni);
+                const int sc[1] = {2 * e->layer[l - 1].C}, scw[1] = {2 * e->layer[l - 1].C}, sc0[1] = {e->layer[l - 1].C};
+                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, scw, sw);
+                std::vector<float> pw0 = pack_weights_wino(C, ni, nb, false, 1, sc0, scw, sw);
+                if (upload(&op.d_wpk, pw.data(), pw.size()) || upload(&t0.d_wpk, pw0.data(), pw0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d, Winograd form)", l);
+                for (ConvOp* f : {&op, &t0}) { f->wino = true; f->TW = 16; f->NI = ni; f->n_nblk = nb; }
+                op.macs = (double)(op.H / 2) * (op.W / 2) * 16 * C * sc[0];
+                t0.macs = (double)(op.H / 2) * (op.W / 2) * 16 * C * sc0[0];
+            }
         }
         // ---- ConvLSTM_l: 4 gates fused on N.  Chain over E_l, h_l + chain of the unpooled R_{l+1} in its 2x2 form (own launch, Layer::up4)
         {
@@ -861,24 +882,23 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             // execute < 2.5e10 multiply-adds per launch at this engine's device batch (~0.35 ms); EIGEN_FUSEUP=0 / 1 force it.
             // EIGEN_WINOGRAD = bit mask of layers whose chain over E_l / h_l runs in its Winograd F(2x2, 3x3) form (conv_wino.h): 2.25x fewer
             // multiply-adds, ANOTHER canonical summation order (oracle: wino_mask) -- opt-in.  Such a layer keeps the separate 2x2 pass.
-            static const int wino_env = getenv("EIGEN_WINOGRAD") && *getenv("EIGEN_WINOGRAD") ? atoi(getenv("EIGEN_WINOGRAD")) : EIGEN_WINO_DEFAULT;
-            const bool wino = op.epi == EPI_LSTM && wino_layer(wino_env, l, C, y.H, y.W);
+            const bool wino = op.epi == EPI_LSTM && wino_op(wino_env, 0, l, 3 * C, C, y.H, y.W, l == L - 1);
             if (wino) {
                 const int sc[2] = {2 * C, C}, sw[2] = {2 * C, C}, sc0[1] = {C}, sw0[1] = {2 * C};
                 const float* w2[3][4];
                 for (int g = 0; g < 4; ++g) { w2[0][g] = wx0[g]; w2[1][g] = wh[g]; w2[2][g] = nullptr; }
-                std::vector<float> pw = pack_weights_wino(C, op.n_nblk, 2, sc, sw, w2);
-                std::vector<float> pw0 = pack_weights_wino(C, op.n_nblk, 1, sc0, sw0, w2);
+                std::vector<float> pw = pack_weights_wino(C, 4, op.n_nblk, true, 2, sc, sw, w2);
+                std::vector<float> pw0 = pack_weights_wino(C, 4, op.n_nblk, true, 1, sc0, sw0, w2);
                 if (upload(&op.d_wpk, pw.data(), pw.size()) || upload(&t0.d_wpk, pw0.data(), pw0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, Winograd form)", l);
-                op.epi = t0.epi = EPI_LSTM_WINO; op.TW = t0.TW = 16;
-                op.macs = (double)y.H * y.W / 4 * 16 * 4 * C * (3.0 * C);   // executed: 16 multiply-adds per channel and 2x2 outputs
-                t0.macs = (double)y.H * y.W / 4 * 16 * 4 * C * (1.0 * C);
+                op.wino = t0.wino = true; op.TW = t0.TW = 16;
+                op.macs = (double)((y.H + 1) / 2) * ((y.W + 1) / 2) * 16 * 4 * C * (3.0 * C);   // executed: 16 multiply-adds per channel and 2x2 outputs
+                t0.macs = (double)((y.H + 1) / 2) * ((y.W + 1) / 2) * 16 * 4 * C * (1.0 * C);
             }
             static const int fuse_env = getenv("EIGEN_FUSEUP") ? atoi(getenv("EIGEN_FUSEUP")) : -1;
             static const int fuse_mask = getenv("EIGEN_FUSEUP_MASK") ? atoi(getenv("EIGEN_FUSEUP_MASK")) : -1;  // bit l: layer l in-kernel (A/B)
             const double pass_macs = l < L - 1 ? (double)e->B * y.H * y.W * 4 * C * e->layer[l + 1].C * 4 : 0;
             const bool fuse_up = fuse_mask >= 0 ? ((fuse_mask >> l) & 1) != 0 : (fuse_env >= 0 ? fuse_env != 0 : pass_macs < 2.5e10);
-            const bool fused = fuse_up && l < L - 1 && op.epi == EPI_LSTM && op.TW == 16 && (op.W % 8) == 0 && KC == 8;
+            const bool fused = fuse_up && !wino && l < L - 1 && op.epi == EPI_LSTM && op.TW == 16 && (op.W % 8) == 0 && KC == 8;
             if (fused) {
                 const int Cup = e->layer[l + 1].C;
                 std::vector<float> pf = pack_weights_upfuse(C, op.n_nblk, Cup, wx1);
@@ -924,6 +944,14 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             std::vector<float> pk = pack_weights(op, sw, 0);
             if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.biasP, convP_b, C)) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvP%d)", l);
             if (l == 0 && (C == 1 || C == 3) && upload(&op.d_wraw, convP_w, (size_t)C * C * 9)) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvP0 direct)");
+            if (wino_op(wino_env, 2, l, C, C, y.H, y.W, l == L - 1)) {
+                const int ni = (C % 64) ? 3 : 4, nb = C / (16 * ni);
+                const int sc[1] = {C};
+                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, sc, sw);
+                if (upload(&op.d_wpk, pw.data(), pw.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvP%d, Winograd form)", l);
+                op.wino = true; op.TW = 16; op.NI = ni; op.n_nblk = nb;
+                op.macs = (double)((y.H + 1) / 2) * ((y.W + 1) / 2) * 16 * C * C;
+            }
         }
     }
     e->have_weights = true;
@@ -1369,7 +1397,7 @@ int eigen_conv_profile(eigen_engine* e, int32_t enable, int32_t reset, double* h
             if (!op) continue;
             if (h_out && n < max_ops) {
                 double* r = h_out + (size_t)n * 8;
-                r[0] = op->layer; r[1] = op->epi + ((op == &e->layer[l].convA_t0 || op == &e->layer[l].lstm_t0) ? 16 : 0); r[2] = op->NI; r[3] = op->TW; r[4] = op->launches; r[5] = op->ms; r[6] = 2.0 * op->macs; r[7] = op->n_nblk;
+                r[0] = op->layer; r[1] = op->epi + ((op == &e->layer[l].convA_t0 || op == &e->layer[l].lstm_t0) ? 16 : 0) + (op->wino ? 32 : 0); r[2] = op->NI; r[3] = op->TW; r[4] = op->launches; r[5] = op->ms; r[6] = 2.0 * op->macs; r[7] = op->n_nblk;
             }
             if (reset) { op->ms = 0; op->launches = 0; }
             ++n;

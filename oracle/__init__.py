@@ -61,8 +61,9 @@ def lib():
         _LIB = ctypes.CDLL(so)
         _LIB.eig_oracle_gate_order.restype = ctypes.c_int
         _LIB.eig_oracle_get_threads.restype = ctypes.c_int
-        # the C loops run one item per (output channel, row): beyond ~64 threads they only add fork/join cost (GPU boxes: 256 CPUs)
-        set_threads(int(os.environ.get("EIG_ORACLE_THREADS", min(os.cpu_count() or 1, 64))))
+        # the C loops run one item per (output channel, row): beyond ~64 threads they only add fork/join cost, and a container's CPU
+        # quota (the GPU boxes: 256 CPUs visible, 16 usable) is the real bound
+        set_threads(int(os.environ.get("EIG_ORACLE_THREADS", _default_threads())))
         _LIB.eig_oracle_prednet_rollout.restype = ctypes.c_int
         _LIB.eig_oracle_prednet_rollout_order.restype = ctypes.c_int
         _LIB.eig_oracle_lucas_kanade.restype = ctypes.c_int
@@ -72,6 +73,17 @@ def lib():
         for f in ("eig_oracle_farneback", "eig_oracle_fb_vectors", "eig_oracle_fb_levels", "eig_oracle_fb_grid_step"):
             getattr(_LIB, f).restype = ctypes.c_int
     return _LIB
+
+
+def _default_threads():
+    n = min(os.cpu_count() or 1, 64)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return n
 
 
 def set_threads(n):
@@ -102,15 +114,16 @@ def tensor_names(n_layers):
     return names
 
 
-# EIGEN_WINOGRAD unset: every eligible layer (eig_oracle.c: eig_wino_eligible; the engine's default is the same mask)
-WINO_AUTO = 0xFE
+# EIGEN_WINOGRAD unset: every eligible operator -- bit l ConvLSTM_l, bit 8 + l ConvA_l, bit 16 + l ConvP_l (eig_oracle.c: eig_wino_op; the
+# engine's default is the same mask)
+WINO_AUTO = 0x00FFFFFE
 
 
 def wino_mask_default():
     """Which ConvLSTM layers run their E_l / h_l chain as Winograd F(2x2, 3x3): the engine's switch EIGEN_WINOGRAD (bit l = layer
     l), so that checker and library follow the same setting by default."""
     v = os.environ.get("EIGEN_WINOGRAD")
-    return WINO_AUTO if v is None or v == "" else int(v)
+    return WINO_AUTO if v is None or v == "" else int(v, 0)
 
 
 def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=False, return_float=False, order="canonical", wino_mask=None):
@@ -132,7 +145,7 @@ def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=
         ctypes.c_int(L), _p(ch, ctypes.c_int), ctypes.c_int(w), ctypes.c_int(h), tab, _p(img, ctypes.c_uint8),
         ctypes.c_int(n_repeat), ctypes.c_int(n_ext), ctypes.c_int(int(requant)), _p(out, ctypes.c_uint8),
         _p(p0, ctypes.c_float) if return_float else None,
-        ctypes.c_int({"canonical": 0, "chainer": 1}[order] | ((((wino_mask_default() if wino_mask is None else int(wino_mask)) & 0xff) << 8) if order == "canonical" else 0)))
+        ctypes.c_int({"canonical": 0, "chainer": 1}[order] | ((((wino_mask_default() if wino_mask is None else int(wino_mask)) & 0xffffff) << 8) if order == "canonical" else 0)))
     if rc != 0:
         raise ValueError("eig_oracle_prednet_rollout failed (size must be divisible by 2^(L-1))")
     return (out, p0) if return_float else out

@@ -84,8 +84,11 @@ static inline float det_expf(float x)
 #endif
 int eig_oracle_gate_order(void) { return EIG_GATE_ORDER; }
 /* Threads of the OpenMP loops (oracle/__init__.py caps them: one item per (channel, row) does not feed 256 threads well). */
-void eig_oracle_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
-int eig_oracle_get_threads(void) { return omp_get_max_threads(); }
+static int g_threads = 0;  /* 0: the OpenMP default.  A num_threads clause of THIS library's loops only: omp_set_num_threads would also
+                              re-size the pools of every other OpenMP user of the process (torch's CPU convolutions in bench.py's CPU leg) */
+void eig_oracle_set_threads(int n) { g_threads = n > 0 ? n : 0; }
+int eig_oracle_get_threads(void) { return g_threads > 0 ? g_threads : omp_get_max_threads(); }
+#define EIG_NT (g_threads > 0 ? g_threads : omp_get_max_threads())
 static inline float det_tanhf(float x);
 #if EIG_GATE_ORDER
 static inline float det_sigmoidf(float x) { return det_tanhf(x * 0.5f) * 0.5f + 0.5f; }
@@ -149,7 +152,7 @@ typedef struct {
     float* up;   /* chain of the unpooled source scratch */
     float* tmp;  /* ConvA full-resolution scratch */
     int order;   /* 0: the build's canonical arithmetic; 1: the reference's element-wise order (lstm_reference_order) */
-    int wino_mask; /* canonical order only: bit l = ConvLSTM_l runs its E_l / h_l chain as Winograd F(2x2, 3x3) (wino_* below) */
+    int wino_mask; /* canonical order only: which operators run as Winograd F(2x2, 3x3) (eig_wino_op) */
 } prednet_t;
 
 /* Tensor table order shared with the Python wrapper (oracle/__init__.py: tensor_table()). */
@@ -200,7 +203,7 @@ static void conv3x3_chain(float* acc, const float* pad, const float* w, int Cout
     const size_t PP = (size_t)PW * (H + 2);
     /* one work item per (output channel, row): every output pixel is its own chain, so the split changes no bit (a 3-channel
      * layer keeps a many-core host busy too; tests/test_oracle_algorithms.py compares a 1-thread run) */
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(EIG_NT)
     for (int oy = 0; oy < Cout * H; oy++) {
         const int o = oy / H, y = oy - o * H;
         const float* wo = w + (size_t)o * Cin * 9;
@@ -271,7 +274,7 @@ static void conv_up2x2_chain(float* acc, const float* src, const float* w, int C
     float* w4 = (float*)malloc(sizeof(float) * (size_t)Cout * Cin * 16); /* [o][c][class][a][b] */
     for (size_t oc = 0; oc < (size_t)Cout * Cin; oc++)
         for (int cls = 0; cls < 4; cls++) presum_up_weights(w + oc * 9, cls >> 1, cls & 1, w4 + oc * 16 + cls * 4);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(EIG_NT)
     for (int oy = 0; oy < Cout * H; oy++) {
         const int o = oy / H, y = oy - o * H;
         float* ao = acc + (size_t)o * H * W;
@@ -301,7 +304,7 @@ static void conv_up2x2_chain(float* acc, const float* src, const float* w, int C
 }
 
 /* ---- Winograd F(2x2, 3x3) form of a 3x3 'same' convolution, fp32, ONE fixed order of operations (the HIP kernel conv_wino.h runs
- * exactly these; eligibility and switch: see eig_wino_eligible).  Per 2x2 output tile T = (ty, tx), input patch d[4][4] =
+ * exactly these; eligibility and switch: see eig_wino_op).  Per 2x2 output tile T = (ty, tx), input patch d[4][4] =
  * in[c][2ty-1+i][2tx-1+j] (zeros outside the image):
  *   input transform   t_ij = rows:  t0j = d0j - d2j, t1j = d1j + d2j, t2j = d2j - d1j, t3j = d1j - d3j   (B^T d)
  *                     V_ij = cols:  Vi0 = ti0 - ti2, Vi1 = ti1 + ti2, Vi2 = ti2 - ti1, Vi3 = ti1 - ti3   ((B^T d) B)
@@ -329,14 +332,15 @@ static void wino_weights(const float* g /*[3][3]*/, float* U /*[16]*/)
     }
 }
 
-/* M[16][Cout][TH*TW] += chains over the Cin channels of one source (pad: [Cin][H+2][W+2], zero border) */
+/* M[16][Cout][TH*TW] += chains over the Cin channels of one source (pad: [Cin][H+2][W+2], zero border).  Odd H (a top-layer map,
+ * e.g. 20 x 15): TH = (H + 1) / 2 tile rows, the rows below the map read as zeros and the outputs below it are dropped. */
 static void wino_accumulate(float* M, const float* pad, const float* w, int Cout, int Cin, int H, int W)
 {
-    const int TH = H / 2, TW = W / 2, NT = TH * TW, PW = W + 2;
-    const size_t PP = (size_t)PW * (H + 2);
+    const int TH = (H + 1) / 2, TW = W / 2, NT = TH * TW, PW = W + 2, PH = H + 2;
+    const size_t PP = (size_t)PW * PH;
     float* V = (float*)malloc(sizeof(float) * (size_t)Cin * 16 * NT);
     float* U = (float*)malloc(sizeof(float) * (size_t)Cout * Cin * 16);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(EIG_NT)
     for (int c = 0; c < Cin; c++) {
         const float* pc = pad + (size_t)c * PP;
         float* vc = V + (size_t)c * 16 * NT;
@@ -344,7 +348,7 @@ static void wino_accumulate(float* M, const float* pad, const float* w, int Cout
             for (int tx = 0; tx < TW; tx++) {
                 float d[4][4], t[4][4];
                 for (int i = 0; i < 4; i++)
-                    for (int j = 0; j < 4; j++) d[i][j] = pc[(size_t)(2 * ty + i) * PW + 2 * tx + j];  /* pad offset +1 absorbs the -1 */
+                    for (int j = 0; j < 4; j++) d[i][j] = (2 * ty + i < PH) ? pc[(size_t)(2 * ty + i) * PW + 2 * tx + j] : 0.0f;  /* pad offset +1 absorbs the -1 */
                 for (int j = 0; j < 4; j++) {
                     t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
                 }
@@ -358,7 +362,7 @@ static void wino_accumulate(float* M, const float* pad, const float* w, int Cout
             }
     }
     for (size_t oc = 0; oc < (size_t)Cout * Cin; oc++) wino_weights(w + oc * 9, U + oc * 16);
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(EIG_NT)
     for (int op = 0; op < Cout * 16; op++) {
         const int o = op / 16, pos = op - o * 16;
         float* m = M + ((size_t)pos * Cout + o) * NT;
@@ -374,8 +378,8 @@ static void wino_accumulate(float* M, const float* pad, const float* w, int Cout
 /* out[o][2ty+a][2tx+b] = y_ab of the output transform (overwrites out) */
 static void wino_finish(float* out, const float* M, int Cout, int H, int W)
 {
-    const int TH = H / 2, TW = W / 2, NT = TH * TW;
-#pragma omp parallel for schedule(static)
+    const int TH = (H + 1) / 2, TW = W / 2, NT = TH * TW;
+#pragma omp parallel for schedule(static) num_threads(EIG_NT)
     for (int o = 0; o < Cout; o++)
         for (int ty = 0; ty < TH; ty++)
             for (int tx = 0; tx < TW; tx++) {
@@ -389,26 +393,34 @@ static void wino_finish(float* out, const float* M, int Cout, int H, int W)
                 float* po = out + (size_t)o * H * W;
                 for (int b = 0; b < 2; b++) {
                     po[(size_t)(2 * ty) * W + 2 * tx + b] = (c[0][b] + c[1][b]) + c[2][b];
-                    po[(size_t)(2 * ty + 1) * W + 2 * tx + b] = c[1][b] - (c[2][b] + c[3][b]);
+                    if (2 * ty + 1 < H) po[(size_t)(2 * ty + 1) * W + 2 * tx + b] = c[1][b] - (c[2][b] + c[3][b]);
                 }
             }
 }
+static size_t wino_m_floats(int Cout, int H, int W) { return (size_t)16 * Cout * ((H + 1) / 2) * (W / 2); }
 
-/* Which ConvLSTM layers the Winograd form exists for (the HIP engine applies the same rule, eigen_engine.hip: wino_eligible):
- * 16-channel gate groups, even maps, 16-byte rows. */
-static int eig_wino_eligible(int l, int C, int H, int W) { return l >= 1 && (C % 16) == 0 && (H % 2) == 0 && (W % 4) == 0; }
-/* The switch: bit l of wino_mask = layer l may take the Winograd form (if eligible).  Eligibility is a property of the layer's shape
- * only, never of the batch: results must not depend on how a population is split into device batches. */
-static int eig_wino_layer(int wino_mask, int l, int C, int H, int W) { return ((wino_mask >> l) & 1) && eig_wino_eligible(l, C, H, W); }
+/* Which operators take the Winograd form (the HIP engine applies the same rule, eigen_engine.hip: wino_op).  wino_mask: bit l =
+ * ConvLSTM_l, bit 8 + l = ConvA_l, bit 16 + l = ConvP_l.  kind 0 ConvLSTM_l, 1 ConvA_l, 2 ConvP_l; Cin: every full-resolution source
+ * has a multiple of 8 channels; Cout (per gate): 16-channel groups, and for the plain convolutions N-blocks of 48 or 64 columns
+ * without padding; rows of 16-byte chunks; odd H only for an operator of the TOP layer.  A property of the operator's shape only,
+ * never of the batch: results must not depend on how a population is split into device batches. */
+static int eig_wino_op(int wino_mask, int kind, int l, int Cin, int Cout, int H, int W, int top)
+{
+    if (!((wino_mask >> (8 * kind + l)) & 1) || l < 1) return 0;
+    if ((Cin % 8) || (Cout % 16) || (W % 4)) return 0;
+    if ((H % 2) && !(top && kind != 1)) return 0;
+    if (kind != 0 && (Cout % 48) && (Cout % 64)) return 0;
+    return 1;
+}
 
 /* exported for kernel-level tests: out[Cout][H][W] = Winograd chain over the listed full-resolution sources (canonical order) */
 int eig_oracle_wino_chain(int ns, const float* const* src, const int* cin, const float* const* w, int Cout, int H, int W, float* out)
 {
-    if ((H & 1) || (W & 1)) return -1;
+    if (W & 1) return -1;
     size_t maxc = 0;
     for (int s = 0; s < ns; s++) if ((size_t)cin[s] > maxc) maxc = (size_t)cin[s];
     float* pad = (float*)malloc(sizeof(float) * maxc * (H + 2) * (W + 2));
-    float* M = (float*)calloc((size_t)16 * Cout * (H / 2) * (W / 2), sizeof(float));
+    float* M = (float*)calloc(wino_m_floats(Cout, H, W), sizeof(float));
     for (int s = 0; s < ns; s++) {
         const int PW = W + 2;
         memset(pad, 0, sizeof(float) * (size_t)cin[s] * PW * (H + 2));
@@ -537,6 +549,12 @@ static void prednet_step(prednet_t* n, const float* x)
         const int Ho = n->H[l], Wo = n->W[l];
         fill_padded(n->pad, n->E[l - 1], Ci, Hi, Wi, 0);
         memset(n->tmp, 0, sizeof(float) * (size_t)Co * Hi * Wi);
+        if (eig_wino_op(n->wino_mask, 1, l, n->ch[l - 1], Co, Hi, Wi, 0)) {  /* Winograd form: the 2x2 tile is the pooling window */
+            float* M = (float*)calloc(wino_m_floats(Co, Hi, Wi), sizeof(float));
+            wino_accumulate(M, n->pad, n->convA_w[l], Co, Ci, Hi, Wi);
+            wino_finish(n->tmp, M, Co, Hi, Wi);
+            free(M);
+        } else
         conv3x3_chain(n->tmp, n->pad, n->convA_w[l], Co, Ci, Hi, Wi);
         /* A = max_pooling_2d(relu(conv + b), 2, stride=2); E_l = err(A, P_l) */
         float* E = n->E[l];
@@ -565,10 +583,10 @@ static void prednet_step(prednet_t* n, const float* x)
         if (n->order == 1) { lstm_reference_order(n, l); goto predict; }
         memset(n->gate, 0, sizeof(float) * 4 * C * hw);
         /* one chain over the full-resolution sources E_l, h_l (ConvLSTM.__call__: x_*0, h_*) ... */
-        if (eig_wino_layer(n->wino_mask, l, C, H, W)) {  /* ... in its Winograd form: 16 chains per 2x2 tile */
-            float* M = (float*)calloc((size_t)16 * C * (hw / 4), sizeof(float));
+        if (eig_wino_op(n->wino_mask, 0, l, C, C, H, W, l == L - 1)) {  /* ... in its Winograd form: 16 chains per 2x2 tile */
+            float* M = (float*)calloc(wino_m_floats(C, H, W), sizeof(float));
             for (int g = 0; g < 4; g++) {
-                memset(M, 0, sizeof(float) * (size_t)16 * C * (hw / 4));
+                memset(M, 0, sizeof(float) * wino_m_floats(C, H, W));
                 fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
                 wino_accumulate(M, n->pad, n->wx0[l][g], C, 2 * C, H, W);
                 fill_padded(n->pad, n->h[l], C, H, W, 0);
@@ -631,6 +649,12 @@ static void prednet_step(prednet_t* n, const float* x)
         /* P_l = act(ConvP_l(R_l)) */
         fill_padded(n->pad, n->h[l], C, H, W, 0);
         memset(n->gate, 0, sizeof(float) * C * hw);
+        if (eig_wino_op(n->wino_mask, 2, l, C, C, H, W, l == L - 1)) {
+            float* M = (float*)calloc(wino_m_floats(C, H, W), sizeof(float));
+            wino_accumulate(M, n->pad, n->convP_w[l], C, C, H, W);
+            wino_finish(n->gate, M, C, H, W);
+            free(M);
+        } else
         conv3x3_chain(n->gate, n->pad, n->convP_w[l], C, C, H, W);
         for (int o = 0; o < C; o++) {
             const float b = n->convP_b[l][o];
@@ -670,7 +694,7 @@ int eig_oracle_prednet_rollout_order(int L, const int* channels, int W, int H, c
                                      const uint8_t* img, int n_repeat, int n_ext, int requant,
                                      uint8_t* out_frames, float* out_p0, int order)
 {
-    const int wino_mask = (order >> 8) & 0xff;  /* order = base | (wino_mask << 8) */
+    const int wino_mask = (order >> 8) & 0xffffff;  /* order = base | (wino_mask << 8) */
     order &= 0xff;
     if (L < 1 || L > EIG_MAX_LAYERS || order < 0 || order > 1) return -1;
     if ((W % (1 << (L - 1))) || (H % (1 << (L - 1)))) return -1;
