@@ -43,6 +43,8 @@ static_assert(KC == 8, "conv_wino.h: 8-channel K-blocks");
 //   0  every wave transforms K-block k + 1, then multiplies K-block k
 //   4  software pipeline written out: 8 chunks of 8 MFMAs, each with the operand reads of the next chunk and a slice of the staging
 //      work, separated by scheduling fences (a wave fills its own matrix-pipe shadows): +3.6 % on the headline
+//   5, 6, 7  MEASUREMENT ONLY (wrong results): mode 4 without the U DMA after the prologue / without the patch loads / without patch loads
+//      and most V writes -- what the staging traffic costs (profiles/r04_k_wino_bounds.txt)
 //   (tried and dropped: the waves of one half / of one parity multiplying first and transforming afterwards, -3 ... -6 %; the same
 //    interleave dictated with sched_group_barrier, -1.5 %)
 template <int NI, int EPI, int MODE>
@@ -201,9 +203,9 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         const float* const ucur = Ub + (kb & 1) * WINO_U_FLOATS;
         // the U slab of K-block kb + 1 first: every vector-memory instruction issued after it (the 12 patch loads) may still be in
         // flight at the barrier, the DMA may not
-        if constexpr (!LAST) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS);
+        if constexpr (!LAST) { if constexpr (MODE != 5) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); }   // (MODE 5: measurement only)
         else if (has_up) up_loads();
-        if constexpr (MODE == 4 && !LAST) {
+        if constexpr (MODE >= 4 && !LAST) {
             // software pipeline written out: 8 chunks of 2 NI MFMAs (k-step ks = c >> 2, positions 2 pp, 2 pp + 1 with pp = c & 3); each
             // chunk carries the operand reads of the NEXT chunk and a slice of the staging work, fenced so that the slices stay in
             // the matrix-pipe shadow of their chunk: c = 0, 1 the column pass of B^T d, c = 2..5 one row of V each (4 subtractions +
@@ -245,11 +247,12 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                     }
                 } else if (c < 6) {
                     const int i = c - 2;
+                    if constexpr (MODE != 7)
                     vnext[(i * 4 + 0) * KC * WINO_VS] = t[i][0] - t[i][2];
                     vnext[(i * 4 + 1) * KC * WINO_VS] = t[i][1] + t[i][2];
                     vnext[(i * 4 + 2) * KC * WINO_VS] = t[i][2] - t[i][1];
                     vnext[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
-                } else {
+                } else if constexpr (MODE != 6 && MODE != 7) {
 #pragma unroll
                     for (int i = 2 * (c - 6); i < 2 * (c - 6) + 2; ++i) {
                         const unsigned vl = __builtin_elementwise_add_sat((unsigned)off_l[i], coff), vc = __builtin_elementwise_add_sat((unsigned)off_c[i], coff),
@@ -282,7 +285,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                     for (int ni = 0; ni < NI; ++ni) acc[p][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p][ni], acc[p][ni], 0, 0, 0);
             }
         }
-        if constexpr (!LAST) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // (12 = the loads of load_patch)
+        if constexpr (!LAST && MODE != 6 && MODE != 7) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // (12 = the loads of load_patch)
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
     };

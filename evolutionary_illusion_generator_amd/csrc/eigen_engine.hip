@@ -558,7 +558,10 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             hipLaunchKernelGGL(kern, dim3(g), dim3(WINO_THREADS), lds, st, a);
         };
         const bool m4 = mode != 0;
-        if (op.epi == EPI_LSTM) { if (m4) go(wino_kernel<4, EPI_LSTM, 4>, 4); else go(wino_kernel<4, EPI_LSTM, 0>, 4); }
+        if (op.epi == EPI_LSTM && mode == 5) go(wino_kernel<4, EPI_LSTM, 5>, 4);        // (measurement builds of the ConvLSTM kernel: wrong results)
+        else if (op.epi == EPI_LSTM && mode == 6) go(wino_kernel<4, EPI_LSTM, 6>, 4);
+        else if (op.epi == EPI_LSTM && mode == 7) go(wino_kernel<4, EPI_LSTM, 7>, 4);
+        else if (op.epi == EPI_LSTM) { if (m4) go(wino_kernel<4, EPI_LSTM, 4>, 4); else go(wino_kernel<4, EPI_LSTM, 0>, 4); }
         else if (op.epi == EPI_CONVA && op.NI == 4) { if (m4) go(wino_kernel<4, EPI_CONVA, 4>, 4); else go(wino_kernel<4, EPI_CONVA, 0>, 4); }
         else if (op.epi == EPI_CONVA) { if (m4) go(wino_kernel<3, EPI_CONVA, 4>, 3); else go(wino_kernel<3, EPI_CONVA, 0>, 3); }
         else if (op.NI == 4) { if (m4) go(wino_kernel<4, EPI_CONVP, 4>, 4); else go(wino_kernel<4, EPI_CONVP, 0>, 4); }
