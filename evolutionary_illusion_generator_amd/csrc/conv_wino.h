@@ -32,7 +32,8 @@ constexpr int WINO_THREADS = 512;
 constexpr int WINO_VS = 80;                          // floats per (position, channel) row of V: 64 tiles + 16 (k-slots q, q+1 on disjoint banks)
 constexpr int WINO_V_FLOATS = 16 * KC * WINO_VS;     // 10240
 constexpr int wino_u_floats(int NI) { return 16 * KC * 16 * NI; }   // [16 pos][8 ch][16 cols][NI]: 8192 for NI = 4
-constexpr int wino_lds_bytes(int NI) { return 2 * (WINO_V_FLOATS + wino_u_floats(NI)) * 4 + 16; }  // 147472 for NI = 4
+constexpr int WINO_RAW_FLOATS = 18 * 24;               // MODE 8: one channel's haloed rows y0-1 .. y0+16, aligned chunks x0-4 .. x0+19, per WAVE
+constexpr int wino_lds_bytes(int NI, bool raw = false) { return (2 * (WINO_V_FLOATS + wino_u_floats(NI)) + (raw ? 8 * WINO_RAW_FLOATS : 0)) * 4 + (NI == 3 ? 16 : 0); }  // 147456 / 161280 for NI = 4
 static_assert(KC == 8, "conv_wino.h: 8-channel K-blocks");
 
 // NI 16-column N-tiles per block.  EPI_LSTM (NI = 4): N-tile = gate, column = channel 16 nblk + col; the wave pair of a region splits the
@@ -43,6 +44,8 @@ static_assert(KC == 8, "conv_wino.h: 8-channel K-blocks");
 //   0  every wave transforms K-block k + 1, then multiplies K-block k
 //   4  software pipeline written out: 8 chunks of 8 MFMAs, each with the operand reads of the next chunk and a slice of the staging
 //      work, separated by scheduling fences (a wave fills its own matrix-pipe shadows): +3.6 % on the headline
+//   8  (default) mode 4 with the patch rows staged through wave-private LDS planes by LDS-DMA (see dma_raw): +3.3 % again, and every
+//      input element crosses the memory system 1.7 times instead of 4 (profiles/r04_m_wino_raw_staging.txt)
 //   5, 6, 7  MEASUREMENT ONLY (wrong results): mode 4 without the U DMA after the prologue / without the patch loads / without patch loads
 //      and most V writes -- what the staging traffic costs (profiles/r04_k_wino_bounds.txt)
 //   (tried and dropped: the waves of one half / of one parity multiplying first and transforming afterwards, -3 ... -6 %; the same
@@ -122,6 +125,39 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
             d[i][1] = m[0]; d[i][2] = m[1];
         }
     };
+    // MODE 8: the patch rows come through LDS.  Every wave owns a private plane [18][24] behind V and U and fills it by LDS-DMA -- 108 chunks
+    // of 16 B: chunk `lane` and, for lane < 44, chunk 64 + lane -- with the rows of ITS channel of the K-block; its lanes then read their
+    // 4x4 patches from it (12 LDS reads instead of 12 global loads, and every input element crosses the memory system 1.7 times
+    // instead of 4).  Private planes need no barrier: the wave reads the plane (K-block k + 1), then refills it (k + 2).
+    float* const rawp = lds + 2 * (WINO_V_FLOATS + WINO_U_FLOATS) + wv * WINO_RAW_FLOATS;
+    int roff[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int c = lane + 64 * r, row = c / 6, cx = c - row * 6;
+        const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * cx;
+        roff[r] = (c < 108 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : -1;
+    }
+    auto dma_raw = [&](int kb) __attribute__((always_inline)) {
+        const bool s1 = kb >= nkb0;
+        const unsigned long long u = s1 ? sb1 : sb0;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(s1 ? sz1 : sz0), 0x00020000);
+        const unsigned in_range = (unsigned)((kb - nkb) >> 31);
+        const unsigned coff = ((unsigned)(((kb - (s1 ? nkb0 : 0)) * KC + wv) * HW * 4) & in_range) | (0x80000000u & ~in_range);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat((unsigned)roff[0], coff), 0, 0, 0);
+        if (lane < 44)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rawp + 64 * 4), 16, (int)__builtin_elementwise_add_sat((unsigned)roff[1], coff), 0, 0, 0);
+    };
+    const int rd_off = (2 * t_ty) * 24 + 2 * t_tx + 3;   // plane row 0 = image row y0 - 1, plane column 0 = image column x0 - 4
+    auto read_patch = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            d[i][0] = rawp[rd_off + i * 24];
+            const f32x2 m = *reinterpret_cast<const f32x2*>(rawp + rd_off + i * 24 + 1);
+            d[i][1] = m[0]; d[i][2] = m[1];
+            d[i][3] = rawp[rd_off + i * 24 + 3];
+        }
+    };
     // B^T d B of the patch in d -> V[buf][pos][wv][lane]  (oracle/eig_oracle.c: wino_accumulate, same operations in the same order)
     auto transform = [&](float* vbuf) __attribute__((always_inline)) {
         float t[4][4];
@@ -166,10 +202,20 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
     };
 
     // ---- prologue: K-block 0 transformed and staged, the patch of K-block 1 in flight
-    load_patch(0);
-    dma_u(0, Ub);
-    transform(Vb);
-    load_patch(1);
+    if constexpr (MODE == 8) {
+        dma_raw(0);
+        dma_u(0, Ub);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        read_patch();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_raw(1);
+        transform(Vb);
+    } else {
+        load_patch(0);
+        dma_u(0, Ub);
+        transform(Vb);
+        load_patch(1);
+    }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -230,6 +276,11 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(s1 ? sz1 : sz0), 0x00020000);
             const unsigned in_range = (unsigned)((kb2 - nkb) >> 31);
             const unsigned coff = ((unsigned)(((kb2 - (s1 ? nkb0 : 0)) * KC + wv) * HW * 4) & in_range) | (0x80000000u & ~in_range);
+            if constexpr (MODE == 8) {   // the patch of K-block kb + 1 out of this wave's plane, then the plane is refilled for kb + 2
+                read_patch();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                dma_raw(kb + 2);
+            }
             fetch(0, 0);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -252,7 +303,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                     vnext[(i * 4 + 1) * KC * WINO_VS] = t[i][1] + t[i][2];
                     vnext[(i * 4 + 2) * KC * WINO_VS] = t[i][2] - t[i][1];
                     vnext[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
-                } else if constexpr (MODE != 6 && MODE != 7) {
+                } else if constexpr (MODE != 6 && MODE != 7 && MODE != 8) {
 #pragma unroll
                     for (int i = 2 * (c - 6); i < 2 * (c - 6) + 2; ++i) {
                         const unsigned vl = __builtin_elementwise_add_sat((unsigned)off_l[i], coff), vc = __builtin_elementwise_add_sat((unsigned)off_c[i], coff),
@@ -285,7 +336,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                     for (int ni = 0; ni < NI; ++ni) acc[p][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p][ni], acc[p][ni], 0, 0, 0);
             }
         }
-        if constexpr (!LAST && MODE != 6 && MODE != 7) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // (12 = the loads of load_patch)
+        if constexpr (!LAST && MODE != 6 && MODE != 7 && MODE != 8) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // (12 = the loads of load_patch)
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
     };

@@ -547,18 +547,25 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
     if (op.wino) {  // Winograd form (conv_wino.h): 16 x 16-pixel blocks of one image, eight waves, one block per CU
-        static const int mode = getenv("EIGEN_WINO_MODE") ? atoi(getenv("EIGEN_WINO_MODE")) : 4;  // conv_wino.h: MODE (A/B; same results)
+        static const int mode = getenv("EIGEN_WINO_MODE") ? atoi(getenv("EIGEN_WINO_MODE")) : 8;  // conv_wino.h: MODE (A/B; 0, 4, 8: same results; 5-7: measurement only)
         a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
         const int nt = batch * a.tilesX * a.tilesY;
         const int g = op.n_nblk * ((nt + 7) / 8) * 8;
         op.last_grid = g; op.last_waves = 8;
-        auto go = [&](auto kern, int ni) {
-            const int lds = wino_lds_bytes(ni);
+        auto go = [&](auto kern, int ni, bool raw = false) {
+            const int lds = wino_lds_bytes(ni, raw);
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipLaunchKernelGGL(kern, dim3(g), dim3(WINO_THREADS), lds, st, a);
         };
         const bool m4 = mode != 0;
-        if (op.epi == EPI_LSTM && mode == 5) go(wino_kernel<4, EPI_LSTM, 5>, 4);        // (measurement builds of the ConvLSTM kernel: wrong results)
+        if (mode == 8) {
+            if (op.epi == EPI_LSTM) go(wino_kernel<4, EPI_LSTM, 8>, 4, true);
+            else if (op.epi == EPI_CONVA && op.NI == 4) go(wino_kernel<4, EPI_CONVA, 8>, 4, true);
+            else if (op.epi == EPI_CONVA) go(wino_kernel<3, EPI_CONVA, 8>, 3, true);
+            else if (op.NI == 4) go(wino_kernel<4, EPI_CONVP, 8>, 4, true);
+            else go(wino_kernel<3, EPI_CONVP, 8>, 3, true);
+        }
+        else if (op.epi == EPI_LSTM && mode == 5) go(wino_kernel<4, EPI_LSTM, 5>, 4);        // (measurement builds of the ConvLSTM kernel: wrong results)
         else if (op.epi == EPI_LSTM && mode == 6) go(wino_kernel<4, EPI_LSTM, 6>, 4);
         else if (op.epi == EPI_LSTM && mode == 7) go(wino_kernel<4, EPI_LSTM, 7>, 4);
         else if (op.epi == EPI_LSTM) { if (m4) go(wino_kernel<4, EPI_LSTM, 4>, 4); else go(wino_kernel<4, EPI_LSTM, 0>, 4); }
