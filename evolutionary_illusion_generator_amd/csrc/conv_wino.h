@@ -96,9 +96,15 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         off_r[i] = (rok && px0 + 2 < a.W) ? (y * a.W + px0 + 2) * 4 : -1;
     }
     // K-blocks: 8 channels of one source, sources in list order (every source here has a multiple of 8 channels)
+    // ConvLSTM with its unpooled source R_{l+1} INSIDE the chains (a.up_src, MODE 8): K-blocks nkb0 .. nkb0 + nkbu - 1, between E_l and h_l,
+    // are 8 channels of the HALF-resolution map -- oracle/eig_oracle.c: eig_wino_fuse_up
+    const bool up_fused = EPI == EPI_LSTM && MODE == 8 && a.up_src != nullptr;
     const int nkb0 = a.src[0].C >> 3;
-    const int nkb = nkb0 + (a.nsrc > 1 ? (a.src[1].C >> 3) : 0);
+    const int nkbu = up_fused ? (a.up_C >> 3) : 0;
+    const int nkb = nkb0 + nkbu + (a.nsrc > 1 ? (a.src[1].C >> 3) : 0);
     const bool has1 = a.nsrc > 1;
+    const int up_lo = nkb0, up_hi = nkb0 + nkbu;   // K-blocks [up_lo, up_hi) read the unpooled source (empty range: none)
+#define EIG_IS_UP(kb) ((kb) >= up_lo && (kb) < up_hi)
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb * WINO_U_FLOATS), 0, nkb * WINO_U_FLOATS * 4, 0x00020000);
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -137,25 +143,45 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * cx;
         roff[r] = (c < 108 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : -1;
     }
+    // an unpooled-source K-block: plane [10][16] of the half-resolution map, rows Y0 - 1 .. Y0 + 8, aligned chunks X0 - 4 .. X0 + 11 (40 chunks)
+    const int Hh = a.H >> 1, Wh = a.W >> 1, HWh = Hh * Wh;
+    int uoff;
+    {
+        const int row = lane >> 2, cx = lane & 3;
+        const int gy = (y0 >> 1) - 1 + row, gx = (x0 >> 1) - 4 + 4 * cx;
+        uoff = (lane < 40 && gy >= 0 && gy < Hh && gx >= 0 && gx < Wh) ? (gy * Wh + gx) * 4 : -1;
+    }
+    const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
+    const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
     auto dma_raw = [&](int kb) __attribute__((always_inline)) {
-        const bool s1 = kb >= nkb0;
-        const unsigned long long u = s1 ? sb1 : sb0;
+        const bool up = EIG_IS_UP(kb);
+        const bool s1 = kb >= nkb0 + nkbu;
+        // additive selects (a three-way ?: of base pointers becomes a table in scratch memory)
+        const unsigned long long u = sb0 + (s1 ? sb1 - sb0 : 0ull) + (up ? sbu - sb0 : 0ull);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(s1 ? sz1 : sz0), 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(sz0 + (s1 ? sz1 - sz0 : 0) + (up ? szu - sz0 : 0)), 0x00020000);
         const unsigned in_range = (unsigned)((kb - nkb) >> 31);
-        const unsigned coff = ((unsigned)(((kb - (s1 ? nkb0 : 0)) * KC + wv) * HW * 4) & in_range) | (0x80000000u & ~in_range);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat((unsigned)roff[0], coff), 0, 0, 0);
-        if (lane < 44)
+        const int cidx = (kb - (up ? nkb0 : 0) - (s1 ? nkb0 + nkbu : 0)) * KC + wv;
+        const unsigned coff = ((unsigned)(cidx * (up ? HWh : HW) * 4) & in_range) | (0x80000000u & ~in_range);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat((unsigned)(up ? uoff : roff[0]), coff), 0, 0, 0);
+        if (!up && lane < 44)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rawp + 64 * 4), 16, (int)__builtin_elementwise_add_sat((unsigned)roff[1], coff), 0, 0, 0);
     };
     const int rd_off = (2 * t_ty) * 24 + 2 * t_tx + 3;   // plane row 0 = image row y0 - 1, plane column 0 = image column x0 - 4
-    auto read_patch = [&]() __attribute__((always_inline)) {
+    const int rd_off_u = t_ty * 16 + t_tx + 3;           // unpooled source: plane row 0 = source row Y0 - 1, column 0 = source column X0 - 4
+    auto read_patch = [&](int kb) __attribute__((always_inline)) {
+        // full-resolution source: rows i of the 4x4 patch = plane rows 2 ty + i, columns 2 tx + 3 .. + 6.  Unpooled source: the patch of the
+        // x2 nearest-unpooled map around tile (ty, tx) = source pixel (Y0 + ty, X0 + tx) has rows / columns s_-1, s_0, s_0, s_+1 -- 3x3
+        // distinct values at plane rows ty + (0, 1, 1, 2), columns tx + 3 + (0, 1, 1, 2).  One address computation serves both.
+        const bool up = EIG_IS_UP(kb);
+        const int base = up ? rd_off_u : rd_off, rs_ = up ? 16 : 24;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            d[i][0] = rawp[rd_off + i * 24];
-            const f32x2 m = *reinterpret_cast<const f32x2*>(rawp + rd_off + i * 24 + 1);
-            d[i][1] = m[0]; d[i][2] = m[1];
-            d[i][3] = rawp[rd_off + i * 24 + 3];
+            const int ro = base + (up ? ((i + 1) >> 1) : i) * rs_;
+            d[i][0] = rawp[ro];
+            d[i][1] = rawp[ro + 1];
+            d[i][2] = rawp[ro + (up ? 1 : 2)];
+            d[i][3] = rawp[ro + (up ? 2 : 3)];
         }
     };
     // B^T d B of the patch in d -> V[buf][pos][wv][lane]  (oracle/eig_oracle.c: wino_accumulate, same operations in the same order)
@@ -206,7 +232,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         dma_raw(0);
         dma_u(0, Ub);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        read_patch();
+        read_patch(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         dma_raw(1);
         transform(Vb);
@@ -251,6 +277,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         // flight at the barrier, the DMA may not
         if constexpr (!LAST) { if constexpr (MODE != 5) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); }   // (MODE 5: measurement only)
         else if (has_up) up_loads();
+        const bool up_k = EIG_IS_UP(kb);
         if constexpr (MODE >= 4 && !LAST) {
             // software pipeline written out: 8 chunks of 2 NI MFMAs (k-step ks = c >> 2, positions 2 pp, 2 pp + 1 with pp = c & 3); each
             // chunk carries the operand reads of the NEXT chunk and a slice of the staging work, fenced so that the slices stay in
@@ -277,7 +304,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
             const unsigned in_range = (unsigned)((kb2 - nkb) >> 31);
             const unsigned coff = ((unsigned)(((kb2 - (s1 ? nkb0 : 0)) * KC + wv) * HW * 4) & in_range) | (0x80000000u & ~in_range);
             if constexpr (MODE == 8) {   // the patch of K-block kb + 1 out of this wave's plane, then the plane is refilled for kb + 2
-                read_patch();
+                read_patch(kb + 1);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 dma_raw(kb + 2);
             }
@@ -287,10 +314,13 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                 const int pp = c & 3;
                 if (c + 1 < 8) fetch(c + 1, (c + 1) & 1);
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
+                for (int u = 0; u < 2; ++u) {
+                    // an unpooled-source K-block: the positions with xi = 2 (this wave's xl = 0 when half = 1) or nu = 2 are chains of exact zeros
+                    if (up_k && ((((2 * pp + u) & 3) == 2) || (half && pp < 2))) continue;
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[2 * pp + u][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u][ni], acc[2 * pp + u][ni], 0, 0, 0);
+                }
                 if (c < 2) {
 #pragma unroll
                     for (int j = 2 * c; j < 2 * c + 2; ++j) {
@@ -331,9 +361,11 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                     read_b(ucur, p, ks, bv[p]);
                 }
 #pragma unroll
-                for (int p = 0; p < 8; ++p)
+                for (int p = 0; p < 8; ++p) {
+                    if (up_k && (((p & 3) == 2) || (half && p < 4))) continue;   // (zero chains of an unpooled-source K-block)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) acc[p][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p][ni], acc[p][ni], 0, 0, 0);
+                }
             }
         }
         if constexpr (!LAST && MODE != 6 && MODE != 7 && MODE != 8) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // (12 = the loads of load_patch)
@@ -503,4 +535,5 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
     }
 }
 
+#undef EIG_IS_UP
 }  // namespace eig

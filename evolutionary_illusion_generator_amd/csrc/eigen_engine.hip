@@ -378,7 +378,7 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
 //   kind 0 ConvLSTM_l, 1 ConvA_l, 2 ConvP_l; Cin = channels of the full-resolution sources (multiples of 8 each), Cout per gate;
 //   H x W = the resolution the convolution runs at; odd H only for an operator of the TOP layer (nothing is pooled / unpooled from it)
 #ifndef EIGEN_WINO_DEFAULT
-#define EIGEN_WINO_DEFAULT 0x00FFFFFE
+#define EIGEN_WINO_DEFAULT 0x01FFFFFE
 #endif
 static bool wino_op(int mask, int kind, int l, int Cin, int Cout, int H, int W, bool top)
 {
@@ -893,16 +893,29 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             // EIGEN_WINOGRAD = bit mask of layers whose chain over E_l / h_l runs in its Winograd F(2x2, 3x3) form (conv_wino.h): 2.25x fewer
             // multiply-adds, ANOTHER canonical summation order (oracle: wino_mask) -- opt-in.  Such a layer keeps the separate 2x2 pass.
             const bool wino = op.epi == EPI_LSTM && wino_op(wino_env, 0, l, 3 * C, C, y.H, y.W, l == L - 1);
+            bool wino_fuse = false;
             if (wino) {
-                const int sc[2] = {2 * C, C}, sw[2] = {2 * C, C}, sc0[1] = {C}, sw0[1] = {2 * C};
-                const float* w2[3][4];
-                for (int g = 0; g < 4; ++g) { w2[0][g] = wx0[g]; w2[1][g] = wh[g]; w2[2][g] = nullptr; }
-                std::vector<float> pw = pack_weights_wino(C, 4, op.n_nblk, true, 2, sc, sw, w2);
-                std::vector<float> pw0 = pack_weights_wino(C, 4, op.n_nblk, true, 1, sc0, sw0, w2);
+                // the unpooled source R_{l+1} inside the same chains, between E_l and h_l (conv_wino.h: up_fused; oracle/eig_oracle.c: eig_wino_fuse_up):
+                // bit 24 of the switch (EIGEN_WINO_FUSEUP=0 clears it), 16-byte rows at the source resolution, 8-channel K-blocks
+                static const bool fuse_bit = ((wino_env >> 24) & 1) && !(getenv("EIGEN_WINO_FUSEUP") && !atoi(getenv("EIGEN_WINO_FUSEUP")));
+                wino_fuse = fuse_bit && l < L - 1 && (y.W % 8) == 0 && (e->layer[l + 1].C % 8) == 0;
+                static const int wmode = getenv("EIGEN_WINO_MODE") ? atoi(getenv("EIGEN_WINO_MODE")) : 8;
+                if (wino_fuse && wmode != 8)
+                    return fail(EIGEN_ERR_INVALID, "EIGEN_WINO_MODE=%d has no fused unpooled source: set EIGEN_WINO_FUSEUP=0 with it (the oracle reads the same variable)", wmode);
+                const int Cu = wino_fuse ? e->layer[l + 1].C : 0;
+                const float* w3[3][4];
+                for (int g = 0; g < 4; ++g) { w3[0][g] = wx0[g]; w3[1][g] = wino_fuse ? wx1[g] : wh[g]; w3[2][g] = wino_fuse ? wh[g] : nullptr; }
+                const int sc[3] = {2 * C, wino_fuse ? Cu : C, C}, sw[3] = {2 * C, wino_fuse ? Cu : C, C};
+                const int sc0[2] = {C, Cu}, sw0[2] = {2 * C, Cu};
+                std::vector<float> pw = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 3 : 2, sc, sw, w3);
+                std::vector<float> pw0 = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 2 : 1, sc0, sw0, w3);
                 if (upload(&op.d_wpk, pw.data(), pw.size()) || upload(&t0.d_wpk, pw0.data(), pw0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, Winograd form)", l);
                 op.wino = t0.wino = true; op.TW = t0.TW = 16;
-                op.macs = (double)((y.H + 1) / 2) * ((y.W + 1) / 2) * 16 * 4 * C * (3.0 * C);   // executed: 16 multiply-adds per channel and 2x2 outputs
-                t0.macs = (double)((y.H + 1) / 2) * ((y.W + 1) / 2) * 16 * 4 * C * (1.0 * C);
+                const double tiles = (double)((y.H + 1) / 2) * ((y.W + 1) / 2);
+                op.macs = tiles * 16 * 4 * C * (3.0 * C) + tiles * 9 * 4 * C * Cu;   // executed: 16 (unpooled source: 9) multiply-adds per channel and 2x2 outputs
+                t0.macs = tiles * 16 * 4 * C * (1.0 * C) + tiles * 9 * 4 * C * Cu;
+                if (wino_fuse)
+                    for (ConvOp* f : {&op, &t0}) { f->fused = true; f->up_C = Cu; f->up_kb = Cu / KC; }
             }
             static const int fuse_env = getenv("EIGEN_FUSEUP") ? atoi(getenv("EIGEN_FUSEUP")) : -1;
             static const int fuse_mask = getenv("EIGEN_FUSEUP_MASK") ? atoi(getenv("EIGEN_FUSEUP_MASK")) : -1;  // bit l: layer l in-kernel (A/B)
@@ -918,7 +931,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             }
             ConvOp& u = y.up4;
             { float* k0 = u.d_wpk; u = ConvOp(); u.d_wpk = k0; }
-            if (l < L - 1 && !fused) {  // R_{l+1}, at ITS resolution; columns = the ConvLSTM's
+            if (l < L - 1 && !fused && !wino_fuse) {  // R_{l+1}, at ITS resolution; columns = the ConvLSTM's
                 const Layer& yu = e->layer[l + 1];
                 u.epi = EPI_UP4; u.layer = l; u.nsrc = 1; u.src_C[0] = e->layer[l + 1].C; u.H = yu.H; u.W = yu.W; u.Cout = C;
                 u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W, lstm_mode == 1);

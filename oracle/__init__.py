@@ -66,6 +66,7 @@ def lib():
         set_threads(int(os.environ.get("EIG_ORACLE_THREADS", _default_threads())))
         _LIB.eig_oracle_prednet_rollout.restype = ctypes.c_int
         _LIB.eig_oracle_prednet_rollout_order.restype = ctypes.c_int
+        _LIB.eig_oracle_prednet_rollout_wino.restype = ctypes.c_int
         _LIB.eig_oracle_lucas_kanade.restype = ctypes.c_int
         _LIB.eig_oracle_good_features.restype = ctypes.c_int
         _LIB.eig_oracle_conv_chain.restype = ctypes.c_int
@@ -115,15 +116,18 @@ def tensor_names(n_layers):
 
 
 # EIGEN_WINOGRAD unset: every eligible operator -- bit l ConvLSTM_l, bit 8 + l ConvA_l, bit 16 + l ConvP_l (eig_oracle.c: eig_wino_op; the
-# engine's default is the same mask)
-WINO_AUTO = 0x00FFFFFE
+# engine's default is the same mask); bit 24: the unpooled source inside the Winograd ConvLSTM's chains (eig_wino_fuse_up)
+WINO_AUTO = 0x01FFFFFE
 
 
 def wino_mask_default():
     """Which ConvLSTM layers run their E_l / h_l chain as Winograd F(2x2, 3x3): the engine's switch EIGEN_WINOGRAD (bit l = layer
     l), so that checker and library follow the same setting by default."""
     v = os.environ.get("EIGEN_WINOGRAD")
-    return WINO_AUTO if v is None or v == "" else int(v, 0)
+    m = WINO_AUTO if v is None or v == "" else int(v, 0)
+    if os.environ.get("EIGEN_WINO_FUSEUP") == "0":   # (the engine reads the same variable)
+        m &= ~(1 << 24)
+    return m
 
 
 def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=False, return_float=False, order="canonical", wino_mask=None):
@@ -141,11 +145,11 @@ def prednet_rollout(weights, channels, w, h, img, n_repeat=20, n_ext=2, requant=
     T = n_repeat + n_ext
     out = np.zeros((T, channels[0], h, w), dtype=np.uint8)
     p0 = np.zeros((T, channels[0], h, w), dtype=np.float32) if return_float else None
-    rc = lib().eig_oracle_prednet_rollout_order(
+    rc = lib().eig_oracle_prednet_rollout_wino(
         ctypes.c_int(L), _p(ch, ctypes.c_int), ctypes.c_int(w), ctypes.c_int(h), tab, _p(img, ctypes.c_uint8),
         ctypes.c_int(n_repeat), ctypes.c_int(n_ext), ctypes.c_int(int(requant)), _p(out, ctypes.c_uint8),
-        _p(p0, ctypes.c_float) if return_float else None,
-        ctypes.c_int({"canonical": 0, "chainer": 1}[order] | ((((wino_mask_default() if wino_mask is None else int(wino_mask)) & 0xffffff) << 8) if order == "canonical" else 0)))
+        _p(p0, ctypes.c_float) if return_float else None, ctypes.c_int({"canonical": 0, "chainer": 1}[order]),
+        ctypes.c_int((wino_mask_default() if wino_mask is None else int(wino_mask)) if order == "canonical" else 0))
     if rc != 0:
         raise ValueError("eig_oracle_prednet_rollout failed (size must be divisible by 2^(L-1))")
     return (out, p0) if return_float else out

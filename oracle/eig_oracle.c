@@ -334,12 +334,11 @@ static void wino_weights(const float* g /*[3][3]*/, float* U /*[16]*/)
 
 /* M[16][Cout][TH*TW] += chains over the Cin channels of one source (pad: [Cin][H+2][W+2], zero border).  Odd H (a top-layer map,
  * e.g. 20 x 15): TH = (H + 1) / 2 tile rows, the rows below the map read as zeros and the outputs below it are dropped. */
-static void wino_accumulate(float* M, const float* pad, const float* w, int Cout, int Cin, int H, int W)
+static float* wino_input(const float* pad, int Cin, int H, int W)   /* -> V[Cin][16][TH*TW] (malloc'ed): B^T d B of every tile of every channel */
 {
     const int TH = (H + 1) / 2, TW = W / 2, NT = TH * TW, PW = W + 2, PH = H + 2;
     const size_t PP = (size_t)PW * PH;
     float* V = (float*)malloc(sizeof(float) * (size_t)Cin * 16 * NT);
-    float* U = (float*)malloc(sizeof(float) * (size_t)Cout * Cin * 16);
 #pragma omp parallel for schedule(static) num_threads(EIG_NT)
     for (int c = 0; c < Cin; c++) {
         const float* pc = pad + (size_t)c * PP;
@@ -361,6 +360,13 @@ static void wino_accumulate(float* M, const float* pad, const float* w, int Cout
                 }
             }
     }
+    return V;
+}
+/* M[16][Cout][TH*TW]: the sixteen chains continue over the Cin channels whose transformed tiles are in V */
+static void wino_chains(float* M, const float* V, const float* w, int Cout, int Cin, int H, int W)
+{
+    const int NT = ((H + 1) / 2) * (W / 2);
+    float* U = (float*)malloc(sizeof(float) * (size_t)Cout * Cin * 16);
     for (size_t oc = 0; oc < (size_t)Cout * Cin; oc++) wino_weights(w + oc * 9, U + oc * 16);
 #pragma omp parallel for schedule(static) num_threads(EIG_NT)
     for (int op = 0; op < Cout * 16; op++) {
@@ -372,7 +378,13 @@ static void wino_accumulate(float* M, const float* pad, const float* w, int Cout
             for (int T = 0; T < NT; T++) m[T] = fmaf(v[T], u, m[T]);
         }
     }
-    free(V); free(U);
+    free(U);
+}
+static void wino_accumulate(float* M, const float* pad, const float* w, int Cout, int Cin, int H, int W)
+{
+    float* V = wino_input(pad, Cin, H, W);
+    wino_chains(M, V, w, Cout, Cin, H, W);
+    free(V);
 }
 
 /* out[o][2ty+a][2tx+b] = y_ab of the output transform (overwrites out) */
@@ -412,6 +424,14 @@ static int eig_wino_op(int wino_mask, int kind, int l, int Cin, int Cout, int H,
     if (kind != 0 && (Cout % 48) && (Cout % 64)) return 0;
     return 1;
 }
+
+/* Bit 24 of wino_mask: a ConvLSTM in Winograd form takes its unpooled source R_{l+1} INTO the same sixteen chains, between E_l and h_l --
+ * x_g0(E) + x_g1(unpool R) + h_g(h), chainer's own left-to-right order -- as the plain Winograd convolution of the unpooled
+ * (nearest x2) map, instead of adding a separate 2x2-form chain afterwards.  The 4x4 patch of an unpooled map has only 3x3 distinct
+ * values (rows s_-1, s_0, s_0, s_+1), so t_2 = d_2 - d_1 = 0: the positions with xi = 2 or nu = 2 are chains of exact zeros (the HIP
+ * kernel skips them; fma(0, u, M) = M and c + 0 = c exactly) -- 9 multiply-adds per channel and tile instead of the 2x2 form's 16.
+ * Needs 16-byte rows at the source resolution (W % 8 == 0) and a multiple of 8 source channels; same rule in eigen_engine.hip. */
+static int eig_wino_fuse_up(int wino_mask, int l, int L, int W, int Cup) { return ((wino_mask >> 24) & 1) && l < L - 1 && (W % 8) == 0 && (Cup % 8) == 0; }
 
 /* exported for kernel-level tests: out[Cout][H][W] = Winograd chain over the listed full-resolution sources (canonical order) */
 int eig_oracle_wino_chain(int ns, const float* const* src, const int* cin, const float* const* w, int Cout, int H, int W, float* out)
@@ -584,15 +604,24 @@ static void prednet_step(prednet_t* n, const float* x)
         memset(n->gate, 0, sizeof(float) * 4 * C * hw);
         /* one chain over the full-resolution sources E_l, h_l (ConvLSTM.__call__: x_*0, h_*) ... */
         if (eig_wino_op(n->wino_mask, 0, l, C, C, H, W, l == L - 1)) {  /* ... in its Winograd form: 16 chains per 2x2 tile */
-            float* M = (float*)calloc(wino_m_floats(C, H, W), sizeof(float));
-            for (int g = 0; g < 4; g++) {
-                memset(M, 0, sizeof(float) * wino_m_floats(C, H, W));
-                fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
-                wino_accumulate(M, n->pad, n->wx0[l][g], C, 2 * C, H, W);
-                fill_padded(n->pad, n->h[l], C, H, W, 0);
-                wino_accumulate(M, n->pad, n->wh[l][g], C, C, H, W);
-                wino_finish(n->gate + (size_t)g * C * hw, M, C, H, W);
+            const int fuse = l < L - 1 && eig_wino_fuse_up(n->wino_mask, l, L, W, n->ch[l + 1]);
+            float* M = (float*)calloc(4 * wino_m_floats(C, H, W), sizeof(float));   /* the sixteen chains of each of the four gates */
+            float* V;
+            fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
+            V = wino_input(n->pad, 2 * C, H, W);
+            for (int g = 0; g < 4; g++) wino_chains(M + g * wino_m_floats(C, H, W), V, n->wx0[l][g], C, 2 * C, H, W);
+            free(V);
+            if (fuse) {   /* x_g1(unpooling_2d(R_{l+1})) in the same chains */
+                fill_padded(n->pad, n->h[l + 1], n->ch[l + 1], H, W, 1);
+                V = wino_input(n->pad, n->ch[l + 1], H, W);
+                for (int g = 0; g < 4; g++) wino_chains(M + g * wino_m_floats(C, H, W), V, n->wx1[l][g], C, n->ch[l + 1], H, W);
+                free(V);
             }
+            fill_padded(n->pad, n->h[l], C, H, W, 0);
+            V = wino_input(n->pad, C, H, W);
+            for (int g = 0; g < 4; g++) wino_chains(M + g * wino_m_floats(C, H, W), V, n->wh[l][g], C, C, H, W);
+            free(V);
+            for (int g = 0; g < 4; g++) wino_finish(n->gate + (size_t)g * C * hw, M + g * wino_m_floats(C, H, W), C, H, W);
             free(M);
         } else {
         fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
@@ -601,7 +630,7 @@ static void prednet_step(prednet_t* n, const float* x)
         for (int g = 0; g < 4; g++) conv3x3_chain(n->gate + (size_t)g * C * hw, n->pad, n->wh[l][g], C, C, H, W);
         }
         /* ... plus the chain of the unpooled R_{l+1} (x_*1; 2x2 form, see the header): one fp32 addition */
-        if (l < L - 1) { /* h[l+1] already holds R_{l+1} of this step */
+        if (l < L - 1 && !(eig_wino_op(n->wino_mask, 0, l, C, C, H, W, 0) && eig_wino_fuse_up(n->wino_mask, l, L, W, n->ch[l + 1]))) { /* h[l+1] already holds R_{l+1} of this step */
             memset(n->up, 0, sizeof(float) * 4 * C * hw);
             for (int g = 0; g < 4; g++) conv_up2x2_chain(n->up + (size_t)g * C * hw, n->h[l + 1], n->wx1[l][g], C, n->ch[l + 1], H, W);
             for (size_t i = 0; i < 4 * C * hw; i++) n->gate[i] = n->gate[i] + n->up[i];
@@ -689,13 +718,22 @@ int eig_oracle_prednet_rollout(int L, const int* channels, int W, int H, const f
     return eig_oracle_prednet_rollout_order(L, channels, W, H, tensors, img, n_repeat, n_ext, requant, out_frames, out_p0, 0);
 }
 
-/* order: 0 = the build's canonical arithmetic, 1 = the reference's element-wise order (lstm_reference_order); bits 8..15: wino_mask */
+int eig_oracle_prednet_rollout_wino(int L, const int* channels, int W, int H, const float* const* tensors,
+                                    const uint8_t* img, int n_repeat, int n_ext, int requant,
+                                    uint8_t* out_frames, float* out_p0, int order, int wino_mask);
+/* order: 0 = the build's canonical arithmetic with direct convolutions, 1 = the reference's element-wise order (lstm_reference_order) */
 int eig_oracle_prednet_rollout_order(int L, const int* channels, int W, int H, const float* const* tensors,
                                      const uint8_t* img, int n_repeat, int n_ext, int requant,
                                      uint8_t* out_frames, float* out_p0, int order)
 {
-    const int wino_mask = (order >> 8) & 0xffffff;  /* order = base | (wino_mask << 8) */
-    order &= 0xff;
+    return eig_oracle_prednet_rollout_wino(L, channels, W, H, tensors, img, n_repeat, n_ext, requant, out_frames, out_p0, order, 0);
+}
+
+/* wino_mask (canonical order only): which operators run in their Winograd form -- eig_wino_op; bit 24: eig_wino_fuse_up */
+int eig_oracle_prednet_rollout_wino(int L, const int* channels, int W, int H, const float* const* tensors,
+                                    const uint8_t* img, int n_repeat, int n_ext, int requant,
+                                    uint8_t* out_frames, float* out_p0, int order, int wino_mask)
+{
     if (L < 1 || L > EIG_MAX_LAYERS || order < 0 || order > 1) return -1;
     if ((W % (1 << (L - 1))) || (H % (1 << (L - 1)))) return -1;
     prednet_t n;

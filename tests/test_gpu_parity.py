@@ -454,19 +454,20 @@ print("WINO_OK" if ok else "WINO_FAIL")
 """
 
 
-@pytest.mark.parametrize("switch", ["14", None, "0x0E0E00"])
+@pytest.mark.parametrize("switch", ["14", None, "0x0E0E00", "0x0100000E"])
 def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     """The Winograd F(2x2, 3x3) form of the 3x3 convolutions (csrc/conv_wino.h) against the oracle's statement of exactly that arithmetic
     (eig_oracle.c: wino_*; the oracle follows the same environment switch): all frames of four small roll-outs, bit for bit -- incl.
     step-0 operators (one source), ragged tiles, a top layer without an unpooled source, the 20 x 15 top layer of 160 x 120 (odd
     height), N-blocks of 48 and 64 columns.  EIGEN_WINOGRAD=14: the ConvLSTMs of layers 1-3 only; unset: the default = every eligible
-    ConvLSTM / ConvA / ConvP; 0x0E0E00: ConvA and ConvP only."""
+    ConvLSTM / ConvA / ConvP with the unpooled source inside the ConvLSTM's chains; 0x0E0E00: ConvA and ConvP only; 0x0100000E: the ConvLSTMs
+    with their unpooled source fused, everything else direct."""
     import subprocess
     env = dict(os.environ)
     env.pop("EIGEN_WINOGRAD", None)
     if switch is not None:
         env["EIGEN_WINOGRAD"] = switch
-    mask = 0x00FFFFFE if switch is None else int(switch, 0)
+    mask = 0x01FFFFFE if switch is None else int(switch, 0)
     r = subprocess.run([sys.executable, "-c", _WINO_SCRIPT % {"root": ROOT, "mask": mask}], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
     print(r.stdout[-3000:])
