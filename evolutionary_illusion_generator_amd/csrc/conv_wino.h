@@ -44,7 +44,7 @@ static_assert(KC == 8, "conv_wino.h: 8-channel K-blocks");
 //   0  every wave transforms K-block k + 1, then multiplies K-block k
 //   4  software pipeline written out: 8 chunks of 8 MFMAs, each with the operand reads of the next chunk and a slice of the staging
 //      work, separated by scheduling fences (a wave fills its own matrix-pipe shadows): +3.6 % on the headline
-//   8  (default) mode 4 with the patch rows staged through wave-private LDS planes by LDS-DMA (see dma_raw): +3.3 % again, and every
+//   8  (default; also prefetches the ConvLSTM's cell state / peepholes during the last K-block: +0.4 %) mode 4 with the patch rows staged through wave-private LDS planes by LDS-DMA (see dma_raw): +3.3 % again, and every
 //      input element crosses the memory system 1.7 times instead of 4 (profiles/r04_m_wino_raw_staging.txt)
 //   5, 6, 7  MEASUREMENT ONLY (wrong results): mode 4 without the U DMA after the prologue / without the patch loads / without patch loads
 //      and most V writes -- what the staging traffic costs (profiles/r04_k_wino_bounds.txt)
@@ -269,6 +269,24 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                 }
     };
 
+    // ConvLSTM: the cell state and the three peephole values of the lane's two 4-pixel segments -- fetched during the LAST K-block where no
+    // separate unpooled-source chain occupies those registers (otherwise in the epilogue, as the direct kernel does): their latency is
+    // then off the block's critical path (one block per CU: nothing else would cover it)
+    f32x4 st4[2][4];
+    const bool pre_state = EPI == EPI_LSTM && !has_up;
+    auto state_loads = [&]() __attribute__((always_inline)) {
+        const int ch = nblk * 16 + col;
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const int gy = y0 + 4 * rg + half + 2 * sl, gx = x0 + 4 * q;
+            if (ch >= a.Cout || gy >= a.H || gx >= a.W) continue;
+            const size_t pix = (size_t)gy * a.W + gx, cb = ((size_t)eb * a.Cout + ch) * HW + pix, pb = (size_t)ch * HW + pix, ps = (size_t)a.Cout * HW;
+            st4[sl][0] = *reinterpret_cast<const f32x4*>(a.c_state + cb);
+            st4[sl][1] = *reinterpret_cast<const f32x4*>(a.peep + pb);
+            st4[sl][2] = *reinterpret_cast<const f32x4*>(a.peep + ps + pb);
+            st4[sl][3] = *reinterpret_cast<const f32x4*>(a.peep + 2 * ps + pb);
+        }
+    };
     auto kiter = [&](const int kb, auto last_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
         const float* const vcur = Vb + (kb & 1) * WINO_V_FLOATS;
@@ -277,6 +295,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         // flight at the barrier, the DMA may not
         if constexpr (!LAST) { if constexpr (MODE != 5) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); }   // (MODE 5: measurement only)
         else if (has_up) up_loads();
+        else if constexpr (EPI == EPI_LSTM) state_loads();
         const bool up_k = EIG_IS_UP(kb);
         if constexpr (MODE >= 4 && !LAST) {
             // software pipeline written out: 8 chunks of 2 NI MFMAs (k-step ks = c >> 2, positions 2 pp, 2 pp + 1 with pp = c & 3); each
@@ -430,10 +449,14 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
             const int gy = y0 + 4 * rg + half + 2 * sl, gx = x0 + 4 * q;
             if (gy >= a.H || gx >= a.W) continue;
             const int pix = gy * a.W + gx;
-            const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
-            const f32x4 pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
-            const f32x4 pf4 = *reinterpret_cast<const f32x4*>(a.peep + pstride + pbase + pix);
-            const f32x4 po4 = *reinterpret_cast<const f32x4*>(a.peep + 2 * pstride + pbase + pix);
+            f32x4 cold4, pi4, pf4, po4;
+            if (pre_state) { cold4 = st4[sl][0]; pi4 = st4[sl][1]; pf4 = st4[sl][2]; po4 = st4[sl][3]; }
+            else {
+                cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
+                pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
+                pf4 = *reinterpret_cast<const f32x4*>(a.peep + pstride + pbase + pix);
+                po4 = *reinterpret_cast<const f32x4*>(a.peep + 2 * pstride + pbase + pix);
+            }
             f32x4 cn4, hn4;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -554,7 +554,8 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         op.last_grid = g; op.last_waves = 8;
         auto go = [&](auto kern, int ni, bool raw = false) {
             const int lds = wino_lds_bytes(ni, raw);
-            (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            static std::unordered_set<const void*> attr_done;   // (the handle is not thread-safe anyway: one rank, one host thread)
+            if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             hipLaunchKernelGGL(kern, dim3(g), dim3(WINO_THREADS), lds, st, a);
         };
         const bool m4 = mode != 0;
