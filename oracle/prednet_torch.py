@@ -55,7 +55,7 @@ class PredNetTorch:
     def __init__(self, weights, channels, w, h, device="cpu", conv="library", order="stacked"):
         """device: "cpu" (oneDNN) or a cuda device (rocBLAS): two more fp32 summation orders, both independent of the build's
         canonical chain.  conv: "library" = F.conv2d, "matmul" = im2col + matmul (what chainer's CPU Convolution2D does:
-        im2col + tensordot -> BLAS sgemm), "winograd" = F(2x2, 3x3) in fp32 (a study, scripts/winograd_study.py).
+        im2col + tensordot -> BLAS sgemm), "winograd" = F(2x2, 3x3) in fp32 (a study, tests/studies/winograd_study.py).
         order: "stacked" = the sources' convolutions summed, bias, then library sigmoid / tanh (round 1-2 cross-check);
                "chainer" = the element-wise order of the reference's own ConvLSTM, as far as it is knowable without its BLAS
                (see _lstm_chainer)."""

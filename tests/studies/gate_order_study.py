@@ -9,7 +9,7 @@ Both canonical variants are the C oracle (= the HIP path bit for bit, tests/test
   (b) torch-CPU / oneDNN in the chainer element order (oracle/prednet_torch.py)
 on the two frames Lucas-Kanade reads, per genome: flipped bytes, fitness deviation, genomes outside 1e-4.
 
-    python scripts/gate_order_study.py [--shape c2|ref160|headline] [--genomes N] [--out profiles/r04_gate_order_cpu.json]
+    python tests/studies/gate_order_study.py [--shape c2|ref160|headline] [--genomes N] [--out profiles/r04_gate_order_cpu.json]
 """
 import argparse
 import ctypes
@@ -20,7 +20,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 import oracle  # noqa: E402

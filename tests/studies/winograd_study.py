@@ -11,7 +11,7 @@ oracle/classify.py (byte flip rate of the two frames Lucas-Kanade reads, genomes
 Decision rule (VERDICT): build nothing unless W is indistinguishable from the fp32 re-order control AND the control says re-orders
 are benign.
 
-    python scripts/winograd_study.py [--genomes 256] [--out profiles/r04_winograd_study.json]
+    python tests/studies/winograd_study.py [--genomes 256] [--out profiles/r04_winograd_study.json]
 """
 import argparse
 import json
@@ -19,7 +19,7 @@ import os
 import sys
 import time
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 
 import numpy as np
 import torch
