@@ -552,6 +552,8 @@ def main():
                                                        if wino_rows else "conv3x3_mfma<4,16,EPI_LSTM> (fused ConvLSTM gates, v_mfma_f32_16x16x4_f32)"),
                            "winograd_layers": sorted({r["layer"] for r in wino_rows}),
                            "dominant_kernel_tflops_as_direct_convolution": direct_fl / (ms * 1e-3) / 1e12,
+                           # SURVEY 8(d)'s ALGORITHMIC count (9 taps on every source) over the same time: > 1 means multiply-adds avoided, not a faster pipe
+                           "frac_on_algorithmic_flops": direct_fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                            "frac_note": ("`achieved` / `frac` count the multiply-adds the kernel EXECUTES (Winograd: 16 per channel and 2x2 outputs); the same launches "
                                          "as 9-tap convolutions are `dominant_kernel_tflops_as_direct_convolution`, which may exceed the fp32 MFMA peak") if wino_rows else None,
                            "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
