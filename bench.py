@@ -46,12 +46,16 @@ SHAPES = {
     # name: (W, H, channels, c_dim, structure, n_hidden, n_outputs, default global pop, label)
     "headline": (256, 256, [3, 48, 96, 192], 3, 1, 20, 3, 256, "neat_configs/circles.txt colour"),
     "ref160": (160, 120, [3, 48, 96, 192], 3, 1, 20, 3, 50, "neat_configs/circles.txt colour"),
+    # configs[0]: the reference's CPU-runnable plumbing case -- default.txt has num_inputs = 4, num_outputs = 6, num_hidden = 8 (:48-50); leaves
+    # x, y, r, bias and the first output (build-defined: PyTorch-NEAT would assert), Free structure, 64x64 gray
+    "c1": (64, 64, [1, 16, 32, 64], 1, 2, 8, 6, 10, "neat_configs/default.txt gray (4 inputs x, y, r, bias; first of 6 outputs)"),
     "c2": (160, 120, [1, 16, 32, 64], 1, 1, 20, 1, 50, "neat_configs/circles_bw.txt gray"),
     # the reference's other real size: `--size big` = 640x480 (generate_illusion.py:742-746); top-layer maps 80x60
     "ref640": (640, 480, [3, 48, 96, 192], 3, 1, 20, 3, 16, "neat_configs/circles.txt colour, --size big"),
     "c4": (256, 256, [3, 48, 96, 192], 3, 0, 8, 6, 512, "neat_configs/bands.txt colour (first 3 of 6 outputs)"),
     "c5": (512, 512, [3, 48, 96, 192], 3, 2, 20, 6, 1024, "neat_configs/free.txt colour (first 3 of 6 outputs)"),
 }
+SHAPE_INPUTS = {"c1": 4}  # CPPN leaves of a shape's NEAT config (default 2: x, y)
 STRUCT_NAMES = ["Bands", "Circles", "Free", "CirclesFree"]
 SCORE_NAMES = ["horizontal-symmetry", "rotation-symmetry", "swarm", "rotation-symmetry"]
 
@@ -333,7 +337,7 @@ def conv_roofline(eng, fitness_mod, workload, nb):
 def make_workload(shape_name, global_pop):
     from evolutionary_illusion_generator_amd import synth, weights
     W, H, CHANNELS, C_DIM, STRUCTURE, n_hidden, n_outputs, _, _ = SHAPES[shape_name]
-    cfg = synth.make_config(2, n_outputs)
+    cfg = synth.make_config(SHAPE_INPUTS.get(shape_name, 2), n_outputs)
     population = synth.make_population(global_pop, cfg, seed=0, num_hidden=n_hidden)  # identical on every rank (seeded)
     wts = weights.synthetic_prednet_weights(CHANNELS, W, H, seed=0)
     return cfg, population, wts
@@ -380,7 +384,7 @@ def main():
     ap.add_argument("--shape", default="headline", choices=sorted(SHAPES),
                     help="headline: 256x256 colour pop 256 (BASELINE.json metric, configs[2]); ref160: the reference's own default "
                          "160x120 colour, pop 50 (the only published datum: 0.80 evals/s on a Colab GPU, BASELINE.md); "
-                         "c2: configs[1] circles_bw 160x120 gray (channels 1,16,32,64) pop 50; c4: configs[3] bands.txt (8 hidden, "
+                         "c1: configs[0] default.txt 64x64 gray pop 10 (4 CPPN inputs); c2: configs[1] circles_bw 160x120 gray (channels 1,16,32,64) pop 50; ref640: the reference's --size big, 640x480 colour pop 16; c4: configs[3] bands.txt (8 hidden, "
                          "6 outputs) 256x256 colour Bands pop 512; c5: configs[4] free.txt 512x512 colour Free structure pop 1024")
     ap.add_argument("--flow", default="lk", choices=["lk", "farneback"],
                     help="supplementary: 'farneback' swaps the reference's Lucas-Kanade call for the dense Farneback option (no CPU leg)")
@@ -629,7 +633,7 @@ def main():
         sup = {}
         fitness.clear_engines()
         torch.cuda.empty_cache()
-        for name, pop_s, steps_s, key in (("ref160", 50, 10, "ref160 (the reference's own default shape, pop 50)"), ("c2", 50, 20, "configs[1]"),
+        for name, pop_s, steps_s, key in (("ref160", 50, 10, "ref160 (the reference's own default shape, pop 50)"), ("c1", 10, 20, "configs[0] (on the GPU path)"), ("c2", 50, 20, "configs[1]"),
                                           ("ref640", 16, 4, "ref640 (the reference's `--size big`, 640x480 colour, pop 16)"),
                                           ("c4", 512, 2, "configs[3] (single-GPU: two device batches of 256)"), ("c5", 64, 2, "configs[4] (single-GPU sample: one device batch of 64)")):
             try:

@@ -544,4 +544,4 @@ def test_bench_refuses_what_it_cannot_launch():
     assert r.returncode != 0 and "WORLD_SIZE=2" in (r.stdout + r.stderr)
     import bench as B
     assert len(B.kernel_sources_sha()) == 16 and B.kernel_sources_sha() == B.kernel_sources_sha()
-    assert set(B.SHAPES) == {"headline", "ref160", "ref640", "c2", "c4", "c5"} and B.SHAPES["ref640"][:2] == (640, 480) and B.SHAPES["headline"][:2] == (256, 256) and B.SHAPES["headline"][7] == 256
+    assert set(B.SHAPES) == {"headline", "ref160", "ref640", "c1", "c2", "c4", "c5"} and B.SHAPES["ref640"][:2] == (640, 480) and B.SHAPES["headline"][:2] == (256, 256) and B.SHAPES["headline"][7] == 256
