@@ -1,28 +1,31 @@
-// conv_wino.h -- the ConvLSTM's chain over its full-resolution sources (E_l, h_l) as Winograd F(2x2, 3x3) on the fp32 matrix pipe.
+// conv_wino.h -- the 3x3 convolutions of PredNet layers >= 1 (ConvLSTM over E_l / unpooled R_{l+1} / h_l, ConvA, ConvP) as Winograd
+// F(2x2, 3x3) on the fp32 matrix pipe.  DESIGN.md section 3.1d.
 //
 // Why: the direct implicit-GEMM kernel (conv_mfma.h) runs at 0.91 of the fp32 MFMA peak; at fp32 only FEWER multiply-adds make the
 // roll-out faster.  F(2x2, 3x3) needs 16 multiply-adds per channel and 2x2 output pixels instead of 36 (2.25x fewer).  The parity
 // half of the question was answered first (profiles/r04_c_winograd_study.json): the reference's element-wise order with Winograd
-// convolutions is indistinguishable from any other fp32 re-order of it.  OPT-IN (EIGEN_WINOGRAD = bit mask of layers) until it has
-// earned the default; the canonical arithmetic of a layer that takes it is stated in oracle/eig_oracle.c (wino_*), operation by
-// operation, and this kernel executes exactly those operations:
+// convolutions is indistinguishable from any other fp32 re-order of it.  Default for every eligible operator since it measured faster at
+// every shape (EIGEN_WINOGRAD = bit mask, eigen_engine.hip: wino_op); the canonical arithmetic of an operator that takes it is stated
+// in oracle/eig_oracle.c (wino_*), operation by operation, and this kernel executes exactly those operations:
 //   input transform   t = B^T d (rows), V = t B (columns)        -- fp32 additions / subtractions, fixed order
 //   16 chains         M_pos[o][T] = fmaf(V_pos[c][T], U_pos[o][c], .) over (source, channel) ascending -- v_mfma_f32_16x16x4_f32
 //   output transform  c = M A (columns), y = A^T c (rows)        -- fixed order
-// then the unpooled source's 2x2-form chain is added (one fp32 addition) and the gate epilogue runs: lstm_cell of conv_mfma.h.
+// then bias and the operator's epilogue: lstm_cell of conv_mfma.h / relu + 2x2 max-pool + error units / relu.  A ConvLSTM's unpooled
+// source either rides in the same chains (up_fused below: 9 of the 16 positions are non-zero) or, where that does not apply, its
+// 2x2-form chain (an EPI_UP4 launch of conv_mfma.h) is added with one fp32 addition.
 //
-// Block = 16 x 16 output pixels of one image (64 tiles of 2x2 = the 64 pooling windows of the class-major map) x 16 channels x 4
-// gates; 8 waves.  K-block = 8 channels of one source.  Per K-block and block: 512 MFMAs (direct kernel: 1152).
-//   wave w, lane l TRANSFORMS channel w of the K-block for tile l: 12 global loads (the 4x4 patch; rows / columns outside the image
-//     are out of the buffer descriptor's range = zeros), 32 additions, 16 ds_write_b32 into V[pos][channel][tile];
+// Block = 16 x 16 output pixels of one image (64 tiles of 2x2 = the 64 pooling windows of the class-major map) x NI 16-column N-tiles;
+// 8 waves, one block per CU.  K-block = 8 channels of one source.  Per K-block and block: 128 NI MFMAs (direct kernel, NI = 4: 1152).
+//   wave w, lane l TRANSFORMS channel w of the K-block for tile l: the 4x4 patch out of the wave's private LDS plane (MODE 8; filled by
+//     LDS-DMA, rows / chunks outside the image are out of the buffer descriptor's range = zeros), 32 additions, 16 ds_write_b32 into
+//     V[pos][channel][tile];
 //   wave w COMPUTES region rg = w & 3 (tiles 16 rg .. 16 rg + 15 = rows 4 rg .. 4 rg + 3 of the tile) for positions (xi, nu) with
-//     xi in {2 h, 2 h + 1}, h = w >> 2: 8 positions x 4 gates = 32 accumulator tiles; per k-step 8 ds_read_b32 (A) + 8 ds_read_b128
-//     (B: a lane's 4 gates of one channel are contiguous) for 32 MFMAs.
-//   U (32 KB per K-block) travels global -> LDS by LDS-DMA, double-buffered; V is double-buffered too: the transform of K-block k+1
+//     xi in {2 h, 2 h + 1}, h = w >> 2: 8 positions x NI accumulator tiles; per k-step 8 ds_read_b32 (A) + 8 ds_read_b128 (B: a lane's
+//     NI columns of one channel are contiguous) for 8 NI MFMAs.
+//   U (8 NI KB per K-block) travels global -> LDS by LDS-DMA, double-buffered; V is double-buffered too: the transform of K-block k+1
 //     is written while K-block k is being multiplied -- ONE barrier per K-block.
-//   Output transform: columns in-lane; the row transform needs xi = 0..3, so the two waves of a region exchange one c-row each
-//     through LDS (free after the K loop); wave (rg, h) then owns output row parity py = h of its region -- exactly the pixel
-//     ownership of the eight-wave direct kernel (conv_mfma.h: W8), whose epilogue indexing is reused.
+//   Output transform: columns in-lane; the row transform needs xi = 0..3, so the two waves of a region exchange c-rows through LDS
+//     (free after the K loop) -- see the two splits below.
 #pragma once
 #include "conv_mfma.h"
 
