@@ -1,4 +1,6 @@
 """CPU: self-consistency of the C oracle (the stages whose parity is UNPINNED -- no reference fixture exists)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -114,6 +116,39 @@ def test_oracle_threads_do_not_change_a_bit(oracle_lib):
     for o in outs[1:]:
         for (fa, pa), (fb, pb) in zip(outs[0], o):
             assert np.array_equal(fa, fb) and np.array_equal(pa, pb)
+
+
+def test_winograd_statement_is_the_same_convolution(oracle_lib):
+    """oracle/eig_oracle.c: wino_* (the canonical arithmetic of the operators csrc/conv_wino.h takes) IS the 3x3 'same' convolution: against a
+    float64 reference it is as accurate as the direct fma chain (F(2x2, 3x3) in fp32: ~1e-6 relative), on even and on odd heights (a
+    20 x 15 top-layer map), with several chained sources; and a roll-out under any switch setting stays within fp32 round-off of the
+    direct one -- the switch selects a summation order, never a different function."""
+    import torch
+    import torch.nn.functional as F
+    from evolutionary_illusion_generator_amd import weights
+    rng = np.random.default_rng(3)
+    for H, W, cins, cout in ((12, 20, (6, 3), 5), (15, 20, (8,), 16), (2, 4, (1, 2, 3), 2)):
+        srcs = [rng.standard_normal((c, H, W)).astype(np.float32) for c in cins]
+        ws = [rng.standard_normal((cout, c, 3, 3)).astype(np.float32) for c in cins]
+        ref = sum(F.conv2d(torch.from_numpy(s_).double()[None], torch.from_numpy(w_).double(), padding=1)[0] for s_, w_ in zip(srcs, ws)).numpy()
+        wino = oracle_lib.wino_chain(srcs, ws, H, W)
+        direct = oracle_lib.conv_chain(srcs, [0] * len(srcs), ws, H, W)
+        scale = np.abs(ref).max()
+        assert np.abs(wino - ref).max() <= 3e-6 * scale and np.abs(direct - ref).max() <= 3e-6 * scale
+        assert not np.array_equal(wino, direct)   # ... but another order: not the same bits
+    with pytest.raises(ValueError):
+        oracle_lib.wino_chain([np.zeros((1, 4, 5), np.float32)], [np.zeros((1, 1, 3, 3), np.float32)], 4, 5)
+    ch, w, h = [3, 48, 96], 64, 40   # ConvLSTM 1-2, ConvA 2, ConvP 1-2 eligible; layer 1 has W % 8 == 0: its unpooled source can ride in the chains
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=9)
+    img = (rng.random((3, h, w)) * 255).astype(np.uint8)
+    _, p_direct = oracle_lib.prednet_rollout(wts, ch, w, h, img, 4, 1, return_float=True, wino_mask=0)
+    seen = set()
+    for mask in (0x6, 0x0600, 0x060000, 0x00FFFFFE, 0x01FFFFFE):
+        _, p = oracle_lib.prednet_rollout(wts, ch, w, h, img, 4, 1, return_float=True, wino_mask=mask)
+        assert np.abs(p - p_direct).max() <= 2e-6
+        seen.add(p.tobytes())
+    assert len(seen) == 5 and p_direct.tobytes() not in seen   # every setting is its own (documented) order
+    assert oracle_lib.wino_mask_default() == 0x01FFFFFE or "EIGEN_WINOGRAD" in os.environ or os.environ.get("EIGEN_WINO_FUSEUP") == "0"
 
 
 def test_prednet_rejects_sizes_the_pooling_cannot_halve(oracle_lib):
