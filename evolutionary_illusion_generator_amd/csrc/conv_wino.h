@@ -60,6 +60,8 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
     static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
     static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
     constexpr int WINO_U_FLOATS = wino_u_floats(NI);
+    const unsigned long long tw_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_wino.py)
+    unsigned long long tw_wait = 0, tw_work = 0;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const Vb = lds;                              // [2][16][8][WINO_VS]
     float* const Ub = lds + 2 * WINO_V_FLOATS;          // [2][16][8][16][4]
@@ -156,35 +158,44 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
     }
     const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
+    // (wave-uniform branches between the two kinds of K-block: each side keeps immediate offsets and two-way scalar selects)
     auto dma_raw = [&](int kb) __attribute__((always_inline)) {
-        const bool up = EIG_IS_UP(kb);
-        const bool s1 = kb >= nkb0 + nkbu;
-        // additive selects (a three-way ?: of base pointers becomes a table in scratch memory)
-        const unsigned long long u = sb0 + (s1 ? sb1 - sb0 : 0ull) + (up ? sbu - sb0 : 0ull);
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(sz0 + (s1 ? sz1 - sz0 : 0) + (up ? szu - sz0 : 0)), 0x00020000);
         const unsigned in_range = (unsigned)((kb - nkb) >> 31);
-        const int cidx = (kb - (up ? nkb0 : 0) - (s1 ? nkb0 + nkbu : 0)) * KC + wv;
-        const unsigned coff = ((unsigned)(cidx * (up ? HWh : HW) * 4) & in_range) | (0x80000000u & ~in_range);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat((unsigned)(up ? uoff : roff[0]), coff), 0, 0, 0);
-        if (!up && lane < 44)
+        if (EIG_IS_UP(kb)) {
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sbu), hi = __builtin_amdgcn_readfirstlane((unsigned)(sbu >> 32));
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(szu), 0x00020000);
+            const unsigned coff = (unsigned)(((kb - nkb0) * KC + wv) * HWh * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat((unsigned)uoff, coff), 0, 0, 0);
+            return;
+        }
+        const bool s1 = kb >= nkb0 + nkbu;
+        const unsigned long long u = s1 ? sb1 : sb0;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(s1 ? sz1 : sz0), 0x00020000);
+        const unsigned coff = ((unsigned)(((kb - (s1 ? nkb0 + nkbu : 0)) * KC + wv) * HW * 4) & in_range) | (0x80000000u & ~in_range);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat((unsigned)roff[0], coff), 0, 0, 0);
+        if (lane < 44)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rawp + 64 * 4), 16, (int)__builtin_elementwise_add_sat((unsigned)roff[1], coff), 0, 0, 0);
     };
     const int rd_off = (2 * t_ty) * 24 + 2 * t_tx + 3;   // plane row 0 = image row y0 - 1, plane column 0 = image column x0 - 4
     const int rd_off_u = t_ty * 16 + t_tx + 3;           // unpooled source: plane row 0 = source row Y0 - 1, column 0 = source column X0 - 4
     auto read_patch = [&](int kb) __attribute__((always_inline)) {
-        // full-resolution source: rows i of the 4x4 patch = plane rows 2 ty + i, columns 2 tx + 3 .. + 6.  Unpooled source: the patch of the
-        // x2 nearest-unpooled map around tile (ty, tx) = source pixel (Y0 + ty, X0 + tx) has rows / columns s_-1, s_0, s_0, s_+1 -- 3x3
-        // distinct values at plane rows ty + (0, 1, 1, 2), columns tx + 3 + (0, 1, 1, 2).  One address computation serves both.
-        const bool up = EIG_IS_UP(kb);
-        const int base = up ? rd_off_u : rd_off, rs_ = up ? 16 : 24;
+        if (EIG_IS_UP(kb)) {
+            // the 4x4 patch of the x2 nearest-unpooled map around tile (ty, tx) = source pixel (Y0 + ty, X0 + tx): rows / columns
+            // s_-1, s_0, s_0, s_+1 -- 3x3 distinct values at plane rows ty + (0, 1, 1, 2), columns tx + 3 + (0, 1, 1, 2)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ro = base + (up ? ((i + 1) >> 1) : i) * rs_;
-            d[i][0] = rawp[ro];
-            d[i][1] = rawp[ro + 1];
-            d[i][2] = rawp[ro + (up ? 1 : 2)];
-            d[i][3] = rawp[ro + (up ? 2 : 3)];
+            for (int i = 0; i < 4; ++i) {
+                const int ro = rd_off_u + ((i + 1) >> 1) * 16;
+                d[i][0] = rawp[ro]; d[i][1] = rawp[ro + 1]; d[i][2] = rawp[ro + 1]; d[i][3] = rawp[ro + 2];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d[i][0] = rawp[rd_off + i * 24];
+                const f32x2 m = *reinterpret_cast<const f32x2*>(rawp + rd_off + i * 24 + 1);
+                d[i][1] = m[0]; d[i][2] = m[1];
+                d[i][3] = rawp[rd_off + i * 24 + 3];
+            }
         }
     };
     // B^T d B of the patch in d -> V[buf][pos][wv][lane]  (oracle/eig_oracle.c: wino_accumulate, same operations in the same order)
@@ -290,8 +301,14 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
             st4[sl][3] = *reinterpret_cast<const f32x4*>(a.peep + 2 * ps + pb);
         }
     };
+    // An unpooled-source K-block skips its zero chains: positions (p = 4 xl + nu) with nu = 2, and xl = 0 of the upper half (xi = 2) -- one
+    // bit per position in a scalar mask (spelled out as predicates they cost every K-block ~60 scalar instructions; two compile-time
+    // bodies made the register allocator spill 500 VGPRs)
+    const unsigned wave_skip = half ? 0x4Fu : 0x44u;
     auto kiter = [&](const int kb, auto last_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
+        const unsigned skip = EIG_IS_UP(kb) ? wave_skip : 0u;
+        const unsigned long long tk0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
         const float* const vcur = Vb + (kb & 1) * WINO_V_FLOATS;
         const float* const ucur = Ub + (kb & 1) * WINO_U_FLOATS;
         // the U slab of K-block kb + 1 first: every vector-memory instruction issued after it (the 12 patch loads) may still be in
@@ -299,7 +316,6 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         if constexpr (!LAST) { if constexpr (MODE != 5) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); }   // (MODE 5: measurement only)
         else if (has_up) up_loads();
         else if constexpr (EPI == EPI_LSTM) state_loads();
-        const bool up_k = EIG_IS_UP(kb);
         if constexpr (MODE >= 4 && !LAST) {
             // software pipeline written out: 8 chunks of 2 NI MFMAs (k-step ks = c >> 2, positions 2 pp, 2 pp + 1 with pp = c & 3); each
             // chunk carries the operand reads of the NEXT chunk and a slice of the staging work, fenced so that the slices stay in
@@ -338,7 +354,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     // an unpooled-source K-block: the positions with xi = 2 (this wave's xl = 0 when half = 1) or nu = 2 are chains of exact zeros
-                    if (up_k && ((((2 * pp + u) & 3) == 2) || (half && pp < 2))) continue;
+                    if ((skip >> (2 * pp + u)) & 1) continue;
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni)
                         acc[2 * pp + u][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u][ni], acc[2 * pp + u][ni], 0, 0, 0);
@@ -384,18 +400,33 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                 }
 #pragma unroll
                 for (int p = 0; p < 8; ++p) {
-                    if (up_k && (((p & 3) == 2) || (half && p < 4))) continue;   // (zero chains of an unpooled-source K-block)
+                    if ((skip >> p) & 1) continue;   // (zero chains of an unpooled-source K-block)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) acc[p][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p][ni], acc[p][ni], 0, 0, 0);
                 }
             }
         }
+        const unsigned long long tk1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
         if constexpr (!LAST && MODE != 6 && MODE != 7 && MODE != 8) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // (12 = the loads of load_patch)
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
+        if (EIG_TIMING) { const unsigned long long tk2 = __builtin_readcyclecounter(); tw_work += tk1 - tk0; tw_wait += tk2 - tk1; }
     };
+    const unsigned long long tw_loop0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     for (int kb = 0; kb + 1 < nkb; ++kb) kiter(kb, std::false_type{});
     kiter(nkb - 1, std::true_type{});
+    const unsigned long long tw_loop1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
+    // [entry, K loop start, K loop end, exit, HW_ID | XCC_ID << 32, cycles waiting (waitcnt + barrier) in the K loop, cycles working in it, K-blocks]
+    auto timeline = [&]() {
+        if (EIG_TIMING && a.dbg && lane == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* dd = a.dbg + ((size_t)blockIdx.x * 8 + wv) * 8;
+            dd[0] = tw_entry; dd[1] = tw_loop0; dd[2] = tw_loop1; dd[3] = __builtin_readcyclecounter();
+            dd[4] = (unsigned long long)hwid | ((unsigned long long)xcc << 32); dd[5] = tw_wait; dd[6] = tw_work; dd[7] = (unsigned long long)nkb;
+        }
+    };
 
     // ---- output transform.  Columns in-lane: c_xi0 = (M_xi0 + M_xi1) + M_xi2, c_xi1 = (M_xi1 - M_xi2) - M_xi3.
     f32x4 cc[2][2][NI];  // [xl][b][ni]
@@ -442,7 +473,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         // gate epilogue: the eight-wave (W8), 16-wide, 16-byte-access path of conv_mfma.h's EPI_LSTM.  Segment sl = row
         // 4 rg + half + 2 sl of the tile, columns 4 q .. 4 q + 3; element j = register 2 sl + (j >> 1) of sub-tile j & 1.
         const int ch = ch0;
-        if (ch >= a.Cout) return;
+        if (ch >= a.Cout) { timeline(); return; }
         const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
         const size_t cbase = ((size_t)eb * a.Cout + ch) * cHW;
         const size_t pbase = (size_t)ch * cHW;
@@ -559,6 +590,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
             }
         }
     }
+    timeline();
 }
 
 #undef EIG_IS_UP
