@@ -109,6 +109,14 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
     const int nkb = nkb0 + nkbu + (a.nsrc > 1 ? (a.src[1].C >> 3) : 0);
     const bool has1 = a.nsrc > 1;
     const int up_lo = nkb0, up_hi = nkb0 + nkbu;   // K-blocks [up_lo, up_hi) read the unpooled source (empty range: none)
+// s_waitcnt through the builtin (gfx9 encoding: vmcnt [3:0] + [15:14], expcnt [6:4], lgkmcnt [11:8]; 0x0F70 = vmcnt(0), 0xC07F = lgkmcnt(0),
+// 0x0070 = both, 0x007C = vmcnt(12) lgkmcnt(0)): the compiler's own wait-count pass sees it and stops assuming the reads in front of it
+// are still in flight (behind an `asm` wait it added lgkmcnt(0) in front of the first MFMAs of a K-block, i.e. a second and third LDS
+// round trip); the empty asm keeps the memory fence of the old spelling
+#ifndef EIG_WINO_RAWBAR
+#define EIG_WINO_RAWBAR 1
+#endif
+#define EIG_WAITCNT(imm) do { __builtin_amdgcn_s_waitcnt(imm); asm volatile("" ::: "memory"); } while (0)
 #define EIG_IS_UP(kb) ((kb) >= up_lo && (kb) < up_hi)
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb * WINO_U_FLOATS), 0, nkb * WINO_U_FLOATS * 4, 0x00020000);
 
@@ -148,54 +156,52 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * cx;
         roff[r] = (c < 108 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : -1;
     }
-    // an unpooled-source K-block: plane [10][16] of the half-resolution map, rows Y0 - 1 .. Y0 + 8, aligned chunks X0 - 4 .. X0 + 11 (40 chunks)
+    // an unpooled-source K-block: plane [10][24] of the half-resolution map (the same row stride as the full-resolution plane), rows
+    // Y0 - 1 .. Y0 + 8, aligned chunks X0 - 4 .. X0 + 11 in the first four chunks of a row (60 lanes, 40 of them fetch)
     const int Hh = a.H >> 1, Wh = a.W >> 1, HWh = Hh * Wh;
     int uoff;
     {
-        const int row = lane >> 2, cx = lane & 3;
+        const int row = lane / 6, cx = lane - row * 6;
         const int gy = (y0 >> 1) - 1 + row, gx = (x0 >> 1) - 4 + 4 * cx;
-        uoff = (lane < 40 && gy >= 0 && gy < Hh && gx >= 0 && gx < Wh) ? (gy * Wh + gx) * 4 : -1;
+        uoff = (lane < 60 && cx < 4 && gy >= 0 && gy < Hh && gx >= 0 && gx < Wh) ? (gy * Wh + gx) * 4 : -1;
     }
     const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
-    // (wave-uniform branches between the two kinds of K-block: each side keeps immediate offsets and two-way scalar selects)
+    // ONE instruction stream for both kinds of K-block (no branch, no merge copies): descriptor, channel offset and the lanes' chunk
+    // offsets are selects on the wave-uniform kind; an unpooled-source K-block's second instruction fetches nothing (zeros behind its rows)
     auto dma_raw = [&](int kb) __attribute__((always_inline)) {
-        const unsigned in_range = (unsigned)((kb - nkb) >> 31);
-        if (EIG_IS_UP(kb)) {
-            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sbu), hi = __builtin_amdgcn_readfirstlane((unsigned)(sbu >> 32));
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(szu), 0x00020000);
-            const unsigned coff = (unsigned)(((kb - nkb0) * KC + wv) * HWh * 4);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat((unsigned)uoff, coff), 0, 0, 0);
-            return;
-        }
+        const bool up = EIG_IS_UP(kb);
         const bool s1 = kb >= nkb0 + nkbu;
-        const unsigned long long u = s1 ? sb1 : sb0;
+        // (additive selects: a three-way ?: of the base pointers sent the kernel arguments through scratch memory)
+        const unsigned long long mu = 0ull - (unsigned long long)up, m1 = 0ull - (unsigned long long)(s1 && !up);
+        const unsigned long long u = sb0 + ((sb1 - sb0) & m1) + ((sbu - sb0) & mu);
         const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(s1 ? sz1 : sz0), 0x00020000);
-        const unsigned coff = ((unsigned)(((kb - (s1 ? nkb0 + nkbu : 0)) * KC + wv) * HW * 4) & in_range) | (0x80000000u & ~in_range);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat((unsigned)roff[0], coff), 0, 0, 0);
+        const int sz = sz0 + ((sz1 - sz0) & (int)m1) + ((szu - sz0) & (int)mu);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(sz), 0x00020000);
+        const unsigned in_range = (unsigned)((kb - nkb) >> 31);
+        const unsigned chan = (unsigned)((kb - (up ? nkb0 : (s1 ? nkb0 + nkbu : 0))) * KC + wv) * (unsigned)((up ? HWh : HW) * 4);
+        const unsigned coff = (chan & in_range) | (0x80000000u & ~in_range);
+        const unsigned o0 = up ? (unsigned)uoff : (unsigned)roff[0], o1 = up ? 0xFFFFFFFFu : (unsigned)roff[1];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat(o0, coff), 0, 0, 0);
         if (lane < 44)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rawp + 64 * 4), 16, (int)__builtin_elementwise_add_sat((unsigned)roff[1], coff), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rawp + 64 * 4), 16, (int)__builtin_elementwise_add_sat(o1, coff), 0, 0, 0);
     };
-    const int rd_off = (2 * t_ty) * 24 + 2 * t_tx + 3;   // plane row 0 = image row y0 - 1, plane column 0 = image column x0 - 4
-    const int rd_off_u = t_ty * 16 + t_tx + 3;           // unpooled source: plane row 0 = source row Y0 - 1, column 0 = source column X0 - 4
+    // the lane's 4x4 patch out of the plane.  Full resolution: plane row 0 = image row y0 - 1, plane column 0 = image column x0 - 4, the patch
+    // of tile (ty, tx) at rows 2 ty + i, columns 2 tx + 3 + j.  Unpooled source: the patch of the x2 nearest-unpooled map around the tile = source
+    // pixel (Y0 + ty, X0 + tx) has rows / columns s_-1, s_0, s_0, s_+1, i.e. plane rows ty + (0, 1, 1, 2), columns tx + 3 + (0, 1, 1, 2): the
+    // same sixteen reads with the base of rows 2, 3 moved up one row and the base of columns 2, 3 one column to the left.
+    const int rd_off = (2 * t_ty) * 24 + 2 * t_tx + 3;
+    const int rd_off_u = t_ty * 24 + t_tx + 3;
     auto read_patch = [&](int kb) __attribute__((always_inline)) {
-        if (EIG_IS_UP(kb)) {
-            // the 4x4 patch of the x2 nearest-unpooled map around tile (ty, tx) = source pixel (Y0 + ty, X0 + tx): rows / columns
-            // s_-1, s_0, s_0, s_+1 -- 3x3 distinct values at plane rows ty + (0, 1, 1, 2), columns tx + 3 + (0, 1, 1, 2)
+        const bool up = EIG_IS_UP(kb);
+        const float* const p00 = rawp + (up ? rd_off_u : rd_off);
+        const float* const p10 = p00 - (up ? 24 : 0);
+        const int cs = up ? 1 : 0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ro = rd_off_u + ((i + 1) >> 1) * 16;
-                d[i][0] = rawp[ro]; d[i][1] = rawp[ro + 1]; d[i][2] = rawp[ro + 1]; d[i][3] = rawp[ro + 2];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                d[i][0] = rawp[rd_off + i * 24];
-                const f32x2 m = *reinterpret_cast<const f32x2*>(rawp + rd_off + i * 24 + 1);
-                d[i][1] = m[0]; d[i][2] = m[1];
-                d[i][3] = rawp[rd_off + i * 24 + 3];
-            }
+        for (int i = 0; i < 4; ++i) {
+            const float* const pl = (i < 2 ? p00 : p10) + i * 24;
+            const float* const pr = pl - cs;
+            d[i][0] = pl[0]; d[i][1] = pl[1]; d[i][2] = pr[2]; d[i][3] = pr[3];
         }
     };
     // B^T d B of the patch in d -> V[buf][pos][wv][lane]  (oracle/eig_oracle.c: wino_accumulate, same operations in the same order)
@@ -245,9 +251,9 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
     if constexpr (MODE == 8) {
         dma_raw(0);
         dma_u(0, Ub);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        EIG_WAITCNT(0x0F70);
         read_patch(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        EIG_WAITCNT(0xC07F);
         dma_raw(1);
         transform(Vb);
     } else {
@@ -256,7 +262,8 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         transform(Vb);
         load_patch(1);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    EIG_WAITCNT(0x0070);
+    if constexpr (MODE == 8) read_patch(1);   // (MODE 8: a K-block's patch is read out of the plane BEFORE the barrier in front of it, see kiter)
     __syncthreads();
 
     // the chain of the unpooled source (EPI_UP4 launch at half this resolution): loaded during the LAST K-block (ConvLSTM only)
@@ -341,12 +348,14 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(s1 ? sz1 : sz0), 0x00020000);
             const unsigned in_range = (unsigned)((kb2 - nkb) >> 31);
             const unsigned coff = ((unsigned)(((kb2 - (s1 ? nkb0 : 0)) * KC + wv) * HW * 4) & in_range) | (0x80000000u & ~in_range);
-            if constexpr (MODE == 8) {   // the patch of K-block kb + 1 out of this wave's plane, then the plane is refilled for kb + 2
-                read_patch(kb + 1);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            fetch(0, 0);
+            if constexpr (MODE == 8) {
+                // the patch of K-block kb + 1 was read out of this wave's plane before the barrier (end of the previous K-block: the plane
+                // is private and its DMA had landed), so that ONE LDS round trip -- shared with the first operands -- stands between the
+                // barrier and the first MFMA; then the plane is refilled for kb + 2
+                EIG_WAITCNT(0xC07F);
                 dma_raw(kb + 2);
             }
-            fetch(0, 0);
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
                 const int pp = c & 3;
@@ -407,9 +416,16 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
             }
         }
         const unsigned long long tk1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
-        if constexpr (!LAST && MODE != 6 && MODE != 7 && MODE != 8) asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");   // (12 = the loads of load_patch)
-        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if constexpr (!LAST && MODE != 6 && MODE != 7 && MODE != 8) EIG_WAITCNT(0x007C);   // (12 = the loads of load_patch)
+        else EIG_WAITCNT(0x0070);
+        if constexpr (MODE == 8 && !LAST) read_patch(kb + 2);   // (past the end: the plane holds zeros, never used)
+#if EIG_WINO_RAWBAR
+        // the bare barrier: every LDS write and DMA of this wave has landed (the wait above); __syncthreads() would add a release fence =
+        // lgkmcnt(0), i.e. wait for the patch reads just issued, which are private to the wave and may stay in flight across the barrier
+        asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+#else
         __syncthreads();
+#endif
         if (EIG_TIMING) { const unsigned long long tk2 = __builtin_readcyclecounter(); tw_work += tk1 - tk0; tw_wait += tk2 - tk1; }
     };
     const unsigned long long tw_loop0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
@@ -594,4 +610,5 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
 }
 
 #undef EIG_IS_UP
+#undef EIG_WAITCNT
 }  // namespace eig
