@@ -113,6 +113,12 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
 // 0x0070 = both, 0x007C = vmcnt(12) lgkmcnt(0)): the compiler's own wait-count pass sees it and stops assuming the reads in front of it
 // are still in flight (behind an `asm` wait it added lgkmcnt(0) in front of the first MFMAs of a K-block, i.e. a second and third LDS
 // round trip); the empty asm keeps the memory fence of the old spelling
+// measurement builds only (wrong results): -DEIG_WINO_DIAG=mask leaves parts of a K-block out -- 1 the U DMA, 2 the plane DMA, 4 the transform's LDS
+// writes (a sink keeps the values alive), 8 the barrier, 16 the additions of the transform, 32 the wait for the DMAs in front of the barrier, 64 the
+// patch reads (opaque register definitions instead)
+#ifndef EIG_WINO_DIAG
+#define EIG_WINO_DIAG 0
+#endif
 #ifndef EIG_WINO_RAWBAR
 #define EIG_WINO_RAWBAR 1
 #endif
@@ -169,7 +175,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
     // ONE instruction stream for both kinds of K-block (no branch, no merge copies): descriptor, channel offset and the lanes' chunk
     // offsets are selects on the wave-uniform kind; an unpooled-source K-block's second instruction fetches nothing (zeros behind its rows)
-    auto dma_raw = [&](int kb) __attribute__((always_inline)) {
+    auto dma_raw = [&](int kb, float* plane) __attribute__((always_inline)) {
         const bool up = EIG_IS_UP(kb);
         const bool s1 = kb >= nkb0 + nkbu;
         // (additive selects: a three-way ?: of the base pointers sent the kernel arguments through scratch memory)
@@ -182,9 +188,9 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         const unsigned chan = (unsigned)((kb - (up ? nkb0 : (s1 ? nkb0 + nkbu : 0))) * KC + wv) * (unsigned)((up ? HWh : HW) * 4);
         const unsigned coff = (chan & in_range) | (0x80000000u & ~in_range);
         const unsigned o0 = up ? (unsigned)uoff : (unsigned)roff[0], o1 = up ? 0xFFFFFFFFu : (unsigned)roff[1];
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat(o0, coff), 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)plane, 16, (int)__builtin_elementwise_add_sat(o0, coff), 0, 0, 0);
         if (lane < 44)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rawp + 64 * 4), 16, (int)__builtin_elementwise_add_sat(o1, coff), 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(plane + 64 * 4), 16, (int)__builtin_elementwise_add_sat(o1, coff), 0, 0, 0);
     };
     // the lane's 4x4 patch out of the plane.  Full resolution: plane row 0 = image row y0 - 1, plane column 0 = image column x0 - 4, the patch
     // of tile (ty, tx) at rows 2 ty + i, columns 2 tx + 3 + j.  Unpooled source: the patch of the x2 nearest-unpooled map around the tile = source
@@ -192,9 +198,16 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
     // same sixteen reads with the base of rows 2, 3 moved up one row and the base of columns 2, 3 one column to the left.
     const int rd_off = (2 * t_ty) * 24 + 2 * t_tx + 3;
     const int rd_off_u = t_ty * 24 + t_tx + 3;
-    auto read_patch = [&](int kb) __attribute__((always_inline)) {
+    auto read_patch = [&](int kb, const float* plane) __attribute__((always_inline)) {
+        if constexpr (EIG_WINO_DIAG & 64) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) asm volatile("" : "=v"(d[i][j]));
+            return;
+        }
         const bool up = EIG_IS_UP(kb);
-        const float* const p00 = rawp + (up ? rd_off_u : rd_off);
+        const float* const p00 = plane + (up ? rd_off_u : rd_off);
         const float* const p10 = p00 - (up ? 24 : 0);
         const int cs = up ? 1 : 0;
 #pragma unroll
@@ -249,12 +262,12 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
 
     // ---- prologue: K-block 0 transformed and staged, the patch of K-block 1 in flight
     if constexpr (MODE == 8) {
-        dma_raw(0);
+        dma_raw(0, rawp);
         dma_u(0, Ub);
         EIG_WAITCNT(0x0F70);
-        read_patch(0);
+        read_patch(0, rawp);
         EIG_WAITCNT(0xC07F);
-        dma_raw(1);
+        dma_raw(1, rawp);
         transform(Vb);
     } else {
         load_patch(0);
@@ -263,7 +276,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         load_patch(1);
     }
     EIG_WAITCNT(0x0070);
-    if constexpr (MODE == 8) read_patch(1);   // (MODE 8: a K-block's patch is read out of the plane BEFORE the barrier in front of it, see kiter)
+    if constexpr (MODE == 8) read_patch(1, rawp);   // (MODE 8: a K-block's patch is read out of the plane BEFORE the barrier in front of it, see kiter)
     __syncthreads();
 
     // the chain of the unpooled source (EPI_UP4 launch at half this resolution): loaded during the LAST K-block (ConvLSTM only)
@@ -320,7 +333,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         const float* const ucur = Ub + (kb & 1) * WINO_U_FLOATS;
         // the U slab of K-block kb + 1 first: every vector-memory instruction issued after it (the 12 patch loads) may still be in
         // flight at the barrier, the DMA may not
-        if constexpr (!LAST) { if constexpr (MODE != 5) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); }   // (MODE 5: measurement only)
+        if constexpr (!LAST) { if constexpr (MODE != 5 && !(EIG_WINO_DIAG & 1)) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); }   // (MODE 5: measurement only)
         else if (has_up) up_loads();
         else if constexpr (EPI == EPI_LSTM) state_loads();
         if constexpr (MODE >= 4 && !LAST) {
@@ -354,7 +367,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                 // is private and its DMA had landed), so that ONE LDS round trip -- shared with the first operands -- stands between the
                 // barrier and the first MFMA; then the plane is refilled for kb + 2
                 EIG_WAITCNT(0xC07F);
-                dma_raw(kb + 2);
+                if constexpr (!(EIG_WINO_DIAG & 2)) dma_raw(kb + 2, rawp);
             }
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
@@ -371,15 +384,18 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
                 if (c < 2) {
 #pragma unroll
                     for (int j = 2 * c; j < 2 * c + 2; ++j) {
+                        if constexpr (EIG_WINO_DIAG & 16) { t[0][j] = d[0][j]; t[1][j] = d[1][j]; t[2][j] = d[2][j]; t[3][j] = d[3][j]; continue; }
                         t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
                     }
                 } else if (c < 6) {
                     const int i = c - 2;
-                    if constexpr (MODE != 7)
-                    vnext[(i * 4 + 0) * KC * WINO_VS] = t[i][0] - t[i][2];
-                    vnext[(i * 4 + 1) * KC * WINO_VS] = t[i][1] + t[i][2];
-                    vnext[(i * 4 + 2) * KC * WINO_VS] = t[i][2] - t[i][1];
-                    vnext[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
+                    float v4[4] = {t[i][0] - t[i][2], t[i][1] + t[i][2], t[i][2] - t[i][1], t[i][1] - t[i][3]};
+                    if constexpr (EIG_WINO_DIAG & 16) { v4[0] = t[i][0]; v4[1] = t[i][1]; v4[2] = t[i][2]; v4[3] = t[i][3]; }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (EIG_WINO_DIAG & 4) asm volatile("" :: "v"(v4[j]));   // (a sink: the value stays alive, no LDS write)
+                        else if (MODE != 7 || j > 0) vnext[(i * 4 + j) * KC * WINO_VS] = v4[j];
+                    }
                 } else if constexpr (MODE != 6 && MODE != 7 && MODE != 8) {
 #pragma unroll
                     for (int i = 2 * (c - 6); i < 2 * (c - 6) + 2; ++i) {
@@ -417,9 +433,11 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
         }
         const unsigned long long tk1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
         if constexpr (!LAST && MODE != 6 && MODE != 7 && MODE != 8) EIG_WAITCNT(0x007C);   // (12 = the loads of load_patch)
+        else if constexpr (EIG_WINO_DIAG & 32) EIG_WAITCNT(0xC07F);
         else EIG_WAITCNT(0x0070);
-        if constexpr (MODE == 8 && !LAST) read_patch(kb + 2);   // (past the end: the plane holds zeros, never used)
-#if EIG_WINO_RAWBAR
+        if constexpr (MODE == 8 && !LAST) read_patch(kb + 2, rawp);   // (past the end: the plane holds zeros, never used)
+#if EIG_WINO_DIAG & 8
+#elif EIG_WINO_RAWBAR
         // the bare barrier: every LDS write and DMA of this wave has landed (the wait above); __syncthreads() would add a release fence =
         // lgkmcnt(0), i.e. wait for the patch reads just issued, which are private to the wave and may stay in flight across the barrier
         asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
