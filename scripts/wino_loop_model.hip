@@ -6,6 +6,8 @@
 //            8 the transform's 32 additions          16 the 8 patch reads (ds_read2_b32) in front of the barrier
 //            32 six LDS-DMA instructions per K-block (U slab 4, plane 2) + vmcnt(0) in front of the barrier
 //            256 / 512 the staging slice of a chunk in front of / between its MFMA groups (default: behind them)
+//            1024 instead of s_barrier: two LDS counters -- `written` signalled behind chunk 5, waited for at the top of the next K-block; `read`
+//                 signalled at the end of a K-block, waited for in front of chunk 2 of the next (U DMA moved there)
 //            64 operand reads TWO chunks ahead       128 A operands as one ds_read_b64 per chunk (pair-contiguous layout) instead of ds_read2st64_b32
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -23,7 +25,22 @@ __global__ void __launch_bounds__(512, 1) k(float* out, const float* __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int rg = wv & 3, half = wv >> 2, q = lane >> 4, col = lane & 15;
     float* const rawp = lds + 2 * (V_FLOATS + U_FLOATS) + wv * RAW;
-    for (int i = tid; i < 2 * (V_FLOATS + U_FLOATS) + 8 * RAW; i += 512) lds[i] = (float)(i & 7) * 0.125f;
+    // bit 1024: the barrier split into two LDS counters (written / read), signalled early and waited for late -- see main()
+    unsigned* const cnt = reinterpret_cast<unsigned*>(lds + 2 * (V_FLOATS + U_FLOATS) + 8 * RAW);   // [0] K-blocks written, [1] K-blocks read (x 8 waves)
+    auto signal = [&](int which) __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(cnt + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        asm volatile("" ::: "memory");
+    };
+    auto wait_for = [&](int which, unsigned target) __attribute__((always_inline)) {
+        asm volatile("" ::: "memory");
+        for (int spin = 0; spin < (1 << 16); ++spin) {   // (bounded: a wrong protocol ends with wrong numbers, not with a hung GPU)
+            const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt + which, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            if (v >= target) break;
+        }
+        asm volatile("" ::: "memory");
+    };
+    for (int i = tid; i < 2 * (V_FLOATS + U_FLOATS) + 8 * RAW + 2; i += 512) lds[i] = i >= 2 * (V_FLOATS + U_FLOATS) + 8 * RAW ? 0.0f : (float)(i & 7) * 0.125f;
     __syncthreads();
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 1 << 26, 0x00020000);
     f32x4 acc[8][4];
@@ -59,7 +76,8 @@ __global__ void __launch_bounds__(512, 1) k(float* out, const float* __restrict_
                 bv[slot][u][0] = b4[0]; bv[slot][u][1] = b4[1]; bv[slot][u][2] = b4[2]; bv[slot][u][3] = b4[3];
             }
         };
-        if constexpr (FEAT & 32) {
+        if constexpr (FEAT & 1024) wait_for(0, 8u * (unsigned)kb);   // V / U of this K-block written by every wave
+        if constexpr ((FEAT & 32) && !(FEAT & 1024)) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + ((kb + 1) & 1) * U_FLOATS + (j * 512 + wv * 64) * 4), 16,
@@ -100,6 +118,15 @@ __global__ void __launch_bounds__(512, 1) k(float* out, const float* __restrict_
                 }
             }
             };
+            if constexpr (FEAT & 1024) if (c == 2) {
+                wait_for(1, 8u * (unsigned)kb);   // every wave has read K-block kb - 1: its buffers may be overwritten
+                if constexpr (FEAT & 32) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + ((kb + 1) & 1) * U_FLOATS + (j * 512 + wv * 64) * 4), 16,
+                                                                 (int)((unsigned)(tid * 16 + j * 8192) + (unsigned)(kb & 63) * 32768u), 0, 0, 0);
+                }
+            }
             if constexpr (FEAT & 256) staging();
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -109,10 +136,11 @@ __global__ void __launch_bounds__(512, 1) k(float* out, const float* __restrict_
                 if constexpr (FEAT & 512) if (u == 0) staging();
             }
             if constexpr (!(FEAT & (256 | 512))) staging();
+            if constexpr (FEAT & 1024) if (c == 5) { __builtin_amdgcn_s_waitcnt(0x0070); signal(0); }   // my V rows and U pieces of K-block kb + 1 are in LDS
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (FEAT & 32) __builtin_amdgcn_s_waitcnt(0x0070);
-        else if constexpr (FEAT & (4 | 2)) __builtin_amdgcn_s_waitcnt(0xC07F);
+        else if constexpr (FEAT & (4 | 2 | 1024)) __builtin_amdgcn_s_waitcnt(0xC07F);
         if constexpr (FEAT & 16) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) { d[i][0] = rawp[rd_off + i * 24]; d[i][1] = rawp[rd_off + i * 24 + 1]; d[i][2] = rawp[rd_off + i * 24 + 2]; d[i][3] = rawp[rd_off + i * 24 + 3]; }
@@ -122,7 +150,8 @@ __global__ void __launch_bounds__(512, 1) k(float* out, const float* __restrict_
 #pragma unroll
                 for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(d[i][j]));
         }
-        if constexpr (FEAT & 2) { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+        if constexpr (FEAT & 1024) signal(1);   // (the operands of this K-block's last chunk have arrived: lgkmcnt(0) above)
+        else if constexpr (FEAT & 2) { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
     }
     float s = junk;
     for (int p = 0; p < 8; ++p) for (int n = 0; n < 4; ++n) s += acc[p][n][0] + acc[p][n][1] + acc[p][n][2] + acc[p][n][3];
@@ -132,7 +161,7 @@ __global__ void __launch_bounds__(512, 1) k(float* out, const float* __restrict_
 template <int FEAT> void run(const char* name)
 {
     const int blocks = 256 * 4, nkb = 600;
-    const int lds = (2 * (V_FLOATS + U_FLOATS) + 8 * RAW) * 4;
+    const int lds = (2 * (V_FLOATS + U_FLOATS) + 8 * RAW) * 4 + 16;
     hipFuncSetAttribute((const void*)k<FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     float *d, *src; hipMalloc(&d, (size_t)blocks * 512 * 4); hipMalloc(&src, 1 << 26); hipMemset(src, 0, 1 << 26);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -165,6 +194,8 @@ int main()
     run<1 | 2 | 4 | 8 | 16 | 32>("everything (the kernel's full K-block)");
     run<1 | 4 | 8 | 16 | 32>("everything but the barrier");
     run<1 | 2 | 4 | 8 | 16 | 32 | 64>("everything, operands two chunks ahead");
+    run<1 | 4 | 8 | 16 | 32 | 1024>("everything, the barrier split into written / read counters in LDS");
+    run<1 | 1024>("LDS + split barrier");
     run<1 | 2 | 8 | 256>("LDS + barrier + additions, in FRONT of the chunk's MFMAs");
     run<1 | 2 | 8 | 512>("LDS + barrier + additions, BETWEEN the chunk's two MFMA groups");
     run<1 | 2 | 4 | 8 | 16 | 32 | 256>("everything, staging slice in front of the chunk's MFMAs");
