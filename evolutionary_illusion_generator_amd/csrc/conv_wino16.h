@@ -1,0 +1,307 @@
+// conv_wino16.h -- the Winograd ConvLSTM of conv_wino.h on SIXTEEN waves per block (four per SIMD).  DESIGN.md section 3.1d.
+//
+// Why: the model of conv_wino.h's K-block (scripts/wino_loop_model.hip, profiles/r04_w_wino_loop_model.txt) shows every piece of the staging work
+// costing the matrix pipe several times its instruction count when only ONE partner wave per SIMD can fill in, and the barrier 9 points once
+// the waves drift; the same K-block on sixteen waves of half the accumulators each loses 4 points to all of it instead of 17.
+//
+// Same block (16 x 16 output pixels of one image x 64 columns = 16 channels x 4 gates), same K-blocks, same LDS image (V, U double-buffered,
+// eight planes), same arithmetic in the same order as wino_kernel<4, EPI_LSTM, 8> -- the results are identical bit for bit.  What changes:
+//   wave w COMPUTES region rg = w & 3 for the FOUR positions (xi, nu = 0..3) with xi = w >> 2: 4 x 4 accumulator tiles (64 VGPRs), 32 MFMAs per
+//     K-block in 8 chunks of 4, each with the operand reads of the next chunk;
+//   waves 0-7 TRANSFORM channel w of the K-block (plane DMA, patch reads before the barrier, column pass in chunk 0, one row in each of the chunks 1-4),
+//     waves 8-15 fetch the U slab (4 LDS-DMA instructions each): on every SIMD two waves of each kind;
+//   an unpooled-source K-block (xi = 2 and nu = 2 are chains of exact zeros): waves 8-11 have nothing to multiply, the others 3 positions;
+//   output transform: columns in-lane (c_xi,b), every wave publishes its 32 values per lane in LDS, then wave (rg, 2 a + s) finishes output row
+//     parity a of segment s (tile rows 4 rg + a + 2 s: window row s) from c_0..c_2 or c_1..c_3 -- the pixel ownership of the eight-wave
+//     kernel's gate epilogue split in two, whose code (lstm_cell, 16-byte accesses) is reused.
+#pragma once
+#include "conv_wino.h"
+
+namespace eig {
+
+constexpr int WINO16_THREADS = 1024;
+
+__global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const ConvArgs a)
+{
+    constexpr int NI = 4;
+    constexpr int WINO_U_FLOATS = wino_u_floats(NI);
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Vb = lds;
+    float* const Ub = lds + 2 * WINO_V_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wv & 3, xi = wv >> 2;
+    const int q = lane >> 4, col = lane & 15;
+    const bool xf = wv < 8;            // transforming wave (channel wv); the others fetch U
+    const int tch = wv & 7;
+
+    const int tiles = a.tilesX * a.tilesY;
+    const int ntile = a.B * tiles;
+    const int xcd = blockIdx.x & 7, xi_ = blockIdx.x >> 3;
+    const int nblk = xi_ % a.n_nblk;
+    const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + xi_ / a.n_nblk : (xi_ / a.n_nblk) * 8 + xcd;
+    if (tlin >= ntile) return;
+    const int eb = tlin / tiles;
+    const int t_ = tlin - eb * tiles;
+    const int tyi = t_ / a.tilesX, txi = t_ - tyi * a.tilesX;
+    const int y0 = tyi * 16, x0 = txi * 16;
+    const int HW = a.H * a.W;
+
+    // transform side (conv_wino.h): tile `lane` of the block
+    const int t_rg = lane >> 4, t_r = lane & 15;
+    const int t_ty = 2 * t_rg + ((t_r & 3) >> 1), t_tx = 2 * (t_r >> 2) + (t_r & 1);
+    const bool up_fused = a.up_src != nullptr;
+    const int nkb0 = a.src[0].C >> 3;
+    const int nkbu = up_fused ? (a.up_C >> 3) : 0;
+    const int nkb = nkb0 + nkbu + (a.nsrc > 1 ? (a.src[1].C >> 3) : 0);
+    const bool has1 = a.nsrc > 1;
+    const int up_lo = nkb0, up_hi = nkb0 + nkbu;
+#define EIG16_WAITCNT(imm) do { __builtin_amdgcn_s_waitcnt(imm); asm volatile("" ::: "memory"); } while (0)
+#define EIG16_IS_UP(kb) ((kb) >= up_lo && (kb) < up_hi)
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb * WINO_U_FLOATS), 0, nkb * WINO_U_FLOATS * 4, 0x00020000);
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    float d[4][4];
+    const unsigned long long sb0 = (unsigned long long)(a.src[0].ptr + (size_t)eb * a.src[0].Ct * HW);
+    const unsigned long long sb1 = has1 ? (unsigned long long)(a.src[1].ptr + (size_t)eb * a.src[1].Ct * HW) : sb0;
+    const int sz0 = a.src[0].C * HW * 4, sz1 = has1 ? a.src[1].C * HW * 4 : sz0;
+    float* const rawp = lds + 2 * (WINO_V_FLOATS + WINO_U_FLOATS) + tch * WINO_RAW_FLOATS;
+    int roff[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int c = lane + 64 * r, row = c / 6, cx = c - row * 6;
+        const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * cx;
+        roff[r] = (c < 108 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : -1;
+    }
+    const int Hh = a.H >> 1, Wh = a.W >> 1, HWh = Hh * Wh;
+    int uoff;
+    {
+        const int row = lane / 6, cx = lane - row * 6;
+        const int gy = (y0 >> 1) - 1 + row, gx = (x0 >> 1) - 4 + 4 * cx;
+        uoff = (lane < 60 && cx < 4 && gy >= 0 && gy < Hh && gx >= 0 && gx < Wh) ? (gy * Wh + gx) * 4 : -1;
+    }
+    const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
+    const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
+    auto dma_raw = [&](int kb) __attribute__((always_inline)) {   // (conv_wino.h: dma_raw)
+        const bool up = EIG16_IS_UP(kb);
+        const bool s1 = kb >= nkb0 + nkbu;
+        const unsigned long long mu = 0ull - (unsigned long long)up, m1 = 0ull - (unsigned long long)(s1 && !up);
+        const unsigned long long u = sb0 + ((sb1 - sb0) & m1) + ((sbu - sb0) & mu);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        const int sz = sz0 + ((sz1 - sz0) & (int)m1) + ((szu - sz0) & (int)mu);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(sz), 0x00020000);
+        const unsigned in_range = (unsigned)((kb - nkb) >> 31);
+        const unsigned chan = (unsigned)((kb - (up ? nkb0 : (s1 ? nkb0 + nkbu : 0))) * KC + tch) * (unsigned)((up ? HWh : HW) * 4);
+        const unsigned coff = (chan & in_range) | (0x80000000u & ~in_range);
+        const unsigned o0 = up ? (unsigned)uoff : (unsigned)roff[0], o1 = up ? 0xFFFFFFFFu : (unsigned)roff[1];
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)__builtin_elementwise_add_sat(o0, coff), 0, 0, 0);
+        if (lane < 44)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rawp + 64 * 4), 16, (int)__builtin_elementwise_add_sat(o1, coff), 0, 0, 0);
+    };
+    const int rd_off = (2 * t_ty) * 24 + 2 * t_tx + 3;
+    const int rd_off_u = t_ty * 24 + t_tx + 3;
+    const float* const pbase_n = rawp + rd_off;
+    const float* const pbase_u = rawp + rd_off_u;
+    auto read_patch = [&](int kb) __attribute__((always_inline)) {   // (conv_wino.h: read_patch)
+        const bool up = EIG16_IS_UP(kb);
+        const float* const p00 = up ? pbase_u : pbase_n;
+        const float* const p10 = p00 - (up ? 24 : 0);
+        const int cs = up ? 1 : 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float* const pl = (i < 2 ? p00 : p10) + i * 24;
+            const float* const pr = pl - cs;
+            d[i][0] = pl[0]; d[i][1] = pl[1]; d[i][2] = pr[2]; d[i][3] = pr[3];
+        }
+    };
+    auto transform = [&](float* vbuf) __attribute__((always_inline)) {   // (conv_wino.h: transform)
+        float t[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+        }
+        float* dst = vbuf + tch * WINO_VS + lane;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            dst[(i * 4 + 0) * KC * WINO_VS] = t[i][0] - t[i][2];
+            dst[(i * 4 + 1) * KC * WINO_VS] = t[i][1] + t[i][2];
+            dst[(i * 4 + 2) * KC * WINO_VS] = t[i][2] - t[i][1];
+            dst[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
+        }
+    };
+    // the U slab of K-block kb: 2048 chunks of 16 B, lane-linear -- four instructions on each of the waves 8-15
+    const int ut = tid - 512;
+    auto dma_u = [&](int kb, float* ubuf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ubuf + (j * 512 + (wv - 8) * 64) * 4), 16,
+                                                     ut * 16, (int)((unsigned)(j * 512 * 16) + (unsigned)kb * (WINO_U_FLOATS * 4)), 0, 0);   // (scalar offset: no VALU)
+    };
+
+    // accumulators: position (xi, nu), N-tile ni
+    f32x4 acc[4][NI];
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int a_off = (xi * 4 * KC + q) * WINO_VS + rg * 16 + col;   // V[pos = 4 xi + nu][ch = 4 ks + q][tile 16 rg + col]
+    const int b_off = ((xi * 4 * KC + q) * 16 + col) * NI;           // U[pos][ch][col][0..3]
+
+    // ---- prologue
+    if (xf) {
+        dma_raw(0);
+        EIG16_WAITCNT(0x0F70);
+        read_patch(0);
+        EIG16_WAITCNT(0xC07F);
+        dma_raw(1);
+        transform(Vb);
+    } else {
+        dma_u(0, Ub);
+    }
+    EIG16_WAITCNT(0x0070);
+    if (xf) read_patch(1);
+    __syncthreads();
+
+    // the cell state and the three peephole values of the lane's 4-pixel segment, fetched during the LAST K-block
+    const int ra = xi >> 1, seg = xi & 1;   // this wave finishes output row parity ra of segment seg
+    f32x4 st4[4];
+    auto state_loads = [&]() __attribute__((always_inline)) {
+        const int ch = nblk * 16 + col;
+        const int gy = y0 + 4 * rg + ra + 2 * seg, gx = x0 + 4 * q;
+        if (ch >= a.Cout || gy >= a.H || gx >= a.W) return;
+        const size_t pix = (size_t)gy * a.W + gx, cb = ((size_t)eb * a.Cout + ch) * HW + pix, pb = (size_t)ch * HW + pix, ps = (size_t)a.Cout * HW;
+        st4[0] = *reinterpret_cast<const f32x4*>(a.c_state + cb);
+        st4[1] = *reinterpret_cast<const f32x4*>(a.peep + pb);
+        st4[2] = *reinterpret_cast<const f32x4*>(a.peep + ps + pb);
+        st4[3] = *reinterpret_cast<const f32x4*>(a.peep + 2 * ps + pb);
+    };
+    // an unpooled-source K-block: nu = 2 is a chain of zeros for every xi, xi = 2 entirely
+    const unsigned wave_skip = xi == 2 ? 0xFu : 0x4u;
+    // kind_tag: 0 = a full K-block (no skip tests in the instruction stream: they cost this kernel 4 %), 1 = an unpooled-source K-block, 2 = run time
+    // role_tag: the wave's role (true: transforming wave) as a compile-time constant -- the K loops exist once per role behind ONE wave-uniform
+    // branch, so that no value defined on one role's path only (the transform's registers) needs a definition on the other's
+    auto kiter = [&](const int kb, auto last_tag, auto kind_tag, auto role_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int KIND = decltype(kind_tag)::value;
+        constexpr bool XF = decltype(role_tag)::value;
+        const unsigned skip = KIND == 0 ? 0u : KIND == 1 ? wave_skip : (EIG16_IS_UP(kb) ? wave_skip : 0u);
+        const float* const vcur = Vb + (kb & 1) * WINO_V_FLOATS;
+        const float* const ucur = Ub + (kb & 1) * WINO_U_FLOATS;
+        float* const vnext = Vb + ((kb + 1) & 1) * WINO_V_FLOATS + tch * WINO_VS + lane;
+        if constexpr (!LAST) { if constexpr (!XF) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); }
+        else state_loads();
+        float t[4][4];
+        float av[2][2];
+        float bv[2][2][NI];
+        auto fetch = [&](int c, int slot) __attribute__((always_inline)) {   // chunk c: k-step c >> 1, positions nu = 2 (c & 1), 2 (c & 1) + 1
+            const int ks = c >> 1, pp = c & 1;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                av[slot][u] = vcur[a_off + ((2 * pp + u) * KC + ks * 4) * WINO_VS];
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(ucur + b_off + ((2 * pp + u) * KC + ks * 4) * 16 * NI);
+                bv[slot][u][0] = b4[0]; bv[slot][u][1] = b4[1]; bv[slot][u][2] = b4[2]; bv[slot][u][3] = b4[3];
+            }
+        };
+        fetch(0, 0);
+        if constexpr (!LAST && XF) {
+            EIG16_WAITCNT(0xC07F);   // the patch of K-block kb + 1 (read before the barrier) is out of the plane: refill it for kb + 2
+            dma_raw(kb + 2);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int pp = c & 1;
+            if (c + 1 < 4) fetch(c + 1, (c + 1) & 1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                if ((skip >> (2 * pp + u)) & 1) continue;
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni)
+                    acc[2 * pp + u][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u][ni], acc[2 * pp + u][ni], 0, 0, 0);
+            }
+            if constexpr (!LAST && XF) {
+                if (c == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+                    }
+                } else if (c < 3) {
+#pragma unroll
+                    for (int i = 2 * (c - 1); i < 2 * c; ++i) {
+                        vnext[(i * 4 + 0) * KC * WINO_VS] = t[i][0] - t[i][2];
+                        vnext[(i * 4 + 1) * KC * WINO_VS] = t[i][1] + t[i][2];
+                        vnext[(i * 4 + 2) * KC * WINO_VS] = t[i][2] - t[i][1];
+                        vnext[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        EIG16_WAITCNT(0x0070);
+        if constexpr (!LAST && XF) read_patch(kb + 2);
+        asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
+    };
+    auto kloops = [&](auto role_tag) __attribute__((always_inline)) {
+        int kb = 0;
+        const int e1 = up_lo < nkb - 1 ? up_lo : nkb - 1, e2 = up_hi < nkb - 1 ? up_hi : nkb - 1;
+        for (; kb < e1; ++kb) kiter(kb, std::false_type{}, std::integral_constant<int, 0>{}, role_tag);
+        for (; kb < e2; ++kb) kiter(kb, std::false_type{}, std::integral_constant<int, 1>{}, role_tag);
+        for (; kb < nkb - 1; ++kb) kiter(kb, std::false_type{}, std::integral_constant<int, 0>{}, role_tag);
+    };
+    if (xf) kloops(std::true_type{}); else kloops(std::false_type{});
+    kiter(nkb - 1, std::true_type{}, std::integral_constant<int, 2>{}, std::false_type{});
+
+    // ---- output transform.  Columns in-lane: c_xi,0 = (M_xi0 + M_xi1) + M_xi2, c_xi,1 = (M_xi1 - M_xi2) - M_xi3.
+    f32x4 cc[2][NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        cc[0][ni] = (acc[0][ni] + acc[1][ni]) + acc[2][ni];
+        cc[1][ni] = (acc[1][ni] - acc[2][ni]) - acc[3][ni];
+    }
+    // Rows: y_0b = (c_0b + c_1b) + c_2b, y_1b = c_1b - (c_2b + c_3b).  Every wave publishes its c row; wave (rg, xi = 2 ra + seg) then finishes row
+    // parity ra of segment seg = accumulator registers 2 seg, 2 seg + 1.
+    float* const xb = lds;   // [16 waves][32][64 lanes] = 128 KB: V / U are dead (every wave is past the last barrier)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xb[(wv * 32 + (b * 4 + ni) * 4 + r) * 64 + lane] = cc[b][ni][r];
+    __syncthreads();
+    float y[2][NI][2];   // [b = px][ni][window 2 seg + k]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int r = 2 * seg + k;
+                const int e = ((b * 4 + ni) * 4 + r) * 64 + lane;
+                const float c1 = xb[((4 + rg) * 32) * 64 + e], c2 = xb[((8 + rg) * 32) * 64 + e];
+                const float c03 = xb[(((ra ? 12 : 0) + rg) * 32) * 64 + e];
+                y[b][ni][k] = ra ? c1 - (c2 + c03) : (c03 + c1) + c2;
+            }
+    const int ch = nblk * 16 + col;
+    if (ch >= a.Cout) return;
+    const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
+    const size_t cbase = ((size_t)eb * a.Cout + ch) * (size_t)HW;
+    {
+        const int gy = y0 + 4 * rg + ra + 2 * seg, gx = x0 + 4 * q;
+        if (gy >= a.H || gx >= a.W) return;
+        const int pix = gy * a.W + gx;
+        f32x4 cn4, hn4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {   // element j = sub-tile px = j & 1 of window 2 seg + (j >> 1)
+            float cn, hn;
+            lstm_cell(y[j & 1][0][j >> 1], y[j & 1][1][j >> 1], y[j & 1][2][j >> 1], y[j & 1][3][j >> 1],
+                      bi, bf, bc, bo, st4[0][j], st4[1][j], st4[2][j], st4[3][j], cn, hn);
+            cn4[j] = cn; hn4[j] = hn;
+        }
+        *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
+        *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
+    }
+#undef EIG16_WAITCNT
+#undef EIG16_IS_UP
+}
+
+}  // namespace eig

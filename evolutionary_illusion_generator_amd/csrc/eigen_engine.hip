@@ -16,6 +16,10 @@
 #include "../../include/eigen_engine.h"
 #include "conv_mfma.h"
 #include "conv_wino.h"
+#include "conv_wino16.h"
+#ifndef EIGEN_WINO16_DEFAULT
+#define EIGEN_WINO16_DEFAULT 1
+#endif
 #include "cppn_kernel.h"
 #include "farneback_kernels.h"
 #include "flow_kernels.h"
@@ -559,7 +563,16 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             hipLaunchKernelGGL(kern, dim3(g), dim3(WINO_THREADS), lds, st, a);
         };
         const bool m4 = mode != 0;
-        if (mode == 8) {
+        // EIGEN_WINO16: the ConvLSTM on sixteen waves per block (conv_wino16.h; same results)
+        static const int wino16 = getenv("EIGEN_WINO16") ? atoi(getenv("EIGEN_WINO16")) : EIGEN_WINO16_DEFAULT;
+        if (mode == 8 && wino16 && op.epi == EPI_LSTM && a.acc_init == nullptr) {
+            const int lds = wino_lds_bytes(4, true);
+            static bool attr16 = false;
+            if (!attr16) { attr16 = true; (void)hipFuncSetAttribute((const void*)wino16_lstm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
+            op.last_waves = 16;
+            hipLaunchKernelGGL(wino16_lstm_kernel, dim3(g), dim3(WINO16_THREADS), lds, st, a);
+        }
+        else if (mode == 8) {
             if (op.epi == EPI_LSTM) go(wino_kernel<4, EPI_LSTM, 8>, 4, true);
             else if (op.epi == EPI_CONVA && op.NI == 4) go(wino_kernel<4, EPI_CONVA, 8>, 4, true);
             else if (op.epi == EPI_CONVA) go(wino_kernel<3, EPI_CONVA, 8>, 3, true);

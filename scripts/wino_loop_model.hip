@@ -158,6 +158,130 @@ __global__ void __launch_bounds__(512, 1) k(float* out, const float* __restrict_
     out[blockIdx.x * 512 + tid] = s + d[0][0];
 }
 
+// The same K-block on SIXTEEN waves (four per SIMD, <= 128 VGPRs each): every wave multiplies 4 positions x 4 N-tiles (32 MFMAs per K-block, 4 chunks
+// of 8), waves 0-7 transform one channel each and fetch its plane, waves 8-15 fetch the U slab.  FEAT bits as above (1, 2, 4, 8, 16, 32).
+template <int FEAT>
+__global__ void __launch_bounds__(1024, 1) k16(float* out, const float* __restrict__ src, int nkb)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Vb = lds;
+    float* const Ub = lds + 2 * V_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wv & 3, quarter = wv >> 2, q = lane >> 4, col = lane & 15;
+    const bool xf = wv < 8;
+    float* const rawp = lds + 2 * (V_FLOATS + U_FLOATS) + (wv & 7) * RAW;
+    for (int i = tid; i < 2 * (V_FLOATS + U_FLOATS) + 8 * RAW; i += 1024) lds[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, 1 << 26, 0x00020000);
+    f32x4 acc[4][4];
+    for (int p = 0; p < 4; ++p) for (int n = 0; n < 4; ++n) acc[p][n] = (f32x4){0, 0, 0, 0};
+    const int a_off = (quarter * 4 * KC + q) * VS + rg * 16 + col;
+    const int b_off = ((quarter * 4 * KC + q) * 16 + col) * 4;
+    float d[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) d[i][j] = (float)(lane + i * 4 + j);
+    const int rd_off = (2 * (lane >> 3)) * 24 + 2 * (lane & 7) + 3;
+    for (int kb = 0; kb < nkb; ++kb) {
+        const float* const vcur = Vb + (kb & 1) * V_FLOATS;
+        const float* const ucur = Ub + (kb & 1) * U_FLOATS;
+        float* const vnext = Vb + ((kb + 1) & 1) * V_FLOATS + (wv & 7) * VS + lane;
+        float av[2][2], bv[2][2][4];
+        float t[4][4];
+        auto fetch = [&](int c, int slot) __attribute__((always_inline)) {
+            const int ks = c >> 1, pp = c & 1;
+            if constexpr (!(FEAT & 1)) {
+                for (int u = 0; u < 2; ++u) { av[slot][u] = 1.0f + c; for (int n = 0; n < 4; ++n) bv[slot][u][n] = 0.5f + n; }
+                return;
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                av[slot][u] = vcur[a_off + ((2 * pp + u) * KC + ks * 4) * VS];
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(ucur + b_off + ((2 * pp + u) * KC + ks * 4) * 16 * 4);
+                bv[slot][u][0] = b4[0]; bv[slot][u][1] = b4[1]; bv[slot][u][2] = b4[2]; bv[slot][u][3] = b4[3];
+            }
+        };
+        if constexpr (FEAT & 32) if (!xf) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + ((kb + 1) & 1) * U_FLOATS + (j * 512 + (wv - 8) * 64) * 4), 16,
+                                                         (int)((unsigned)((tid - 512) * 16 + j * 8192) + (unsigned)(kb & 63) * 32768u), 0, 0, 0);
+        }
+        fetch(0, 0);
+        if constexpr (FEAT & 32) if (xf) {
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)rawp, 16, (int)((unsigned)(lane * 16) + (unsigned)((kb & 63) * 8 + wv) * 65536u), 0, 0, 0);
+            if (lane < 44)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(rawp + 256), 16, (int)((unsigned)(lane * 16 + 1024) + (unsigned)((kb & 63) * 8 + wv) * 65536u), 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int pp = c & 1;
+            if (c + 1 < 4) fetch(c + 1, (c + 1) & 1);
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[2 * pp + u][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u][n], acc[2 * pp + u][n], 0, 0, 0);
+            if (xf) {
+                if (c == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (FEAT & 8) { t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j]; }
+                        else { t[0][j] = d[0][j]; t[1][j] = d[1][j]; t[2][j] = d[2][j]; t[3][j] = d[3][j]; }
+                    }
+                } else if (c < 3) {
+#pragma unroll
+                    for (int i = 2 * (c - 1); i < 2 * c; ++i) {
+                        float v4[4] = {t[i][0], t[i][1], t[i][2], t[i][3]};
+                        if constexpr (FEAT & 8) { v4[0] = t[i][0] - t[i][2]; v4[1] = t[i][1] + t[i][2]; v4[2] = t[i][2] - t[i][1]; v4[3] = t[i][1] - t[i][3]; }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if constexpr (FEAT & 4) vnext[(i * 4 + j) * KC * VS] = v4[j];
+                            else asm volatile("" :: "v"(v4[j]));
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (FEAT & 32) __builtin_amdgcn_s_waitcnt(0x0070);
+        else if constexpr (FEAT & (4 | 2)) __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (xf) {
+            if constexpr (FEAT & 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { d[i][0] = rawp[rd_off + i * 24]; d[i][1] = rawp[rd_off + i * 24 + 1]; d[i][2] = rawp[rd_off + i * 24 + 2]; d[i][3] = rawp[rd_off + i * 24 + 3]; }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(d[i][j]));
+            }
+        }
+        if constexpr (FEAT & 2) { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); }
+    }
+    float s = 0;
+    for (int p = 0; p < 4; ++p) for (int n = 0; n < 4; ++n) s += acc[p][n][0] + acc[p][n][1] + acc[p][n][2] + acc[p][n][3];
+    out[blockIdx.x * 1024 + tid] = s + d[0][0];
+}
+
+template <int FEAT> void run16(const char* name)
+{
+    const int blocks = 256 * 4, nkb = 600;
+    const int lds = (2 * (V_FLOATS + U_FLOATS) + 8 * RAW) * 4 + 16;
+    hipFuncSetAttribute((const void*)k16<FEAT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    float *d, *src; hipMalloc(&d, (size_t)blocks * 1024 * 4); hipMalloc(&src, 1 << 26); hipMemset(src, 0, 1 << 26);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k16<FEAT><<<blocks, 1024, lds>>>(d, src, 20);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    k16<FEAT><<<blocks, 1024, lds>>>(d, src, nkb);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double flops = (double)blocks * 16 * nkb * 32 * 2048.0;
+    printf("16w %3d %-74s %7.2f ms  %6.1f TFLOP/s  %.3f of 157.3\n", FEAT, name, ms, flops / ms * 1e-9, flops / ms * 1e-9 / 157.3);
+    fflush(stdout);
+    hipFree(d); hipFree(src);
+}
+
 template <int FEAT> void run(const char* name)
 {
     const int blocks = 256 * 4, nkb = 600;
@@ -179,6 +303,13 @@ template <int FEAT> void run(const char* name)
 
 int main()
 {
+    run16<0>("sixteen waves: operands in registers");
+    run16<1>("sixteen waves: operands from LDS");
+    run16<1 | 2>("sixteen waves: LDS + barrier");
+    run16<1 | 2 | 4 | 8 | 16>("sixteen waves: LDS + barrier + whole transform");
+    run16<1 | 2 | 32>("sixteen waves: LDS + barrier + DMA");
+    run16<1 | 2 | 4 | 8 | 16 | 32>("sixteen waves: everything");
+    run16<1 | 4 | 8 | 16 | 32>("sixteen waves: everything but the barrier");
     run<0>("operands in registers, nothing else");
     run<2>("registers + barrier");
     run<1>("operands from LDS, one chunk ahead");
