@@ -20,6 +20,11 @@
 namespace eig {
 
 constexpr int WINO16_THREADS = 1024;
+// LDS image of this kernel: V [2][16 pos][8 ch][64 tiles] WITHOUT padding -- tile index XOR 16 on odd channels keeps the k-slots q, q + 1 of an
+// operand read on disjoint banks -- (64 KB), U [2][16][8][16][4] (64 KB), and TWO planes per channel (K-blocks of even / odd index: 27 KB)
+constexpr int W16_VS = 64;
+constexpr int W16_V_FLOATS = 16 * KC * W16_VS;   // 8192
+constexpr int wino16_lds_bytes() { return (2 * (W16_V_FLOATS + wino_u_floats(4)) + 16 * WINO_RAW_FLOATS) * 4; }   // 158720
 
 __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const ConvArgs a)
 {
@@ -27,7 +32,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
     constexpr int WINO_U_FLOATS = wino_u_floats(NI);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const Vb = lds;
-    float* const Ub = lds + 2 * WINO_V_FLOATS;
+    float* const Ub = lds + 2 * W16_V_FLOATS;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -66,7 +71,9 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
     const unsigned long long sb0 = (unsigned long long)(a.src[0].ptr + (size_t)eb * a.src[0].Ct * HW);
     const unsigned long long sb1 = has1 ? (unsigned long long)(a.src[1].ptr + (size_t)eb * a.src[1].Ct * HW) : sb0;
     const int sz0 = a.src[0].C * HW * 4, sz1 = has1 ? a.src[1].C * HW * 4 : sz0;
-    float* const rawp = lds + 2 * (WINO_V_FLOATS + WINO_U_FLOATS) + tch * WINO_RAW_FLOATS;
+    // plane (channel tch, parity of the K-block); fetched by wave 8 + tch, read by wave tch
+    float* const planes = lds + 2 * (W16_V_FLOATS + WINO_U_FLOATS) + tch * WINO_RAW_FLOATS;
+    constexpr int PLANE_PAR = 8 * WINO_RAW_FLOATS;   // planes of odd K-blocks behind those of even ones
     int roff[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -83,7 +90,8 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
     }
     const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
-    auto dma_raw = [&](int kb) __attribute__((always_inline)) {   // (conv_wino.h: dma_raw)
+    auto dma_raw = [&](int kb) __attribute__((always_inline)) {   // (conv_wino.h: dma_raw) -> the plane of K-block kb's parity
+        float* const rawp = planes + (kb & 1) * PLANE_PAR;
         const bool up = EIG16_IS_UP(kb);
         const bool s1 = kb >= nkb0 + nkbu;
         const unsigned long long mu = 0ull - (unsigned long long)up, m1 = 0ull - (unsigned long long)(s1 && !up);
@@ -101,11 +109,11 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
     };
     const int rd_off = (2 * t_ty) * 24 + 2 * t_tx + 3;
     const int rd_off_u = t_ty * 24 + t_tx + 3;
-    const float* const pbase_n = rawp + rd_off;
-    const float* const pbase_u = rawp + rd_off_u;
-    auto read_patch = [&](int kb) __attribute__((always_inline)) {   // (conv_wino.h: read_patch)
+    const float* const pbase_n = planes + rd_off;
+    const float* const pbase_u = planes + rd_off_u;
+    auto read_patch = [&](int kb) __attribute__((always_inline)) {   // (conv_wino.h: read_patch) <- the plane of K-block kb's parity
         const bool up = EIG16_IS_UP(kb);
-        const float* const p00 = up ? pbase_u : pbase_n;
+        const float* const p00 = (up ? pbase_u : pbase_n) + (kb & 1) * PLANE_PAR;
         const float* const p10 = p00 - (up ? 24 : 0);
         const int cs = up ? 1 : 0;
 #pragma unroll
@@ -121,13 +129,13 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
         for (int j = 0; j < 4; ++j) {
             t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
         }
-        float* dst = vbuf + tch * WINO_VS + lane;
+        float* dst = vbuf + tch * W16_VS + (lane ^ ((tch & 1) << 4));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            dst[(i * 4 + 0) * KC * WINO_VS] = t[i][0] - t[i][2];
-            dst[(i * 4 + 1) * KC * WINO_VS] = t[i][1] + t[i][2];
-            dst[(i * 4 + 2) * KC * WINO_VS] = t[i][2] - t[i][1];
-            dst[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
+            dst[(i * 4 + 0) * KC * W16_VS] = t[i][0] - t[i][2];
+            dst[(i * 4 + 1) * KC * W16_VS] = t[i][1] + t[i][2];
+            dst[(i * 4 + 2) * KC * W16_VS] = t[i][2] - t[i][1];
+            dst[(i * 4 + 3) * KC * W16_VS] = t[i][1] - t[i][3];
         }
     };
     // the U slab of K-block kb: 2048 chunks of 16 B, lane-linear -- four instructions on each of the waves 8-15
@@ -145,22 +153,23 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
     for (int p = 0; p < 4; ++p)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int a_off = (xi * 4 * KC + q) * WINO_VS + rg * 16 + col;   // V[pos = 4 xi + nu][ch = 4 ks + q][tile 16 rg + col]
+    const int a_off = (xi * 4 * KC + q) * W16_VS + ((rg * 16 + col) ^ ((q & 1) << 4));   // V[pos = 4 xi + nu][ch = 4 ks + q][tile 16 rg + col, swizzled]
     const int b_off = ((xi * 4 * KC + q) * 16 + col) * NI;           // U[pos][ch][col][0..3]
 
-    // ---- prologue
-    if (xf) {
+    // ---- prologue: the planes of K-blocks 0 and 1 and the U slab of K-block 0 (waves 8-15); K-block 0 transformed (waves 0-7)
+    if (!xf) {
         dma_raw(0);
+        dma_raw(1);
+        dma_u(0, Ub);
         EIG16_WAITCNT(0x0F70);
+    }
+    __syncthreads();
+    if (xf) {
         read_patch(0);
         EIG16_WAITCNT(0xC07F);
-        dma_raw(1);
         transform(Vb);
-    } else {
-        dma_u(0, Ub);
     }
     EIG16_WAITCNT(0x0070);
-    if (xf) read_patch(1);
     __syncthreads();
 
     // the cell state and the three peephole values of the lane's 4-pixel segment, fetched during the LAST K-block
@@ -186,10 +195,12 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
         constexpr int KIND = decltype(kind_tag)::value;
         constexpr bool XF = decltype(role_tag)::value;
         const unsigned skip = KIND == 0 ? 0u : KIND == 1 ? wave_skip : (EIG16_IS_UP(kb) ? wave_skip : 0u);
-        const float* const vcur = Vb + (kb & 1) * WINO_V_FLOATS;
+        const float* const vcur = Vb + (kb & 1) * W16_V_FLOATS;
         const float* const ucur = Ub + (kb & 1) * WINO_U_FLOATS;
-        float* const vnext = Vb + ((kb + 1) & 1) * WINO_V_FLOATS + tch * WINO_VS + lane;
-        if constexpr (!LAST) { if constexpr (!XF) dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); }
+        float* const vnext = Vb + ((kb + 1) & 1) * W16_V_FLOATS + tch * W16_VS + (lane ^ ((tch & 1) << 4));
+        // waves 8-15: the U slab of K-block kb + 1 and the plane of K-block kb + 2 (its buffer held K-block kb: read out by wave tch at the top of
+        // K-block kb - 1, a barrier ago); waves 0-7: the patch of K-block kb + 1 (its plane landed before the barrier in front of this K-block)
+        if constexpr (!LAST) { if constexpr (!XF) { dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); dma_raw(kb + 2); } else read_patch(kb + 1); }
         else state_loads();
         float t[4][4];
         float av[2][2];
@@ -198,16 +209,12 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
             const int ks = c >> 1, pp = c & 1;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                av[slot][u] = vcur[a_off + ((2 * pp + u) * KC + ks * 4) * WINO_VS];
+                av[slot][u] = vcur[a_off + ((2 * pp + u) * KC + ks * 4) * W16_VS];
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(ucur + b_off + ((2 * pp + u) * KC + ks * 4) * 16 * NI);
                 bv[slot][u][0] = b4[0]; bv[slot][u][1] = b4[1]; bv[slot][u][2] = b4[2]; bv[slot][u][3] = b4[3];
             }
         };
         fetch(0, 0);
-        if constexpr (!LAST && XF) {
-            EIG16_WAITCNT(0xC07F);   // the patch of K-block kb + 1 (read before the barrier) is out of the plane: refill it for kb + 2
-            dma_raw(kb + 2);
-        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int pp = c & 1;
@@ -228,17 +235,16 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
                 } else if (c < 3) {
 #pragma unroll
                     for (int i = 2 * (c - 1); i < 2 * c; ++i) {
-                        vnext[(i * 4 + 0) * KC * WINO_VS] = t[i][0] - t[i][2];
-                        vnext[(i * 4 + 1) * KC * WINO_VS] = t[i][1] + t[i][2];
-                        vnext[(i * 4 + 2) * KC * WINO_VS] = t[i][2] - t[i][1];
-                        vnext[(i * 4 + 3) * KC * WINO_VS] = t[i][1] - t[i][3];
+                        vnext[(i * 4 + 0) * KC * W16_VS] = t[i][0] - t[i][2];
+                        vnext[(i * 4 + 1) * KC * W16_VS] = t[i][1] + t[i][2];
+                        vnext[(i * 4 + 2) * KC * W16_VS] = t[i][2] - t[i][1];
+                        vnext[(i * 4 + 3) * KC * W16_VS] = t[i][1] - t[i][3];
                     }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
         EIG16_WAITCNT(0x0070);
-        if constexpr (!LAST && XF) read_patch(kb + 2);
         asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory");
     };
     auto kloops = [&](auto role_tag) __attribute__((always_inline)) {

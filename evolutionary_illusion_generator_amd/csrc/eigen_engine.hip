@@ -566,7 +566,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         // EIGEN_WINO16: the ConvLSTM on sixteen waves per block (conv_wino16.h; same results)
         static const int wino16 = getenv("EIGEN_WINO16") ? atoi(getenv("EIGEN_WINO16")) : EIGEN_WINO16_DEFAULT;
         if (mode == 8 && wino16 && op.epi == EPI_LSTM && a.acc_init == nullptr) {
-            const int lds = wino_lds_bytes(4, true);
+            const int lds = wino16_lds_bytes();
             static bool attr16 = false;
             if (!attr16) { attr16 = true; (void)hipFuncSetAttribute((const void*)wino16_lstm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
             op.last_waves = 16;
