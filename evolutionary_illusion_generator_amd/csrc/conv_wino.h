@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(WINO_THREADS, 1) wino_kernel(const ConvArgs a)
 #pragma unroll
         for (int j = 0; j < NI; ++j)   // 512 NI chunks of 16 B, lane-linear
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ubuf + (j * WINO_THREADS + wv * 64) * 4), 16,
-                                                     (int)((unsigned)(tid * 16 + j * WINO_THREADS * 16) + (unsigned)kb * (WINO_U_FLOATS * 4)), 0, 0, 0);
+                                                     tid * 16, (int)((unsigned)(j * WINO_THREADS * 16) + (unsigned)kb * (WINO_U_FLOATS * 4)), 0, 0);   // (scalar offset: no VALU)
     };
 
     // accumulators: position p = 4 xl + nu (xl = 0, 1: xi = 2 half + xl), N-tile ni

@@ -266,27 +266,23 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
     }
     // Rows: y_0b = (c_0b + c_1b) + c_2b, y_1b = c_1b - (c_2b + c_3b).  Every wave publishes its c row; wave (rg, xi = 2 ra + seg) then finishes row
     // parity ra of segment seg = accumulator registers 2 seg, 2 seg + 1.
-    float* const xb = lds;   // [16 waves][32][64 lanes] = 128 KB: V / U are dead (every wave is past the last barrier)
+    float* const xb = lds;   // [16 waves][8 (b, ni)][64 lanes][4 registers] = 128 KB: V / U are dead (every wave is past the last barrier)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) xb[(wv * 32 + (b * 4 + ni) * 4 + r) * 64 + lane] = cc[b][ni][r];
+        for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(xb + ((wv * 8 + b * 4 + ni) * 64 + lane) * 4) = cc[b][ni];
     __syncthreads();
     float y[2][NI][2];   // [b = px][ni][window 2 seg + k]
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni) {
+            const int e = ((b * 4 + ni) * 64 + lane) * 4 + 2 * seg;   // registers 2 seg, 2 seg + 1 of the publishing wave's c row
+            const f32x2 c1 = *reinterpret_cast<const f32x2*>(xb + (4 + rg) * 2048 + e), c2 = *reinterpret_cast<const f32x2*>(xb + (8 + rg) * 2048 + e);
+            const f32x2 c03 = *reinterpret_cast<const f32x2*>(xb + ((ra ? 12 : 0) + rg) * 2048 + e);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int r = 2 * seg + k;
-                const int e = ((b * 4 + ni) * 4 + r) * 64 + lane;
-                const float c1 = xb[((4 + rg) * 32) * 64 + e], c2 = xb[((8 + rg) * 32) * 64 + e];
-                const float c03 = xb[(((ra ? 12 : 0) + rg) * 32) * 64 + e];
-                y[b][ni][k] = ra ? c1 - (c2 + c03) : (c03 + c1) + c2;
-            }
+            for (int k = 0; k < 2; ++k) y[b][ni][k] = ra ? c1[k] - (c2[k] + c03[k]) : (c03[k] + c1[k]) + c2[k];
+        }
     const int ch = nblk * 16 + col;
     if (ch >= a.Cout) return;
     const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
