@@ -40,7 +40,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, den
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
 LSTM_KERNEL_TAG = "conv3x3_mfma<4, 16, 1"  # the dominant kernel's name in rocprofv3 output (EPI_LSTM = 1)
 WINO_KERNEL_TAG = "wino_kernel<4, 1,"       # ... when the ConvLSTM chains run in their Winograd form (EIGEN_WINOGRAD): the eight-wave kernel (EIGEN_WINO16=0)
-WINO16_KERNEL_TAG = "wino16_lstm_kernel"     # ... and the sixteen-wave kernel (csrc/conv_wino16.h, the default)
+WINO16_KERNEL_TAG = "wino16_kernel<4, 1>"    # ... and the sixteen-wave kernel (csrc/conv_wino16.h, the default)
 N_STEPS_PREDNET = 21          # steps 1-20 + first extension (the 22nd step is never read on the population path)
 
 SHAPES = {
@@ -556,7 +556,7 @@ def main():
         flops_step = eng.flops_per_step()
         wino_rows = [r for r in lstm if r.get("wino")]
         direct_fl = sum((r["flops_per_image"] * (36.0 / 16.0 if r.get("wino") else 1.0)) * nb * r["launches"] for r in lstm)  # the same launches as 9-tap chains
-        out["roofline"] = {"bound": "mfma", "kernel": ("wino16_lstm_kernel (EIGEN_WINO16=0: wino_kernel<4,EPI_LSTM>) (ConvLSTM, E / unpooled R / h chains as Winograd F(2x2,3x3): 16 of 36 multiply-adds, fused gates, v_mfma_f32_16x16x4_f32)"
+        out["roofline"] = {"bound": "mfma", "kernel": ("wino16_kernel<4,EPI_LSTM> (EIGEN_WINO16=0: wino_kernel<4,EPI_LSTM,8>) (ConvLSTM, E / unpooled R / h chains as Winograd F(2x2,3x3): 16 of 36 multiply-adds, fused gates, v_mfma_f32_16x16x4_f32)"
                                                        if wino_rows else "conv3x3_mfma<4,16,EPI_LSTM> (fused ConvLSTM gates, v_mfma_f32_16x16x4_f32)"),
                            "winograd_layers": sorted({r["layer"] for r in wino_rows}),
                            "dominant_kernel_tflops_as_direct_convolution": direct_fl / (ms * 1e-3) / 1e12,

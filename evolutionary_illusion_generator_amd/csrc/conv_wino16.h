@@ -24,11 +24,14 @@ constexpr int WINO16_THREADS = 1024;
 // operand read on disjoint banks -- (64 KB), U [2][16][8][16][4] (64 KB), and TWO planes per channel (K-blocks of even / odd index: 27 KB)
 constexpr int W16_VS = 64;
 constexpr int W16_V_FLOATS = 16 * KC * W16_VS;   // 8192
-constexpr int wino16_lds_bytes() { return (2 * (W16_V_FLOATS + wino_u_floats(4)) + 16 * WINO_RAW_FLOATS) * 4; }   // 158720
+constexpr int wino16_lds_bytes(int NI) { return (2 * (W16_V_FLOATS + wino_u_floats(NI)) + 16 * WINO_RAW_FLOATS) * 4; }   // 158720 for NI = 4
 
-__global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const ConvArgs a)
+template <int NI, int EPI>
+__global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArgs a)
 {
-    constexpr int NI = 4;
+    static_assert(EPI == EPI_LSTM || EPI == EPI_CONVA || EPI == EPI_CONVP, "conv_wino16.h: ConvLSTM, ConvA, ConvP");
+    static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
+    static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
     constexpr int WINO_U_FLOATS = wino_u_floats(NI);
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* const Vb = lds;
@@ -56,7 +59,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
     // transform side (conv_wino.h): tile `lane` of the block
     const int t_rg = lane >> 4, t_r = lane & 15;
     const int t_ty = 2 * t_rg + ((t_r & 3) >> 1), t_tx = 2 * (t_r >> 2) + (t_r & 1);
-    const bool up_fused = a.up_src != nullptr;
+    const bool up_fused = EPI == EPI_LSTM && a.up_src != nullptr;
     const int nkb0 = a.src[0].C >> 3;
     const int nkbu = up_fused ? (a.up_C >> 3) : 0;
     const int nkb = nkb0 + nkbu + (a.nsrc > 1 ? (a.src[1].C >> 3) : 0);
@@ -138,11 +141,11 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
             dst[(i * 4 + 3) * KC * W16_VS] = t[i][1] - t[i][3];
         }
     };
-    // the U slab of K-block kb: 2048 chunks of 16 B, lane-linear -- four instructions on each of the waves 8-15
+    // the U slab of K-block kb: 512 NI chunks of 16 B, lane-linear -- NI instructions on each of the waves 8-15
     const int ut = tid - 512;
     auto dma_u = [&](int kb, float* ubuf) __attribute__((always_inline)) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NI; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(ubuf + (j * 512 + (wv - 8) * 64) * 4), 16,
                                                      ut * 16, (int)((unsigned)(j * 512 * 16) + (unsigned)kb * (WINO_U_FLOATS * 4)), 0, 0);   // (scalar offset: no VALU)
     };
@@ -201,7 +204,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
         // waves 8-15: the U slab of K-block kb + 1 and the plane of K-block kb + 2 (its buffer held K-block kb: read out by wave tch at the top of
         // K-block kb - 1, a barrier ago); waves 0-7: the patch of K-block kb + 1 (its plane landed before the barrier in front of this K-block)
         if constexpr (!LAST) { if constexpr (!XF) { dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); dma_raw(kb + 2); } else read_patch(kb + 1); }
-        else state_loads();
+        else if constexpr (EPI == EPI_LSTM) state_loads();
         float t[4][4];
         float av[2][2];
         float bv[2][2][NI];
@@ -210,8 +213,14 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 av[slot][u] = vcur[a_off + ((2 * pp + u) * KC + ks * 4) * W16_VS];
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(ucur + b_off + ((2 * pp + u) * KC + ks * 4) * 16 * NI);
-                bv[slot][u][0] = b4[0]; bv[slot][u][1] = b4[1]; bv[slot][u][2] = b4[2]; bv[slot][u][3] = b4[3];
+                const float* const bsrc = ucur + b_off + ((2 * pp + u) * KC + ks * 4) * 16 * NI;
+                if constexpr (NI == 4) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bsrc);
+                    bv[slot][u][0] = b4[0]; bv[slot][u][1] = b4[1]; bv[slot][u][2] = b4[2]; bv[slot][u][3] = b4[3];
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) bv[slot][u][ni] = bsrc[ni];
+                }
             }
         };
         fetch(0, 0);
@@ -272,35 +281,91 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_lstm_kernel(const Co
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(xb + ((wv * 8 + b * 4 + ni) * 64 + lane) * 4) = cc[b][ni];
     __syncthreads();
-    float y[2][NI][2];   // [b = px][ni][window 2 seg + k]
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int e = ((b * 4 + ni) * 64 + lane) * 4 + 2 * seg;   // registers 2 seg, 2 seg + 1 of the publishing wave's c row
-            const f32x2 c1 = *reinterpret_cast<const f32x2*>(xb + (4 + rg) * 2048 + e), c2 = *reinterpret_cast<const f32x2*>(xb + (8 + rg) * 2048 + e);
-            const f32x2 c03 = *reinterpret_cast<const f32x2*>(xb + ((ra ? 12 : 0) + rg) * 2048 + e);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) y[b][ni][k] = ra ? c1[k] - (c2[k] + c03[k]) : (c03[k] + c1[k]) + c2[k];
+    if constexpr (EPI == EPI_LSTM) {
+        float y[2][NI][2];   // [b = px][ni][window 2 seg + k]
+    #pragma unroll
+        for (int b = 0; b < 2; ++b)
+    #pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int e = ((b * 4 + ni) * 64 + lane) * 4 + 2 * seg;   // registers 2 seg, 2 seg + 1 of the publishing wave's c row
+                const f32x2 c1 = *reinterpret_cast<const f32x2*>(xb + (4 + rg) * 2048 + e), c2 = *reinterpret_cast<const f32x2*>(xb + (8 + rg) * 2048 + e);
+                const f32x2 c03 = *reinterpret_cast<const f32x2*>(xb + ((ra ? 12 : 0) + rg) * 2048 + e);
+    #pragma unroll
+                for (int k = 0; k < 2; ++k) y[b][ni][k] = ra ? c1[k] - (c2[k] + c03[k]) : (c03[k] + c1[k]) + c2[k];
+            }
+        const int ch = nblk * 16 + col;
+        if (ch >= a.Cout) return;
+        const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
+        const size_t cbase = ((size_t)eb * a.Cout + ch) * (size_t)HW;
+        {
+            const int gy = y0 + 4 * rg + ra + 2 * seg, gx = x0 + 4 * q;
+            if (gy >= a.H || gx >= a.W) return;
+            const int pix = gy * a.W + gx;
+            f32x4 cn4, hn4;
+    #pragma unroll
+            for (int j = 0; j < 4; ++j) {   // element j = sub-tile px = j & 1 of window 2 seg + (j >> 1)
+                float cn, hn;
+                lstm_cell(y[j & 1][0][j >> 1], y[j & 1][1][j >> 1], y[j & 1][2][j >> 1], y[j & 1][3][j >> 1],
+                          bi, bf, bc, bo, st4[0][j], st4[1][j], st4[2][j], st4[3][j], cn, hn);
+                cn4[j] = cn; hn4[j] = hn;
+            }
+            *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
+            *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
         }
-    const int ch = nblk * 16 + col;
-    if (ch >= a.Cout) return;
-    const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
-    const size_t cbase = ((size_t)eb * a.Cout + ch) * (size_t)HW;
-    {
-        const int gy = y0 + 4 * rg + ra + 2 * seg, gx = x0 + 4 * q;
-        if (gy >= a.H || gx >= a.W) return;
-        const int pix = gy * a.W + gx;
-        f32x4 cn4, hn4;
+    } else {
+        // N-TILE split: wave (rg, xi) finishes N-tile xi of its region for both row parities (xi = 3 rests where NI = 3): all four parity classes of
+        // a window in one lane -- ConvA's max_pooling_2d is the max over a lane's four values, ConvP stores whole 4 x 4-pixel patches (conv_wino.h)
+        const int k = xi;
+        if (k >= NI) return;
+        f32x4 y[2][2];   // [py][px]
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {   // element j = sub-tile px = j & 1 of window 2 seg + (j >> 1)
-            float cn, hn;
-            lstm_cell(y[j & 1][0][j >> 1], y[j & 1][1][j >> 1], y[j & 1][2][j >> 1], y[j & 1][3][j >> 1],
-                      bi, bf, bc, bo, st4[0][j], st4[1][j], st4[2][j], st4[3][j], cn, hn);
-            cn4[j] = cn; hn4[j] = hn;
+        for (int b = 0; b < 2; ++b) {
+            const int e = ((b * 4 + k) * 64 + lane) * 4;
+            const f32x4 c0 = *reinterpret_cast<const f32x4*>(xb + (0 + rg) * 2048 + e), c1 = *reinterpret_cast<const f32x4*>(xb + (4 + rg) * 2048 + e);
+            const f32x4 c2 = *reinterpret_cast<const f32x4*>(xb + (8 + rg) * 2048 + e), c3 = *reinterpret_cast<const f32x4*>(xb + (12 + rg) * 2048 + e);
+            y[0][b] = (c0 + c1) + c2;
+            y[1][b] = c1 - (c2 + c3);
         }
-        *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
-        *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
+        const int ch = nblk * NI * 16 + k * 16 + col;
+        if (ch >= a.Cout) return;
+        const float bb = a.bias[ch];
+        const size_t cHW = (size_t)HW;
+        if constexpr (EPI == EPI_CONVP) {
+            const size_t base = ((size_t)eb * a.Cout + ch) * cHW;
+#pragma unroll
+            for (int wy = 0; wy < 2; ++wy)
+#pragma unroll
+                for (int py = 0; py < 2; ++py) {
+                    const int gy = y0 + 4 * rg + 2 * wy + py, gx = x0 + 4 * q;
+                    if (gy >= a.H || gx >= a.W) continue;
+                    f32x4 v4;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v4[j] = relu_f(y[py][j & 1][2 * wy + (j >> 1)] + bb);
+                    *reinterpret_cast<f32x4*>(a.Pout + base + gy * a.W + gx) = v4;
+                }
+        } else {
+            const int Ho = a.H >> 1, Wo = a.W >> 1;
+            const size_t plane = (size_t)Ho * Wo;
+            const size_t pb = ((size_t)eb * a.Cout + ch) * plane;
+            const size_t e0 = ((size_t)eb * 2 * a.Cout + ch) * plane, e1 = e0 + (size_t)a.Cout * plane;
+#pragma unroll
+            for (int wy = 0; wy < 2; ++wy) {
+                const int oy = (y0 >> 1) + 2 * rg + wy, ox = (x0 >> 1) + 2 * q;
+                if (oy >= Ho || ox >= Wo) continue;
+                const f32x2 p2 = *reinterpret_cast<const f32x2*>(a.P + pb + oy * Wo + ox);
+                f32x2 ea, eb2;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int r = 2 * wy + j;
+                    const float v00 = relu_f(y[0][0][r] + bb), v01 = relu_f(y[0][1][r] + bb), v10 = relu_f(y[1][0][r] + bb), v11 = relu_f(y[1][1][r] + bb);
+                    const float A = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+                    ea[j] = relu_f(A - p2[j]);
+                    eb2[j] = relu_f(p2[j] - A);
+                }
+                *reinterpret_cast<f32x2*>(a.E + e0 + oy * Wo + ox) = ea;
+                *reinterpret_cast<f32x2*>(a.E + e1 + oy * Wo + ox) = eb2;
+            }
+        }
     }
 #undef EIG16_WAITCNT
 #undef EIG16_IS_UP

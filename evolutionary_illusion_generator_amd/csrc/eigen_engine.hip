@@ -18,7 +18,7 @@
 #include "conv_wino.h"
 #include "conv_wino16.h"
 #ifndef EIGEN_WINO16_DEFAULT
-#define EIGEN_WINO16_DEFAULT 1
+#define EIGEN_WINO16_DEFAULT 7
 #endif
 #include "cppn_kernel.h"
 #include "farneback_kernels.h"
@@ -563,15 +563,18 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             hipLaunchKernelGGL(kern, dim3(g), dim3(WINO_THREADS), lds, st, a);
         };
         const bool m4 = mode != 0;
-        // EIGEN_WINO16: the ConvLSTM on sixteen waves per block (conv_wino16.h; same results)
+        // EIGEN_WINO16: bit mask of the operators on sixteen waves per block (conv_wino16.h; same results): 1 ConvLSTM, 2 ConvA, 4 ConvP
         static const int wino16 = getenv("EIGEN_WINO16") ? atoi(getenv("EIGEN_WINO16")) : EIGEN_WINO16_DEFAULT;
-        if (mode == 8 && wino16 && op.epi == EPI_LSTM && a.acc_init == nullptr) {
-            const int lds = wino16_lds_bytes();
-            static bool attr16 = false;
-            if (!attr16) { attr16 = true; (void)hipFuncSetAttribute((const void*)wino16_lstm_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds); }
+        auto go16 = [&](auto kern, int ni) {
+            const int lds = wino16_lds_bytes(ni);
+            static std::unordered_set<const void*> attr_done;
+            if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
             op.last_waves = 16;
-            hipLaunchKernelGGL(wino16_lstm_kernel, dim3(g), dim3(WINO16_THREADS), lds, st, a);
-        }
+            hipLaunchKernelGGL(kern, dim3(g), dim3(WINO16_THREADS), lds, st, a);
+        };
+        if (mode == 8 && (wino16 & 1) && op.epi == EPI_LSTM && a.acc_init == nullptr) go16(wino16_kernel<4, EPI_LSTM>, 4);
+        else if (mode == 8 && (wino16 & 2) && op.epi == EPI_CONVA) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVA>, 4); else go16(wino16_kernel<3, EPI_CONVA>, 3); }
+        else if (mode == 8 && (wino16 & 4) && op.epi == EPI_CONVP) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVP>, 4); else go16(wino16_kernel<3, EPI_CONVP>, 3); }
         else if (mode == 8) {
             if (op.epi == EPI_LSTM) go(wino_kernel<4, EPI_LSTM, 8>, 4, true);
             else if (op.epi == EPI_CONVA && op.NI == 4) go(wino_kernel<4, EPI_CONVA, 8>, 4, true);
