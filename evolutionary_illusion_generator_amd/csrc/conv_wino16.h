@@ -203,8 +203,6 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
         float* const vnext = Vb + ((kb + 1) & 1) * W16_V_FLOATS + tch * W16_VS + (lane ^ ((tch & 1) << 4));
         // waves 8-15: the U slab of K-block kb + 1 and the plane of K-block kb + 2 (its buffer held K-block kb: read out by wave tch at the top of
         // K-block kb - 1, a barrier ago); waves 0-7: the patch of K-block kb + 1 (its plane landed before the barrier in front of this K-block)
-        if constexpr (!LAST) { if constexpr (!XF) { dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); dma_raw(kb + 2); } else read_patch(kb + 1); }
-        else if constexpr (EPI == EPI_LSTM) state_loads();
         float t[4][4];
         float av[2][2];
         float bv[2][2][NI];
@@ -223,7 +221,9 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
                 }
             }
         };
-        fetch(0, 0);
+        fetch(0, 0);   // (first: the operands of chunk 0 are in flight while the DMAs below are issued)
+        if constexpr (!LAST) { if constexpr (XF) read_patch(kb + 1); }
+        else if constexpr (EPI == EPI_LSTM) state_loads();
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int pp = c & 1;
@@ -235,6 +235,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
                 for (int ni = 0; ni < NI; ++ni)
                     acc[2 * pp + u][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u][ni], acc[2 * pp + u][ni], 0, 0, 0);
             }
+            if constexpr (!LAST && !XF) { if (c == 0) { dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); dma_raw(kb + 2); } }   // (behind the first MFMAs)
             if constexpr (!LAST && XF) {
                 if (c == 0) {
 #pragma unroll
