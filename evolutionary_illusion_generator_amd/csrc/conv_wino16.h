@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
             }
         };
         fetch(0, 0);   // (first: the operands of chunk 0 are in flight while the DMAs below are issued)
-        if constexpr (!LAST) { if constexpr (XF) read_patch(kb + 1); }
+        if constexpr (!LAST) { if constexpr (!XF) { dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); dma_raw(kb + 2); } else read_patch(kb + 1); }
         else if constexpr (EPI == EPI_LSTM) state_loads();
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -235,7 +235,6 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
                 for (int ni = 0; ni < NI; ++ni)
                     acc[2 * pp + u][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][u], bv[c & 1][u][ni], acc[2 * pp + u][ni], 0, 0, 0);
             }
-            if constexpr (!LAST && !XF) { if (c == 0) { dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); dma_raw(kb + 2); } }   // (behind the first MFMAs)
             if constexpr (!LAST && XF) {
                 if (c == 0) {
 #pragma unroll
