@@ -93,8 +93,8 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     }
     const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
-    auto dma_raw = [&](int kb) __attribute__((always_inline)) {   // (conv_wino.h: dma_raw) -> the plane of K-block kb's parity
-        float* const rawp = planes + (kb & 1) * PLANE_PAR;
+    auto dma_raw = [&](int kb, int par) __attribute__((always_inline)) {   // (conv_wino.h: dma_raw) -> the plane of K-block kb's parity (par = kb & 1)
+        float* const rawp = planes + par * PLANE_PAR;
         const bool up = EIG16_IS_UP(kb);
         const bool s1 = kb >= nkb0 + nkbu;
         const unsigned long long mu = 0ull - (unsigned long long)up, m1 = 0ull - (unsigned long long)(s1 && !up);
@@ -114,9 +114,9 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     const int rd_off_u = t_ty * 24 + t_tx + 3;
     const float* const pbase_n = planes + rd_off;
     const float* const pbase_u = planes + rd_off_u;
-    auto read_patch = [&](int kb) __attribute__((always_inline)) {   // (conv_wino.h: read_patch) <- the plane of K-block kb's parity
+    auto read_patch = [&](int kb, int par) __attribute__((always_inline)) {   // (conv_wino.h: read_patch) <- the plane of K-block kb's parity (par = kb & 1)
         const bool up = EIG16_IS_UP(kb);
-        const float* const p00 = (up ? pbase_u : pbase_n) + (kb & 1) * PLANE_PAR;
+        const float* const p00 = (up ? pbase_u : pbase_n) + par * PLANE_PAR;
         const float* const p10 = p00 - (up ? 24 : 0);
         const int cs = up ? 1 : 0;
 #pragma unroll
@@ -161,14 +161,14 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
 
     // ---- prologue: the planes of K-blocks 0 and 1 and the U slab of K-block 0 (waves 8-15); K-block 0 transformed (waves 0-7)
     if (!xf) {
-        dma_raw(0);
-        dma_raw(1);
+        dma_raw(0, 0);
+        dma_raw(1, 1);
         dma_u(0, Ub);
         EIG16_WAITCNT(0x0F70);
     }
     __syncthreads();
     if (xf) {
-        read_patch(0);
+        read_patch(0, 0);
         EIG16_WAITCNT(0xC07F);
         transform(Vb);
     }
@@ -193,14 +193,17 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     // kind_tag: 0 = a full K-block (no skip tests in the instruction stream: they cost this kernel 4 %), 1 = an unpooled-source K-block, 2 = run time
     // role_tag: the wave's role (true: transforming wave) as a compile-time constant -- the K loops exist once per role behind ONE wave-uniform
     // branch, so that no value defined on one role's path only (the transform's registers) needs a definition on the other's
-    auto kiter = [&](const int kb, auto last_tag, auto kind_tag, auto role_tag) __attribute__((always_inline)) {
+    // par_tag: kb & 1 as a compile-time constant (0, 1: the LDS addresses of the K-block's buffers become instruction offsets) or 2 = run time
+    auto kiter = [&](const int kb, auto last_tag, auto kind_tag, auto role_tag, auto par_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
         constexpr int KIND = decltype(kind_tag)::value;
         constexpr bool XF = decltype(role_tag)::value;
+        constexpr int PARC = decltype(par_tag)::value;
+        const int par = PARC == 2 ? (kb & 1) : PARC;
         const unsigned skip = KIND == 0 ? 0u : KIND == 1 ? wave_skip : (EIG16_IS_UP(kb) ? wave_skip : 0u);
-        const float* const vcur = Vb + (kb & 1) * W16_V_FLOATS;
-        const float* const ucur = Ub + (kb & 1) * WINO_U_FLOATS;
-        float* const vnext = Vb + ((kb + 1) & 1) * W16_V_FLOATS + tch * W16_VS + (lane ^ ((tch & 1) << 4));
+        const float* const vcur = Vb + par * W16_V_FLOATS;
+        const float* const ucur = Ub + par * WINO_U_FLOATS;
+        float* const vnext = Vb + (1 - par) * W16_V_FLOATS + tch * W16_VS + (lane ^ ((tch & 1) << 4));
         // waves 8-15: the U slab of K-block kb + 1 and the plane of K-block kb + 2 (its buffer held K-block kb: read out by wave tch at the top of
         // K-block kb - 1, a barrier ago); waves 0-7: the patch of K-block kb + 1 (its plane landed before the barrier in front of this K-block)
         float t[4][4];
@@ -222,7 +225,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
             }
         };
         fetch(0, 0);   // (first: the operands of chunk 0 are in flight while the DMAs below are issued)
-        if constexpr (!LAST) { if constexpr (!XF) { dma_u(kb + 1, Ub + ((kb + 1) & 1) * WINO_U_FLOATS); dma_raw(kb + 2); } else read_patch(kb + 1); }
+        if constexpr (!LAST) { if constexpr (!XF) { dma_u(kb + 1, Ub + (1 - par) * WINO_U_FLOATS); dma_raw(kb + 2, par); } else read_patch(kb + 1, 1 - par); }
         else if constexpr (EPI == EPI_LSTM) state_loads();
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -258,13 +261,21 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     };
     auto kloops = [&](auto role_tag) __attribute__((always_inline)) {
         int kb = 0;
+        const std::false_type nl{};
+        const std::integral_constant<int, 0> p0{};
+        const std::integral_constant<int, 1> p1{};
+        auto run = [&](const int end, auto kind_tag) __attribute__((always_inline)) {   // K-blocks [kb, end) of one kind, in (even, odd) pairs
+            if (kb < end && (kb & 1)) { kiter(kb, nl, kind_tag, role_tag, p1); ++kb; }
+            for (; kb + 1 < end; kb += 2) { kiter(kb, nl, kind_tag, role_tag, p0); kiter(kb + 1, nl, kind_tag, role_tag, p1); }
+            if (kb < end) { kiter(kb, nl, kind_tag, role_tag, p0); ++kb; }
+        };
         const int e1 = up_lo < nkb - 1 ? up_lo : nkb - 1, e2 = up_hi < nkb - 1 ? up_hi : nkb - 1;
-        for (; kb < e1; ++kb) kiter(kb, std::false_type{}, std::integral_constant<int, 0>{}, role_tag);
-        for (; kb < e2; ++kb) kiter(kb, std::false_type{}, std::integral_constant<int, 1>{}, role_tag);
-        for (; kb < nkb - 1; ++kb) kiter(kb, std::false_type{}, std::integral_constant<int, 0>{}, role_tag);
+        run(e1, std::integral_constant<int, 0>{});
+        run(e2, std::integral_constant<int, 1>{});
+        run(nkb - 1, std::integral_constant<int, 0>{});
     };
     if (xf) kloops(std::true_type{}); else kloops(std::false_type{});
-    kiter(nkb - 1, std::true_type{}, std::integral_constant<int, 2>{}, std::false_type{});
+    kiter(nkb - 1, std::true_type{}, std::integral_constant<int, 2>{}, std::false_type{}, std::integral_constant<int, 2>{});
 
     // ---- output transform.  Columns in-lane: c_xi,0 = (M_xi0 + M_xi1) + M_xi2, c_xi,1 = (M_xi1 - M_xi2) - M_xi3.
     f32x4 cc[2][NI];
