@@ -20,6 +20,12 @@
 namespace eig {
 
 constexpr int WINO16_THREADS = 1024;
+#ifndef EIG_W16_TRIM_UP
+#define EIG_W16_TRIM_UP 1      // (0: every K-block's patch through the full 4 x 4 transform -- A/B builds)
+#endif
+#ifndef EIG_W16_CONST_SKIP
+#define EIG_W16_CONST_SKIP 1   // (0: the skipped positions of an unpooled-source K-block as a scalar bit mask tested at run time -- A/B builds)
+#endif
 // LDS image of this kernel: V [2][16 pos][8 ch][64 tiles] WITHOUT padding -- tile index XOR 16 on odd channels keeps the k-slots q, q + 1 of an
 // operand read on disjoint banks -- (64 KB), U [2][16][8][16][4] (64 KB), and TWO planes per channel (K-blocks of even / odd index: 27 KB)
 constexpr int W16_VS = 64;
@@ -126,6 +132,17 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
             d[i][0] = pl[0]; d[i][1] = pl[1]; d[i][2] = pr[2]; d[i][3] = pr[3];
         }
     };
+    auto read_patch_up = [&](int par) __attribute__((always_inline)) {   // read_patch of a K-block known to be an unpooled-source one: d[2] = d[1], d[.][2] = d[.][1]
+        const float* const p00 = pbase_u + par * PLANE_PAR;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (i == 2) continue;
+            const float* const pl = p00 + (i == 3 ? 2 : i) * 24;
+            d[i][0] = pl[0]; d[i][1] = pl[1]; d[i][2] = d[i][1]; d[i][3] = pl[2];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[2][j] = d[1][j];
+    };
     auto transform = [&](float* vbuf) __attribute__((always_inline)) {   // (conv_wino.h: transform)
         float t[4][4];
 #pragma unroll
@@ -191,16 +208,23 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     // an unpooled-source K-block: nu = 2 is a chain of zeros for every xi, xi = 2 entirely
     const unsigned wave_skip = xi == 2 ? 0xFu : 0x4u;
     // kind_tag: 0 = a full K-block (no skip tests in the instruction stream: they cost this kernel 4 %), 1 = an unpooled-source K-block, 2 = run time
-    // role_tag: the wave's role (true: transforming wave) as a compile-time constant -- the K loops exist once per role behind ONE wave-uniform
+    // role_tag: the wave's role as a compile-time constant (1: transforming wave, xi = 0 / 1; 0: U-fetching wave; 2: U-fetching wave with xi = 2, whose
+    // positions an unpooled-source K-block skips entirely; 3: not known at compile time) -- the K loops exist once per role behind ONE wave-uniform
     // branch, so that no value defined on one role's path only (the transform's registers) needs a definition on the other's
     // par_tag: kb & 1 as a compile-time constant (0, 1: the LDS addresses of the K-block's buffers become instruction offsets) or 2 = run time
-    auto kiter = [&](const int kb, auto last_tag, auto kind_tag, auto role_tag, auto par_tag) __attribute__((always_inline)) {
+    // trim_tag: K-block kb + 1 is KNOWN to be an unpooled-source K-block -- its patch has rows 1 = 2 and columns 1 = 2, so the transform's row 2 and
+    // column 2 are exact zeros that no wave reads (the skipped positions): 9 patch reads, 18 additions and 9 LDS writes instead of 16 / 32 / 16
+    auto kiter = [&](const int kb, auto last_tag, auto kind_tag, auto role_tag, auto par_tag, auto trim_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
+        constexpr bool TRIM = EIG_W16_TRIM_UP && decltype(trim_tag)::value;
         constexpr int KIND = decltype(kind_tag)::value;
-        constexpr bool XF = decltype(role_tag)::value;
+        constexpr int ROLE = decltype(role_tag)::value;
+        constexpr bool XF = ROLE == 1;
         constexpr int PARC = decltype(par_tag)::value;
         const int par = PARC == 2 ? (kb & 1) : PARC;
-        const unsigned skip = KIND == 0 ? 0u : KIND == 1 ? wave_skip : (EIG16_IS_UP(kb) ? wave_skip : 0u);
+        // the positions an unpooled-source K-block skips are a compile-time constant of the role (no scalar tests, no operand reads for them)
+        constexpr bool CSKIP = EIG_W16_CONST_SKIP && KIND == 1 && ROLE != 3;
+        const unsigned skip = KIND == 0 ? 0u : CSKIP ? (ROLE == 2 ? 0xFu : 0x4u) : KIND == 1 ? wave_skip : (EIG16_IS_UP(kb) ? wave_skip : 0u);
         const float* const vcur = Vb + par * W16_V_FLOATS;
         const float* const ucur = Ub + par * WINO_U_FLOATS;
         float* const vnext = Vb + (1 - par) * W16_V_FLOATS + tch * W16_VS + (lane ^ ((tch & 1) << 4));
@@ -213,6 +237,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
             const int ks = c >> 1, pp = c & 1;
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
+                if (CSKIP && ((skip >> (2 * pp + u)) & 1)) continue;
                 av[slot][u] = vcur[a_off + ((2 * pp + u) * KC + ks * 4) * W16_VS];
                 const float* const bsrc = ucur + b_off + ((2 * pp + u) * KC + ks * 4) * 16 * NI;
                 if constexpr (NI == 4) {
@@ -225,7 +250,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
             }
         };
         fetch(0, 0);   // (first: the operands of chunk 0 are in flight while the DMAs below are issued)
-        if constexpr (!LAST) { if constexpr (!XF) { dma_u(kb + 1, Ub + (1 - par) * WINO_U_FLOATS); dma_raw(kb + 2, par); } else read_patch(kb + 1, 1 - par); }
+        if constexpr (!LAST) { if constexpr (!XF) { dma_u(kb + 1, Ub + (1 - par) * WINO_U_FLOATS); dma_raw(kb + 2, par); } else if constexpr (TRIM) read_patch_up(1 - par); else read_patch(kb + 1, 1 - par); }
         else if constexpr (EPI == EPI_LSTM) state_loads();
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -247,9 +272,10 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
                 } else if (c < 3) {
 #pragma unroll
                     for (int i = 2 * (c - 1); i < 2 * c; ++i) {
+                        if (TRIM && i == 2) continue;
                         vnext[(i * 4 + 0) * KC * W16_VS] = t[i][0] - t[i][2];
                         vnext[(i * 4 + 1) * KC * W16_VS] = t[i][1] + t[i][2];
-                        vnext[(i * 4 + 2) * KC * W16_VS] = t[i][2] - t[i][1];
+                        if (!TRIM) vnext[(i * 4 + 2) * KC * W16_VS] = t[i][2] - t[i][1];
                         vnext[(i * 4 + 3) * KC * W16_VS] = t[i][1] - t[i][3];
                     }
                 }
@@ -264,18 +290,22 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
         const std::false_type nl{};
         const std::integral_constant<int, 0> p0{};
         const std::integral_constant<int, 1> p1{};
-        auto run = [&](const int end, auto kind_tag) __attribute__((always_inline)) {   // K-blocks [kb, end) of one kind, in (even, odd) pairs
-            if (kb < end && (kb & 1)) { kiter(kb, nl, kind_tag, role_tag, p1); ++kb; }
-            for (; kb + 1 < end; kb += 2) { kiter(kb, nl, kind_tag, role_tag, p0); kiter(kb + 1, nl, kind_tag, role_tag, p1); }
-            if (kb < end) { kiter(kb, nl, kind_tag, role_tag, p0); ++kb; }
+        auto run = [&](const int end, auto kind_tag, auto trim_tag) __attribute__((always_inline)) {   // K-blocks [kb, end) of one kind, in (even, odd) pairs
+            if (kb < end && (kb & 1)) { kiter(kb, nl, kind_tag, role_tag, p1, trim_tag); ++kb; }
+            for (; kb + 1 < end; kb += 2) { kiter(kb, nl, kind_tag, role_tag, p0, trim_tag); kiter(kb + 1, nl, kind_tag, role_tag, p1, trim_tag); }
+            if (kb < end) { kiter(kb, nl, kind_tag, role_tag, p0, trim_tag); ++kb; }
         };
         const int e1 = up_lo < nkb - 1 ? up_lo : nkb - 1, e2 = up_hi < nkb - 1 ? up_hi : nkb - 1;
-        run(e1, std::integral_constant<int, 0>{});
-        run(e2, std::integral_constant<int, 1>{});
-        run(nkb - 1, std::integral_constant<int, 0>{});
+        run(e1, std::integral_constant<int, 0>{}, std::false_type{});
+        // unpooled-source K-blocks: all but the last of them transform the patch of another unpooled-source K-block (kb + 1 < up_hi)
+        if constexpr (EIG_W16_TRIM_UP && decltype(role_tag)::value == 1) run(up_hi - 1 < e2 ? up_hi - 1 : e2, std::integral_constant<int, 1>{}, std::true_type{});
+        run(e2, std::integral_constant<int, 1>{}, std::false_type{});
+        run(nkb - 1, std::integral_constant<int, 0>{}, std::false_type{});
     };
-    if (xf) kloops(std::true_type{}); else kloops(std::false_type{});
-    kiter(nkb - 1, std::true_type{}, std::integral_constant<int, 2>{}, std::false_type{}, std::integral_constant<int, 2>{});
+    if (xf) kloops(std::integral_constant<int, 1>{});
+    else if (EIG_W16_CONST_SKIP && EPI == EPI_LSTM && xi == 2) kloops(std::integral_constant<int, 2>{});
+    else kloops(std::integral_constant<int, EIG_W16_CONST_SKIP ? 0 : 3>{});
+    kiter(nkb - 1, std::true_type{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, std::false_type{});
 
     // ---- output transform.  Columns in-lane: c_xi,0 = (M_xi0 + M_xi1) + M_xi2, c_xi,1 = (M_xi1 - M_xi2) - M_xi3.
     f32x4 cc[2][NI];
