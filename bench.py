@@ -335,6 +335,22 @@ def conv_roofline(eng, fitness_mod, workload, nb):
     return rows, all_fl, allc
 
 
+def survey_8d_convlstm_macs(channels, W, H, l):
+    """multiply-adds of ConvLSTM_l per genome and PredNet step in the REFERENCE's formulation -- 3x3 taps
+    on every source (E_l: 2 C_l channels, the unpooled R_{l+1}: C_{l+1}, h_l: C_l), 4 gates x C_l outputs at H_l x W_l."""
+    C = channels[l]
+    cin = 2 * C + C + (channels[l + 1] if l + 1 < len(channels) else 0)
+    return 4.0 * C * (H >> l) * (W >> l) * cin * 9
+
+
+def convlstm_algorithmic_bytes(channels, W, H, l):
+    """Algorithmic HBM bytes of one ConvLSTM_l launch PER GENOME: every source once (E_l, h_l at H_l x W_l, R_{l+1} at half of it), the cell
+    state in and out, h out; fp32."""
+    C, px = channels[l], (H >> l) * (W >> l)
+    src = (2 * C + C) * px + (channels[l + 1] * (px // 4) if l + 1 < len(channels) else 0)
+    return 4.0 * (src + 2 * C * px + C * px)
+
+
 def make_workload(shape_name, global_pop):
     from evolutionary_illusion_generator_amd import synth, weights
     W, H, CHANNELS, C_DIM, STRUCTURE, n_hidden, n_outputs, _, _ = SHAPES[shape_name]
@@ -371,7 +387,7 @@ def supplementary_shape(name, pop, steps, warmup=1):
            "value": pop * steps / dt, "unit": "genome evals/s", "steps": steps, "ms_per_step": 1e3 * dt / steps, "device_batch": max_batch,
            "nonzero_fitness": int((fit != 0).sum()),
            "all_conv_frac": allc["frac"], "all_conv_tflops": allc["achieved"], "conv_launches": allc["launches"],
-           "effective_tflops_reference_formulation": flops_ref * pop * steps / dt / 1e12}
+           "tflops_on_survey_8d_flops": flops_ref * pop * steps / dt / 1e12}
     return out
 
 
@@ -535,7 +551,7 @@ def main():
         # (separate runs of this command: scripts/pmc_passes.sh + scripts/summarize_pmc.py; FETCH_SIZE doubled as
         # MI355X_MICROARCH.md prescribes for 16 B/lane reads).  The summary is stamped with the hash of the kernel sources
         # it was taken on; a summary of another build is NOT reported (traffic = null).
-        traffic, traffic_commit, traffic_note = None, None, None
+        traffic, traffic_commit, traffic_note, mfma_insts = None, None, None, None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_latest.json")))
             traffic_commit = pm.get("commit")
@@ -550,29 +566,49 @@ def main():
                     hit = [kv for kname, kv in pm["kernels"].items() if tag in kname]
                     if hit:
                         traffic = hit[0].get("hbm_read_bytes_per_launch", 0.0) + hit[0].get("hbm_write_bytes_per_launch", 0.0)
+                        if hit[0].get("counters", {}).get("SQ_INSTS_MFMA") and hit[0].get("calls"):
+                            mfma_insts = hit[0]["counters"]["SQ_INSTS_MFMA"] / hit[0]["calls"]
                         break
         except Exception as e:  # noqa: BLE001
             traffic_note = "no PMC summary: %s" % e
         flops_step = eng.flops_per_step()
         wino_rows = [r for r in lstm if r.get("wino")]
-        direct_fl = sum((r["flops_per_image"] * (36.0 / 16.0 if r.get("wino") else 1.0)) * nb * r["launches"] for r in lstm)  # the same launches as 9-tap chains
+        secs = ms * 1e-3
+        # the reference's formulation of the SAME launches -- 9 taps on every source, every step (the step-0
+        # launch counted like any other).  Computed here from the layer shapes, not from what the kernel executes.
+        s8d_layer = {l_: survey_8d_convlstm_macs(CHANNELS, W, H, l_) for l_ in sorted({r["layer"] for r in lstm})}
+        s8d_fl = sum(2.0 * s8d_layer[r["layer"]] * nb * r["launches"] for r in lstm)
+        alg_bytes = {l_: convlstm_algorithmic_bytes(CHANNELS, W, H, l_) * nb for l_ in s8d_layer}
+        launches_l = {l_: sum(r["launches"] for r in lstm if r["layer"] == l_) for l_ in s8d_layer}
+        alg_bytes_avg = sum(alg_bytes[l_] * launches_l[l_] for l_ in alg_bytes) / max(n_l, 1)
         out["roofline"] = {"bound": "mfma", "kernel": ("wino16_kernel<4,EPI_LSTM> (EIGEN_WINO16=0: wino_kernel<4,EPI_LSTM,8>) (ConvLSTM, E / unpooled R / h chains as Winograd F(2x2,3x3): 16 of 36 multiply-adds, fused gates, v_mfma_f32_16x16x4_f32)"
                                                        if wino_rows else "conv3x3_mfma<4,16,EPI_LSTM> (fused ConvLSTM gates, v_mfma_f32_16x16x4_f32)"),
                            "winograd_layers": sorted({r["layer"] for r in wino_rows}),
-                           "dominant_kernel_tflops_as_direct_convolution": direct_fl / (ms * 1e-3) / 1e12,
-                           # SURVEY 8(d)'s ALGORITHMIC count (9 taps on every source) over the same time: > 1 means multiply-adds avoided, not a faster pipe
-                           "frac_on_algorithmic_flops": direct_fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                           "frac_note": ("`achieved` / `frac` count the multiply-adds the kernel EXECUTES (Winograd: 16 per channel and 2x2 outputs); the same launches "
-                                         "as 9-tap convolutions are `dominant_kernel_tflops_as_direct_convolution`, which may exceed the fp32 MFMA peak") if wino_rows else None,
+                           # `achieved` / `frac`: the multiply-adds the kernel EXECUTES (= SQ_INSTS_MFMA x 2048 FLOP, checkable below) over its HIP-event time
                            "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                           "launches": n_l, "avg_launch_ms": ms / max(n_l, 1),
+                           "executed_flops_per_launch": fl / max(n_l, 1),
+                           "mfma_insts_per_launch": mfma_insts, "flop_per_mfma_inst": 2048,
+                           "executed_flops_per_launch_from_counter": (mfma_insts * 2048.0) if mfma_insts else None,
+                           # SURVEY 8(d)'s ALGORITHMIC count of the same launches; a fraction > 1 = multiply-adds avoided (Winograd 16 of 36, the
+                           # unpooled source 9 of 36, zero sources skipped at step 0), never a faster pipe
+                           "survey_8d_flops_per_launch": s8d_fl / max(n_l, 1),
+                           "survey_8d_gmac_per_genome_step_by_layer": {str(l_): v / 1e9 for l_, v in s8d_layer.items()},
+                           "survey_8d_tflops": s8d_fl / secs / 1e12,
+                           "frac_on_survey_8d_flops": s8d_fl / secs / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                           "executed_over_survey_8d": fl / s8d_fl if s8d_fl else None,
+                           "frac_note": "`frac` = executed multiply-adds / time / peak; `frac_on_survey_8d_flops` = SURVEY 8(d)'s 9-tap count of the same launches / the same time / peak",
                            "traffic": traffic, "traffic_commit": traffic_commit, "traffic_note": traffic_note,
                            "traffic_source": "profiles/pmc_summary_latest.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
-                           "launches": n_l, "avg_launch_ms": ms / max(n_l, 1),
-                           "algorithmic_flops_per_launch": fl / max(n_l, 1),
-                           # the reference's formulation (9 taps on every source) vs what this build executes
-                           "algorithmic_flops_reference_per_genome": flops_step * N_STEPS_PREDNET,
+                           # algorithmic HBM bytes of a launch: every source once + c in / out + h out (peepholes and weights are shared by the batch)
+                           "traffic_algorithmic_bytes_by_layer": {str(l_): v for l_, v in alg_bytes.items()},
+                           "traffic_algorithmic_bytes": alg_bytes_avg,
+                           "traffic_over_algorithmic": (traffic / alg_bytes_avg) if traffic else None,
+                           # whole path: the reference's formulation (9 taps on every source) vs what this build executes
+                           "survey_8d_flops_per_genome": flops_step * N_STEPS_PREDNET,
                            "executed_flops_per_genome": all_fl / nb,
-                           "effective_tflops_reference_formulation": flops_step * N_STEPS_PREDNET * out["value"] / 1e12,
+                           "whole_path_tflops_on_survey_8d_flops": flops_step * N_STEPS_PREDNET * out["value"] / 1e12,
+                           "whole_path_frac_on_executed_flops": (all_fl / nb) * out["value"] / 1e12 / PEAK_F32_MFMA_TFLOPS,
                            "all_conv_kernels": allc,
                            "per_op": [{"layer": r["layer"], "op": r["epi"] + ("(step 0: zero sources skipped)" if r.get("step0") else ""), "ms": round(r["ms"], 3), "launches": r["launches"],
                                        "tflops": (r["flops_per_image"] * nb * r["launches"] / (r["ms"] * 1e-3) / 1e12) if r["ms"] > 0 else 0.0}

@@ -40,6 +40,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
     constexpr int WINO_U_FLOATS = wino_u_floats(NI);
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py)
     float* const Vb = lds;
     float* const Ub = lds + 2 * W16_V_FLOATS;
     const int tid = threadIdx.x;
@@ -177,6 +178,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     const int b_off = ((xi * 4 * KC + q) * 16 + col) * NI;           // U[pos][ch][col][0..3]
 
     // ---- prologue: the planes of K-blocks 0 and 1 and the U slab of K-block 0 (waves 8-15); K-block 0 transformed (waves 0-7)
+    const unsigned long long tq_setup = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     if (!xf) {
         dma_raw(0, 0);
         dma_raw(1, 1);
@@ -191,6 +193,19 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     }
     EIG16_WAITCNT(0x0070);
     __syncthreads();
+    const unsigned long long tq_k0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
+    unsigned long long tq_k1 = 0, tq_x = 0, tq_y = 0;
+    // [entry, set-up done, K loop start, K loop end, exchange barrier passed, y ready (gates start), exit, HW_ID | XCC_ID << 32]
+    auto timeline = [&]() __attribute__((always_inline)) {
+        if (EIG_TIMING && a.dbg && lane == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* dd = a.dbg + ((size_t)blockIdx.x * 16 + wv) * 8;
+            dd[0] = tq_entry; dd[1] = tq_setup; dd[2] = tq_k0; dd[3] = tq_k1; dd[4] = tq_x; dd[5] = tq_y; dd[6] = __builtin_readcyclecounter();
+            dd[7] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+        }
+    };
 
     // the cell state and the three peephole values of the lane's 4-pixel segment, fetched during the LAST K-block
     const int ra = xi >> 1, seg = xi & 1;   // this wave finishes output row parity ra of segment seg
@@ -306,6 +321,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     else if (EIG_W16_CONST_SKIP && EPI == EPI_LSTM && xi == 2) kloops(std::integral_constant<int, 2>{});
     else kloops(std::integral_constant<int, EIG_W16_CONST_SKIP ? 0 : 3>{});
     kiter(nkb - 1, std::true_type{}, std::integral_constant<int, 2>{}, std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{}, std::false_type{});
+    if (EIG_TIMING) tq_k1 = __builtin_readcyclecounter();
 
     // ---- output transform.  Columns in-lane: c_xi,0 = (M_xi0 + M_xi1) + M_xi2, c_xi,1 = (M_xi1 - M_xi2) - M_xi3.
     f32x4 cc[2][NI];
@@ -322,6 +338,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(xb + ((wv * 8 + b * 4 + ni) * 64 + lane) * 4) = cc[b][ni];
     __syncthreads();
+    if (EIG_TIMING) tq_x = __builtin_readcyclecounter();
     if constexpr (EPI == EPI_LSTM) {
         float y[2][NI][2];   // [b = px][ni][window 2 seg + k]
     #pragma unroll
@@ -334,13 +351,14 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     #pragma unroll
                 for (int k = 0; k < 2; ++k) y[b][ni][k] = ra ? c1[k] - (c2[k] + c03[k]) : (c03[k] + c1[k]) + c2[k];
             }
+        if (EIG_TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq_y = __builtin_readcyclecounter(); }
         const int ch = nblk * 16 + col;
-        if (ch >= a.Cout) return;
+        if (ch >= a.Cout) { timeline(); return; }
         const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
         const size_t cbase = ((size_t)eb * a.Cout + ch) * (size_t)HW;
         {
             const int gy = y0 + 4 * rg + ra + 2 * seg, gx = x0 + 4 * q;
-            if (gy >= a.H || gx >= a.W) return;
+            if (gy >= a.H || gx >= a.W) { timeline(); return; }
             const int pix = gy * a.W + gx;
             f32x4 cn4, hn4;
     #pragma unroll
@@ -353,6 +371,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
             *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
             *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
         }
+        timeline();
     } else {
         // N-TILE split: wave (rg, xi) finishes N-tile xi of its region for both row parities (xi = 3 rests where NI = 3): all four parity classes of
         // a window in one lane -- ConvA's max_pooling_2d is the max over a lane's four values, ConvP stores whole 4 x 4-pixel patches (conv_wino.h)
