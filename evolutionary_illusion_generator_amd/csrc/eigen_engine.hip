@@ -17,6 +17,7 @@
 #include "conv_mfma.h"
 #include "conv_wino.h"
 #include "conv_wino16.h"
+#include "conv_winoh.h"
 #ifndef EIGEN_WINO16_DEFAULT
 #define EIGEN_WINO16_DEFAULT 7
 #endif
@@ -384,6 +385,9 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
 #ifndef EIGEN_WINO_DEFAULT
 #define EIGEN_WINO_DEFAULT 0x01FFFFFE
 #endif
+#ifndef EIGEN_WINOH_DEFAULT
+#define EIGEN_WINOH_DEFAULT 0   // (conv_winoh.h; bit mask 1 ConvLSTM, 2 ConvA, 4 ConvP)
+#endif
 static bool wino_op(int mask, int kind, int l, int Cin, int Cout, int H, int W, bool top)
 {
     if (!((mask >> (8 * kind + l)) & 1) || l < 1) return false;
@@ -572,7 +576,20 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             op.last_waves = 16;
             hipLaunchKernelGGL(kern, dim3(g), dim3(WINO16_THREADS), lds, st, a);
         };
-        if (mode == 8 && (wino16 & 1) && op.epi == EPI_LSTM && a.acc_init == nullptr) go16(wino16_kernel<4, EPI_LSTM>, 4);
+        // EIGEN_WINOH: bit mask of the operators on HALF tiles, two co-resident eight-wave blocks per CU (conv_winoh.h; same results): 1 ConvLSTM, 2 ConvA, 4 ConvP
+        static const int winoh = getenv("EIGEN_WINOH") ? atoi(getenv("EIGEN_WINOH")) : EIGEN_WINOH_DEFAULT;
+        auto goh = [&](auto kern) {
+            a.tilesY = (op.H + 7) / 8;
+            const int gh = op.n_nblk * ((batch * a.tilesX * a.tilesY + 7) / 8) * 8;
+            static std::unordered_set<const void*> attr_done;
+            if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, winoh_lds_bytes());
+            op.last_grid = gh; op.last_waves = 8;
+            hipLaunchKernelGGL(kern, dim3(gh), dim3(WH_THREADS), winoh_lds_bytes(), st, a);
+        };
+        if (mode == 8 && (winoh & 1) && op.epi == EPI_LSTM && a.acc_init == nullptr) goh(winoh_kernel<4, EPI_LSTM>);
+        else if (mode == 8 && (winoh & 2) && op.epi == EPI_CONVA) { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVA>); else goh(winoh_kernel<3, EPI_CONVA>); }
+        else if (mode == 8 && (winoh & 4) && op.epi == EPI_CONVP) { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVP>); else goh(winoh_kernel<3, EPI_CONVP>); }
+        else if (mode == 8 && (wino16 & 1) && op.epi == EPI_LSTM && a.acc_init == nullptr) go16(wino16_kernel<4, EPI_LSTM>, 4);
         else if (mode == 8 && (wino16 & 2) && op.epi == EPI_CONVA) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVA>, 4); else go16(wino16_kernel<3, EPI_CONVA>, 3); }
         else if (mode == 8 && (wino16 & 4) && op.epi == EPI_CONVP) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVP>, 4); else go16(wino16_kernel<3, EPI_CONVP>, 3); }
         else if (mode == 8) {

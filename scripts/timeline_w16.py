@@ -11,6 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 GHZ = float(os.environ.get("EIG_GFX_GHZ", "2.4"))
+NW = int(os.environ.get("EIG_TL_WAVES", "16"))   # waves per block: 16 = conv_wino16.h, 8 = conv_winoh.h (EIGEN_WINOH=7; two blocks per CU)
 out_dir = os.environ.setdefault("EIGEN_TIMELINE", "gpurun_out/tl")
 os.makedirs(out_dir, exist_ok=True)
 if "--analyze-only" not in sys.argv:
@@ -34,9 +35,9 @@ for path in sorted(glob.glob(os.path.join(out_dir, "timeline_H*.bin"))):
     if path.endswith("_up4.bin"):
         continue
     raw = np.fromfile(path, dtype=np.uint64)
-    if raw.size % (16 * 8):
+    if raw.size % (NW * 8):
         continue
-    r = raw.reshape(-1, 16, 8)
+    r = raw.reshape(-1, NW, 8)
     r = r[(r[:, :, 0] != 0).all(axis=1)]
     if not len(r):
         continue
@@ -50,11 +51,23 @@ for path in sorted(glob.glob(os.path.join(out_dir, "timeline_H*.bin"))):
     print("   per wave, mean cycles (us at %.1f GHz): set-up %.0f (%.2f)  prologue DMA + first transform %.0f (%.2f)  K loop %.0f (%.2f)  publish + barrier %.0f (%.2f)  row transform %.0f (%.2f)  gates + stores %.0f (%.2f)"
           % (GHZ, (S - E).mean(), us((S - E).mean()), (K0 - S).mean(), us((K0 - S).mean()), (K1 - K0).mean(), us((K1 - K0).mean()),
              (X - K1).mean(), us((X - K1).mean()), (Y - X).mean(), us((Y - X).mean()), (END - Y).mean(), us((END - Y).mean())))
-    for role, sl in (("transforming waves 0-7", slice(0, 8)), ("fetching waves 8-15", slice(8, 16))):
+    for role, sl in (("transforming waves (first half)", slice(0, NW // 2)), ("fetching waves (second half)", slice(NW // 2, NW))):
         print("   %s: set-up %.0f  prologue %.0f  K loop %.0f  publish+barrier %.0f  row transform %.0f  gates+stores %.0f" % (
             role, (S - E)[:, sl].mean(), (K0 - S)[:, sl].mean(), (K1 - K0)[:, sl].mean(), (X - K1)[:, sl].mean(), (Y - X)[:, sl].mean(), (END - Y)[:, sl].mean()))
     print("   inside a block: first wave in -> last wave in %.0f cycles; first wave out -> last wave out %.0f; K-loop end spread %.0f" % (
         (E.max(axis=1) - E.min(axis=1)).mean(), (END.max(axis=1) - END.min(axis=1)).mean(), (K1.max(axis=1) - K1.min(axis=1)).mean()))
+    # co-resident blocks (conv_winoh.h: two per CU): share of a CU's busy span during which NO block of it is inside its K loop
+    cov, spans, conc = 0.0, 0.0, 0.0
+    for key in np.unique(cu_key):
+        idx = np.nonzero(cu_key == key)[0]
+        ev = sorted([(K0[i].mean(), 1) for i in idx] + [(K1[i].mean(), -1) for i in idx])
+        depth, last, c1, c2 = 0, ev[0][0], 0.0, 0.0
+        for tt, dlt in ev:
+            if depth >= 1: c1 += tt - last
+            if depth >= 2: c2 += tt - last
+            depth += dlt; last = tt
+        cov += c1; conc += c2; spans += ev[-1][0] - ev[0][0]
+    print("   per CU: some block inside its K loop %.1f %% of the span (two or more: %.1f %%) -> matrix pipe without any K loop %.1f %%" % (100 * cov / spans, 100 * conc / spans, 100 * (1 - cov / spans)))
     # successive blocks of a CU
     idle, parts = [], []
     for key in np.unique(cu_key):
@@ -72,6 +85,6 @@ for path in sorted(glob.glob(os.path.join(out_dir, "timeline_H*.bin"))):
         print("   MATRIX PIPE IDLE between the K loops of successive blocks of a CU: mean %.0f cycles = %.2f us (median %.0f, p90 %.0f); K loop %.0f cycles = %.2f us -> idle share %.1f %%"
               % (idle.mean(), us(idle.mean()), np.median(idle), np.percentile(idle, 90), m[8], us(m[8]), 100 * idle.mean() / (idle.mean() + m[8])))
         lab = ["publish + exchange barrier", "row transform (LDS reads)", "gates + stores (mean wave)", "  ... until the LAST wave is out", "last wave out -> first wave of the next block in (dispatcher)",
-               "first wave in -> mean wave in (launch of 16 waves)", "set-up (addresses, descriptors)", "prologue: DMA round trip, first transform, 2 barriers"]
+               "first wave in -> mean wave in (launch of the block's waves)", "set-up (addresses, descriptors)", "prologue: DMA round trip, first transform, 2 barriers"]
         for l_, v in zip(lab, m[:8]):
             print("      %-64s %7.0f cycles  %5.2f us  %4.1f %%" % (l_, v, us(v), 100 * v / idle.mean()))
