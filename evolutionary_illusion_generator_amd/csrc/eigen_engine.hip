@@ -386,7 +386,10 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
 #define EIGEN_WINO_DEFAULT 0x01FFFFFE
 #endif
 #ifndef EIGEN_WINOH_DEFAULT
-#define EIGEN_WINOH_DEFAULT 0   // (conv_winoh.h; bit mask 1 ConvLSTM, 2 ConvA, 4 ConvP)
+#define EIGEN_WINOH_DEFAULT 0   // (conv_winoh.h, half tiles; bit mask 1 ConvLSTM, 2 ConvA, 4 ConvP)
+#endif
+#ifndef EIGEN_WINOF_DEFAULT
+#define EIGEN_WINOF_DEFAULT 0   // (conv_winoh.h, full tiles; bit mask 1 ConvLSTM, 2 ConvA, 4 ConvP)
 #endif
 static bool wino_op(int mask, int kind, int l, int Cin, int Cout, int H, int W, bool top)
 {
@@ -576,19 +579,33 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             op.last_waves = 16;
             hipLaunchKernelGGL(kern, dim3(g), dim3(WINO16_THREADS), lds, st, a);
         };
-        // EIGEN_WINOH: bit mask of the operators on HALF tiles, two co-resident eight-wave blocks per CU (conv_winoh.h; same results): 1 ConvLSTM, 2 ConvA, 4 ConvP
+        // conv_winoh.h (A operands built in-wave, no transformed-input buffer; same results).  EIGEN_WINOH: bit mask of the operators on HALF tiles, two co-resident
+        // eight-wave blocks per CU; EIGEN_WINOF: ... on full 16 x 16 tiles, sixteen waves, K-blocks of eight channels -- 1 ConvLSTM, 2 ConvA, 4 ConvP each
         static const int winoh = getenv("EIGEN_WINOH") ? atoi(getenv("EIGEN_WINOH")) : EIGEN_WINOH_DEFAULT;
-        auto goh = [&](auto kern) {
-            a.tilesY = (op.H + 7) / 8;
+        static const int winof = getenv("EIGEN_WINOF") ? atoi(getenv("EIGEN_WINOF")) : EIGEN_WINOF_DEFAULT;
+        auto goh = [&](auto kern, auto rg_tag, auto ks_tag) {
+            constexpr int RG = decltype(rg_tag)::value, KS = decltype(ks_tag)::value;
+            a.tilesY = (op.H + 4 * RG - 1) / (4 * RG);
             const int gh = op.n_nblk * ((batch * a.tilesX * a.tilesY + 7) / 8) * 8;
+            constexpr int ldsb = winoh_lds_bytes<RG, KS>(), nthr = 256 * RG;
             static std::unordered_set<const void*> attr_done;
-            if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, winoh_lds_bytes());
-            op.last_grid = gh; op.last_waves = 8;
-            hipLaunchKernelGGL(kern, dim3(gh), dim3(WH_THREADS), winoh_lds_bytes(), st, a);
+            if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+            op.last_grid = gh; op.last_waves = 4 * RG;
+            hipLaunchKernelGGL(kern, dim3(gh), dim3(nthr), ldsb, st, a);
         };
-        if (mode == 8 && (winoh & 1) && op.epi == EPI_LSTM && a.acc_init == nullptr) goh(winoh_kernel<4, EPI_LSTM>);
-        else if (mode == 8 && (winoh & 2) && op.epi == EPI_CONVA) { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVA>); else goh(winoh_kernel<3, EPI_CONVA>); }
-        else if (mode == 8 && (winoh & 4) && op.epi == EPI_CONVP) { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVP>); else goh(winoh_kernel<3, EPI_CONVP>); }
+        const int cls = op.epi == EPI_LSTM ? 1 : (op.epi == EPI_CONVA ? 2 : 4);
+        const bool lstm_ok = op.epi != EPI_LSTM || a.acc_init == nullptr;
+        const std::integral_constant<int, 1> k1{}; const std::integral_constant<int, 2> k2{}; const std::integral_constant<int, 4> k4{};
+        if (mode == 8 && (winoh & cls) && lstm_ok) {
+            if (op.epi == EPI_LSTM) goh(winoh_kernel<4, EPI_LSTM, 2, 1>, k2, k1);
+            else if (op.epi == EPI_CONVA) { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVA, 2, 1>, k2, k1); else goh(winoh_kernel<3, EPI_CONVA, 2, 1>, k2, k1); }
+            else { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVP, 2, 1>, k2, k1); else goh(winoh_kernel<3, EPI_CONVP, 2, 1>, k2, k1); }
+        }
+        else if (mode == 8 && (winof & cls) && lstm_ok) {
+            if (op.epi == EPI_LSTM) goh(winoh_kernel<4, EPI_LSTM, 4, 2>, k4, k2);
+            else if (op.epi == EPI_CONVA) { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVA, 4, 2>, k4, k2); else goh(winoh_kernel<3, EPI_CONVA, 4, 2>, k4, k2); }
+            else { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVP, 4, 2>, k4, k2); else goh(winoh_kernel<3, EPI_CONVP, 4, 2>, k4, k2); }
+        }
         else if (mode == 8 && (wino16 & 1) && op.epi == EPI_LSTM && a.acc_init == nullptr) go16(wino16_kernel<4, EPI_LSTM>, 4);
         else if (mode == 8 && (wino16 & 2) && op.epi == EPI_CONVA) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVA>, 4); else go16(wino16_kernel<3, EPI_CONVA>, 3); }
         else if (mode == 8 && (wino16 & 4) && op.epi == EPI_CONVP) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVP>, 4); else go16(wino16_kernel<3, EPI_CONVP>, 3); }

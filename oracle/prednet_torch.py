@@ -24,35 +24,60 @@ def _conv_matmul(x, w, b, padding=1):
 _WINO = {}
 
 
-def _conv_winograd(x, w, b, padding=1):
-    """3x3 'same' convolution as Winograd F(2x2, 3x3) in fp32 throughout (a STUDY of what 2.25x fewer
-    multiply-adds would do to the results; nothing in the product uses it).  Fixed transform order: V = B^T d B per 4x4 input tile
-    (rows first, then columns), U = G g G^T per filter, M = sum_c U * V as one fp32 matmul per tile position (16 of them),
-    Y = A^T M A (rows first).  Needs even H and W."""
+# Winograd F(m x m, 3 x 3) transform matrices (Lavin & Gray 2015 / the wincnn construction; interpolation points 0, +-1, [2 | +-2], inf): (B^T, G, A^T)
+_WINO_MATS = {
+    2: ([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]],
+        [[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]],
+        [[1, 1, 1, 0], [0, 1, -1, -1]]),
+    3: ([[2, -1, -2, 1, 0], [0, -2, -1, 1, 0], [0, 2, -3, 1, 0], [0, -1, 0, 1, 0], [0, 2, -1, -2, 1]],
+        [[.5, 0, 0], [-.5, -.5, -.5], [-1 / 6., 1 / 6., -1 / 6.], [1 / 6., 1 / 3., 2 / 3.], [0, 0, 1]],
+        [[1, 1, 1, 1, 0], [0, 1, -1, 2, 0], [0, 1, 1, 4, 1]]),
+    4: ([[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]],
+        [[.25, 0, 0], [-1 / 6., -1 / 6., -1 / 6.], [-1 / 6., 1 / 6., -1 / 6.], [1 / 24., 1 / 12., 1 / 6.], [1 / 24., -1 / 12., 1 / 6.], [0, 0, 1]],
+        [[1, 1, 1, 1, 1, 0], [0, 1, -1, 2, -2, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]]),
+}
+
+
+def _conv_winograd(x, w, b, padding=1, m=2):
+    """3x3 'same' convolution as Winograd F(m x m, 3 x 3), m = 2, 3 or 4, in fp32 throughout (a STUDY of what
+    2.25x / 3.24x / 4x fewer multiply-adds would do to the results; nothing in the product uses it).  Fixed transform order: V = B^T d B per
+    (m + 2)^2 input tile (rows first, then columns), U = G g G^T per filter, M = sum_c U * V as one fp32 matmul per tile position,
+    Y = A^T M A (rows first).  Maps whose size is not a multiple of m are zero-padded at the bottom / right and cropped."""
     B, C, H, W = x.shape
-    assert padding == 1 and H % 2 == 0 and W % 2 == 0
-    key = (x.device, "m")
+    assert padding == 1
+    key = (x.device, m)
     if key not in _WINO:
-        _WINO[key] = (torch.tensor([[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]], dtype=torch.float32, device=x.device),
-                      torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float32, device=x.device),
-                      torch.tensor([[1, 1, 1, 0], [0, 1, -1, -1]], dtype=torch.float32, device=x.device))
+        _WINO[key] = tuple(torch.tensor(t, dtype=torch.float32, device=x.device) for t in _WINO_MATS[m])
     Bt, G, At = _WINO[key]
+    a = m + 2
     O = w.shape[0]
-    U = torch.matmul(torch.matmul(G, w), G.t())                               # [O, C, 4, 4]
-    xp = F.pad(x, (1, 1, 1, 1))
-    d = xp.unfold(2, 4, 2).unfold(3, 4, 2)                                    # [B, C, H/2, W/2, 4, 4]
-    V = torch.matmul(torch.matmul(Bt, d), Bt.t())                             # [B, C, th, tw, 4, 4]
-    th, tw = H // 2, W // 2
-    Vm = V.permute(4, 5, 1, 0, 2, 3).reshape(16, C, B * th * tw)              # [16, C, tiles]
-    Um = U.permute(2, 3, 0, 1).reshape(16, O, C)                              # [16, O, C]
-    M = torch.bmm(Um, Vm).view(4, 4, O, B, th, tw).permute(3, 2, 4, 5, 0, 1)  # [B, O, th, tw, 4, 4]
-    Y = torch.matmul(torch.matmul(At, M), At.t())                             # [B, O, th, tw, 2, 2]
-    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(B, O, H, W)
+    U = torch.matmul(torch.matmul(G, w), G.t())                               # [O, C, a, a]
+    Hp, Wp = -(-H // m) * m, -(-W // m) * m
+    xp = F.pad(x, (1, 1 + Wp - W, 1, 1 + Hp - H))
+    d = xp.unfold(2, a, m).unfold(3, a, m)                                    # [B, C, Hp/m, Wp/m, a, a]
+    V = torch.matmul(torch.matmul(Bt, d), Bt.t())                             # [B, C, th, tw, a, a]
+    th, tw = Hp // m, Wp // m
+    Vm = V.permute(4, 5, 1, 0, 2, 3).reshape(a * a, C, B * th * tw)           # [a^2, C, tiles]
+    Um = U.permute(2, 3, 0, 1).reshape(a * a, O, C)                           # [a^2, O, C]
+    M = torch.bmm(Um, Vm).view(a, a, O, B, th, tw).permute(3, 2, 4, 5, 0, 1)  # [B, O, th, tw, a, a]
+    Y = torch.matmul(torch.matmul(At, M), At.t())                             # [B, O, th, tw, m, m]
+    y = Y.permute(0, 1, 2, 4, 3, 5).reshape(B, O, Hp, Wp)[:, :, :H, :W]
     return y if b is None else y + b.view(1, -1, 1, 1)
 
 
+def _conv_winograd3(x, w, b, padding=1):
+    return _conv_winograd(x, w, b, padding, m=3)
+
+
+def _conv_winograd4(x, w, b, padding=1):
+    return _conv_winograd(x, w, b, padding, m=4)
+
+
+CONVS = {"library": F.conv2d, "matmul": _conv_matmul, "winograd": _conv_winograd, "winograd3": _conv_winograd3, "winograd4": _conv_winograd4}
+
+
 class PredNetTorch:
-    def __init__(self, weights, channels, w, h, device="cpu", conv="library", order="stacked"):
+    def __init__(self, weights, channels, w, h, device="cpu", conv="library", order="stacked", conv_lstm=None, wino_min_layer=0):
         """device: "cpu" (oneDNN) or a cuda device (rocBLAS): two more fp32 summation orders, both independent of the build's
         canonical chain.  conv: "library" = F.conv2d, "matmul" = im2col + matmul (what chainer's CPU Convolution2D does:
         im2col + tensordot -> BLAS sgemm), "winograd" = F(2x2, 3x3) in fp32 (a study, tests/studies/winograd_study.py).
@@ -64,7 +89,11 @@ class PredNetTorch:
         self.order = order
         self.ch, self.w, self.h, self.L = list(channels), w, h, len(channels)
         self.dev = torch.device(device)
-        self.conv = {"library": F.conv2d, "matmul": _conv_matmul, "winograd": _conv_winograd}[conv]
+        # (studies: conv_lstm = another convolution for the ConvLSTM sources only; wino_min_layer = l: the Winograd variants apply to layers >= l, the
+        # layers below run as "matmul" -- the HIP path's own choice is l = 1, the image layer stays direct)
+        self.wino_min_layer = wino_min_layer
+        self._conv_plain = CONVS[conv]
+        self._conv_lstm = CONVS[conv_lstm or conv]
         self.p = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(self.dev) for k, v in weights.items()}
         # one conv per (layer, source): the 4 gates stacked along the output channels
         self.lstm = []
@@ -74,6 +103,14 @@ class PredNetTorch:
             b = torch.cat([self.p["ConvLSTM%d/h_%s/b" % (l, g)] for g in GATES], 0)
             self.lstm.append((ws, b))
         self.reset(1)
+
+    def _cp(self, l):
+        """convolution of a ConvA / ConvP running at the resolution of layer l"""
+        return self._conv_plain if l >= self.wino_min_layer else (_conv_matmul if self._conv_plain not in (F.conv2d, _conv_matmul) else self._conv_plain)
+
+    def _cl(self, l):
+        """convolution of the ConvLSTM sources of layer l"""
+        return self._conv_lstm if l >= self.wino_min_layer else (_conv_matmul if self._conv_lstm not in (F.conv2d, _conv_matmul) else self._conv_lstm)
 
     def _lstm_chainer(self, l, srcs):
         """One ConvLSTM step in the order chainer_prednet's PredNet/net.py ConvLSTM.__call__ evaluates it (quadjr/PredNet
@@ -97,7 +134,7 @@ class PredNetTorch:
         names = (["x0", "x1", "h"] if len(srcs) == 3 else ["x0", "h"])
         z = None
         for s, w_, nm in zip(srcs, ws, names):
-            y = self.conv(s, w_, b if nm == "h" else None, padding=1)  # h_*: the bias is added to that convolution's output
+            y = self._cl(l)(s, w_, b if nm == "h" else None, padding=1)  # h_*: the bias is added to that convolution's output
             z = y if z is None else z + y
         zi, zf, zc, zo = torch.chunk(z, 4, 1)
         c = self.cs[l]
@@ -123,17 +160,17 @@ class PredNetTorch:
         E = [None] * L
         E[0] = torch.cat((F.relu(x - self.P[0]), F.relu(self.P[0] - x)), 1)
         for l in range(1, L):
-            A = F.max_pool2d(F.relu(self.conv(E[l - 1], p["ConvA%d/W" % l], p["ConvA%d/b" % l], padding=1)), 2, 2)
+            A = F.max_pool2d(F.relu(self._cp(l - 1)(E[l - 1], p["ConvA%d/W" % l], p["ConvA%d/b" % l], padding=1)), 2, 2)   # (runs at the resolution of layer l - 1)
             E[l] = torch.cat((F.relu(A - self.P[l]), F.relu(self.P[l] - A)), 1)
         for l in reversed(range(L)):
             ws, b = self.lstm[l]
             srcs = [E[l]] + ([F.interpolate(self.hs[l + 1], scale_factor=2, mode="nearest")] if l < L - 1 else []) + [self.hs[l]]
             if self.order == "chainer":
                 self._lstm_chainer(l, srcs)
-                v = self.conv(self.hs[l], p["ConvP%d/W" % l], p["ConvP%d/b" % l], padding=1)
+                v = self._cp(l)(self.hs[l], p["ConvP%d/W" % l], p["ConvP%d/b" % l], padding=1)
                 self.P[l] = v.clamp(0.0, 1.0) if l == 0 else F.relu(v)
                 continue
-            z = sum(self.conv(s, w_, None, padding=1) for s, w_ in zip(srcs, ws)) + b.view(1, -1, 1, 1)
+            z = sum(self._cl(l)(s, w_, None, padding=1) for s, w_ in zip(srcs, ws)) + b.view(1, -1, 1, 1)
             zi, zf, zc, zo = torch.chunk(z, 4, 1)
             c = self.cs[l]
             i = torch.sigmoid(zi + p["ConvLSTM%d/c_i/W" % l] * c)
@@ -142,7 +179,7 @@ class PredNetTorch:
             cn = torch.tanh(zc) * i + f * c
             self.cs[l] = cn
             self.hs[l] = o * torch.tanh(cn)
-            v = self.conv(self.hs[l], p["ConvP%d/W" % l], p["ConvP%d/b" % l], padding=1)
+            v = self._cp(l)(self.hs[l], p["ConvP%d/W" % l], p["ConvP%d/b" % l], padding=1)
             self.P[l] = v.clamp(0.0, 1.0) if l == 0 else F.relu(v)
         return self.P[0]
 

@@ -39,6 +39,7 @@ def main():
     ap.add_argument("--w", type=int, default=256)
     ap.add_argument("--h", type=int, default=256)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--large-tiles", action="store_true", help="round 5: also F(3x3,3x3) and F(4x4,3x3) variants")
     a = ap.parse_args()
     torch.backends.cuda.matmul.allow_tf32 = False
     torch.backends.cudnn.allow_tf32 = False
@@ -59,18 +60,30 @@ def main():
     torch.cuda.synchronize()
     imgs = d_img.cpu().numpy()
     sides = {"HIP canonical (fp32 MFMA, fma chains, 2x2 form)": (d_fr.cpu().numpy(), vecs, fit)}
-    for name, conv, batch in (("A reference order, im2col + rocBLAS matmul", "matmul", 8), ("B reference order, MIOpen library convolution", "library", 8),
-                              ("W reference order, Winograd F(2x2,3x3) fp32", "winograd", 4)):
+    # (round 5) the larger tiles: F(4x4,3x3) needs 2.25 multiply-adds per output where F(2x2) needs 4 (1.78x fewer again), F(3x3,3x3) 2.78;
+    # "layers >= 1" = the HIP path's own choice of operators (the image layer stays direct), "ConvLSTM only" = ConvA / ConvP stay im2col + matmul
+    variants = [("A reference order, im2col + rocBLAS matmul", dict(conv="matmul"), 8), ("B reference order, MIOpen library convolution", dict(conv="library"), 8),
+                ("W2 Winograd F(2x2,3x3) fp32, every 3x3 convolution", dict(conv="winograd"), 4)]
+    if a.large_tiles:
+        variants += [("W2' Winograd F(2x2,3x3) fp32, layers >= 1 (the HIP path's operators)", dict(conv="winograd", wino_min_layer=1), 4),
+                     ("W3 Winograd F(3x3,3x3) fp32, layers >= 1", dict(conv="winograd3", wino_min_layer=1), 4),
+                     ("W4 Winograd F(4x4,3x3) fp32, layers >= 1", dict(conv="winograd4", wino_min_layer=1), 4),
+                     ("W4L Winograd F(4x4,3x3) fp32, ConvLSTM of layers >= 1 only (ConvA / ConvP: F(2x2))", dict(conv="winograd", conv_lstm="winograd4", wino_min_layer=1), 4),
+                     ("W4T Winograd F(4x4,3x3) fp32, layers >= 2 only (layers 0, 1: im2col + matmul)", dict(conv="winograd4", wino_min_layer=2), 4)]
+    for name, kw, batch in variants:
         t0 = time.time()
-        sides[name] = classify.rollout_side(ST, W, H, imgs, PredNetTorch(wts, CH, W, H, device="cuda", conv=conv, order="chainer"), batch=batch)
+        sides[name] = classify.rollout_side(ST, W, H, imgs, PredNetTorch(wts, CH, W, H, device="cuda", order="chainer", **kw), batch=batch)
         print("%s: %.1f s" % (name, time.time() - t0), flush=True)
     names = list(sides)
     report = {"shape": [W, H], "channels": CH, "genomes": n, "pairs": {}}
+    anchors = names[:3]   # HIP, A, B: every variant is compared with these (and these with each other), not with every other variant
     for i, x in enumerate(names):
         for y in names[i + 1:]:
+            if x not in anchors and y not in anchors:
+                continue
             s, _ = classify.compare_sides(ST, W, H, sides[x], sides[y])
             report["pairs"]["%s  vs  %s" % (x, y)] = {k: s[k] for k in KEYS}
-            print("%-60s vs %-52s flips %.3g outside %d (unexplained %d) identical %d" % (x[:60], y[:52], s["byte_flip_rate"], s["outside_1e-4"], s["outside_1e-4_unexplained"], s["identical_frames"]), flush=True)
+            print("%-44s vs %-44s flips %.3g outside %d (unexplained %d) identical %d max_rel %.2g" % (x[:44], y[:44], s["byte_flip_rate"], s["outside_1e-4"], s["outside_1e-4_unexplained"], s["identical_frames"], s["max_rel"]), flush=True)
     if a.out:
         json.dump(report, open(a.out, "w"), indent=1)
 
