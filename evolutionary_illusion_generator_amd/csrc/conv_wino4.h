@@ -1,0 +1,517 @@
+// conv_wino4.h -- the 3x3 convolutions of PredNet layers >= 1 (ConvLSTM over E_l / unpooled R_{l+1} / h_l, ConvA, ConvP) as Winograd F(4x4, 3x3) on the fp32
+// matrix pipe: 36 multiply-adds per channel and 4x4 output pixels where F(2x2, 3x3) (conv_wino16.h / conv_winoh.h) needs 64 and the direct form 144.
+// DESIGN.md section 3.1.
+//
+// Why: at fp32 only FEWER multiply-adds make the roll-out faster, and the parity half of the question was answered BEFORE this kernel was written
+// (tests/studies/winograd_study.py --large-tiles, profiles/r05_c_winograd_large_tiles_study.json): on the operators that take it (layers >= 1) F(4x4, 3x3) in fp32 is
+// indistinguishable from F(2x2, 3x3) -- the byte flips against the reference-order implementations are decided in the image layer, which stays direct.
+// The canonical arithmetic of an operator that takes this form is stated operation by operation in oracle/eig_oracle.c (wino4_in1d / wino4_w1d / wino4_out1d,
+// wino_input / wino_chains / wino_finish with m = 4); this kernel executes exactly those operations -- results are identical bit for bit:
+//   input transform   1-D on six values, rows of the 6x6 patch first, then columns:  T0 = fmaf(4, d0, fmaf(-5, d2, d4));  p = fmaf(-4, d2, d4), q = fmaf(-4, d1, d3):
+//                     T1 = p + q, T2 = p - q;  r = d4 - d2, s = d3 - d1:  T3 = fmaf(2, s, r), T4 = fmaf(-2, s, r);  T5 = fmaf(4, d1, fmaf(-5, d3, d5))
+//   36 chains         M_pos[o][T] = fmaf(V_pos[c][T], U_pos[o][c], .) over (source, channel) ascending -- v_mfma_f32_16x16x4_f32
+//   output transform  s = m1 + m2, d = m1 - m2, u = m3 + m4, w = m3 - m4:  Y0 = (m0 + s) + u, Y1 = fmaf(2, w, d), Y2 = fmaf(4, u, s), Y3 = fmaf(8, w, d) + m5;
+//                     along nu in every row xi first (in-lane), then along xi
+// then bias and the operator's epilogue (lstm_cell of conv_mfma.h / relu + 2x2 max-pool + error units / relu).  A ConvLSTM's unpooled source rides in the same
+// chains: its 6x6 patch has rows / columns (a, b, b, c, c, d), p and q above are then the same operation on the same operands, T2 is an exact zero, and the positions
+// with xi = 2 or nu = 2 are chains of exact zeros -- not built, not read, not multiplied: 25 of 36.
+//
+// Block = 16 x 32 output pixels of one image = 32 tiles of 4x4 = two REGIONS of 16 tiles (the left / right 16 x 16 pixels; MFMA row r = 4 ty + tx) x NI 16-column
+// N-tiles; TWELVE waves (three per SIMD, <= 168 VGPRs), one block per CU.  The structure is conv_winoh.h's: no transformed-input buffer --
+//   wave (rg, xi), xi = 0..5, multiplies region rg for the six positions (xi, nu = 0..5): 6 NI accumulator tiles; it BUILDS its A operands itself: lane (q, col) holds
+//     channel q of the K-block for tile col, reads the three or four patch rows that row xi of B^T d needs (per row a 16-byte read and two 4-byte reads out of the
+//     channel's plane), 12-18 operations for the row, 12 for the column pass;
+//   K-block = FOUR channels (one MFMA k-step): 6 NI MFMAs per wave in six chunks with the operand read of the next chunk, staging in slices between the chunks;
+//   LDS: U ring 3 x 36 KB ([36 pos][4 ch][16 cols][NI]; the packed weights are [K-blocks of 8][36][8][16][NI], the 4-channel half of a position = one contiguous
+//     KB = one LDS-DMA instruction, three per wave and K-block), plane ring 3 x 4 x [18 rows][40 floats] (one DMA instruction per wave and K-block);
+//     U(j) is fetched during K-block j - 2 and waited for at its end, plane(j) during j - 3 and waited for at the end of j - 2 (vmcnt(1)): both are visible to
+//     everyone during K-block j - 1, whose last instructions read the first operands of j in front of the barrier -- the barrier never drains the matrix pipe;
+//   output transform: along nu in-lane (c_xi,b: 4 x NI vectors), then the six waves of a region exchange their c rows through LDS in two rounds of 96 KB
+//     (b = 0, 1 and b = 2, 3); ConvLSTM / ConvP: wave xi < 4 finishes output row a = xi of every tile of its region -- a lane owns 16 CONTIGUOUS pixels of one image
+//     row per channel (four 16-byte accesses per tensor), all four gates in-lane; ConvA: wave xi < 4 finishes the row PAIR xi >> 1 for the N-tiles of parity
+//     xi & 1, so that the 2x2 pooling windows of the 4x4 tile stay in one lane.
+#pragma once
+#include "conv_winoh.h"
+
+namespace eig {
+
+constexpr int W4_WAVES = 12;
+constexpr int W4_THREADS = 64 * W4_WAVES;
+constexpr int W4_KC = 4;
+constexpr int W4_NPOS = 36;
+constexpr int W4_UPOS = 256;                        // floats per position of a U slot: 4 ch x 16 cols x NI (NI = 3: 192 used)
+constexpr int W4_U_FLOATS = W4_NPOS * W4_UPOS;      // 36 KB
+constexpr int W4_NUS = 3, W4_NPS = 3;
+constexpr int W4_ROW = 40;                          // floats per plane row: aligned chunks x0-4 .. x0+35
+constexpr int W4_PS = 768;                          // floats per channel plane: 18 rows x 40 = 720 -> three DMA instructions of 256
+constexpr int wino4_lds_bytes() { return (W4_NUS * W4_U_FLOATS + W4_NPS * W4_KC * W4_PS) * 4; }   // 147456 (one exchange round: 12 waves x 8 KB = 98304)
+constexpr int wino4_u_floats(int NI) { return W4_NPOS * 8 * 16 * NI; }   // one 8-channel K-block of the packed weights: [36 pos][8 ch][16 cols][NI]
+#ifndef EIG_W4_DIAG
+#define EIG_W4_DIAG 0   // measurement builds only (WRONG RESULTS): 1 no wait for the K loop's DMAs, 2 no barrier in the K loop, 4 no A-operand build, 8 no plane DMA, 16 no U DMA
+#endif
+
+// the 1-D transforms (oracle/eig_oracle.c: wino4_in1d / wino4_out1d); fmaf = one rounding (this translation unit is compiled with -ffp-contract=off)
+__device__ __forceinline__ void w4_in1d(float d0, float d1, float d2, float d3, float d4, float d5, float* T)
+{
+    T[0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+    const float p = fmaf(-4.0f, d2, d4), q = fmaf(-4.0f, d1, d3);
+    T[1] = p + q; T[2] = p - q;
+    const float r = d4 - d2, s = d3 - d1;
+    T[3] = fmaf(2.0f, s, r); T[4] = fmaf(-2.0f, s, r);
+    T[5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+}
+// row XI of B^T d only: the patch rows in d[] are the ones w4_rows(XI) lists, in that order
+template <int XI> __device__ __forceinline__ float w4_row(const float* d)
+{
+    if constexpr (XI == 0) return fmaf(4.0f, d[0], fmaf(-5.0f, d[1], d[2]));                 // rows 0, 2, 4
+    else if constexpr (XI == 5) return fmaf(4.0f, d[0], fmaf(-5.0f, d[1], d[2]));            // rows 1, 3, 5
+    else {                                                                                   // rows 1, 2, 3, 4
+        if constexpr (XI == 1) return fmaf(-4.0f, d[1], d[3]) + fmaf(-4.0f, d[0], d[2]);
+        else if constexpr (XI == 2) return fmaf(-4.0f, d[1], d[3]) - fmaf(-4.0f, d[0], d[2]);
+        else if constexpr (XI == 3) return fmaf(2.0f, d[2] - d[0], d[3] - d[1]);
+        else return fmaf(-2.0f, d[2] - d[0], d[3] - d[1]);
+    }
+}
+constexpr int w4_nrows(int xi) { return (xi == 0 || xi == 5) ? 3 : 4; }
+constexpr int w4_rowidx(int xi, int k) { return xi == 0 ? 2 * k : xi == 5 ? 2 * k + 1 : k + 1; }   // k-th patch row that row xi of B^T d reads
+// the same row of an UNPOOLED patch: patch rows (0..5) are source rows s + (0, 1, 1, 2, 2, 3)
+constexpr int w4_uprow(int i) { return (i + 1) >> 1; }
+
+template <typename V4> __device__ __forceinline__ void w4_out1d(const V4& m0, const V4& m1, const V4& m2, const V4& m3, const V4& m4, const V4& m5, V4* Y)
+{
+    const V4 s = m1 + m2, d = m1 - m2, u = m3 + m4, w = m3 - m4;
+    Y[0] = (m0 + s) + u;
+    for (int e = 0; e < 4; ++e) { Y[1][e] = fmaf(2.0f, w[e], d[e]); Y[2][e] = fmaf(4.0f, u[e], s[e]); Y[3][e] = fmaf(8.0f, w[e], d[e]) + m5[e]; }
+}
+
+template <int NI, int EPI>
+__global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
+{
+    static_assert(EPI == EPI_LSTM || EPI == EPI_CONVA || EPI == EPI_CONVP, "conv_wino4.h: ConvLSTM, ConvA, ConvP");
+    static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
+    static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
+    constexpr int U8 = wino4_u_floats(NI);
+    constexpr int NUS = W4_NUS, NPS = W4_NPS, KC = W4_KC, PS = W4_PS;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* const Ub = lds;
+    float* const Pb = lds + NUS * W4_U_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rg = wv & 1, xi = wv >> 1;
+    const int q = lane >> 4, col = lane & 15;
+
+    const int tiles = a.tilesX * a.tilesY;
+    const int ntile = a.B * tiles;
+    const int xcd = blockIdx.x & 7, xi_ = blockIdx.x >> 3;
+    const int nblk = xi_ % a.n_nblk;
+    const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + xi_ / a.n_nblk : (xi_ / a.n_nblk) * 8 + xcd;
+    if (tlin >= ntile) return;
+    const int eb = tlin / tiles;
+    const int t_ = tlin - eb * tiles;
+    const int tyi = t_ / a.tilesX, txi = t_ - tyi * a.tilesX;
+    const int y0 = tyi * 16, x0 = txi * 32;
+    const int HW = a.H * a.W;
+
+    const bool up_fused = EPI == EPI_LSTM && a.up_src != nullptr;
+    const int nkb0 = a.src[0].C / KC;
+    const int nkbu = up_fused ? (a.up_C / KC) : 0;
+    const bool has1 = a.nsrc > 1;
+    const int nkb = nkb0 + nkbu + (has1 ? (a.src[1].C / KC) : 0);
+    const int up_lo = nkb0, up_hi = nkb0 + nkbu;
+#define EIG4_WAITCNT(imm) do { __builtin_amdgcn_s_waitcnt(imm); asm volatile("" ::: "memory"); } while (0)
+#define EIG4_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define EIG4_IS_UP(kb) ((kb) >= up_lo && (kb) < up_hi)
+    const int nkb8 = nkb / 2;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb8 * U8), 0, nkb8 * U8 * 4, 0x00020000);
+
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    // ---- plane fetch (every wave: channel wv / 3 of the K-block, part wv % 3 of its plane): lane = 16-byte chunk of the 18 x 10-chunk haloed plane (unpooled source:
+    // 10 rows x 6 chunks at half resolution, row stride 10 chunks); rows / chunks outside the image are out of the descriptor's range through a saturating add = zeros
+    const unsigned long long sb0 = (unsigned long long)(a.src[0].ptr + (size_t)eb * a.src[0].Ct * HW);
+    const unsigned long long sb1 = has1 ? (unsigned long long)(a.src[1].ptr + (size_t)eb * a.src[1].Ct * HW) : sb0;
+    const int sz0 = a.src[0].C * HW * 4, sz1 = has1 ? a.src[1].C * HW * 4 : sz0;
+    const int Hh = a.H >> 1, Wh = a.W >> 1, HWh = Hh * Wh;
+    const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
+    const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
+    const int pch = wv / 3, ppart = wv - pch * 3;
+    int roff, uoff;
+    {
+        const int c = lane + 64 * ppart;
+        const int row = c / 10, cx = c - row * 10;
+        const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * cx;
+        roff = (c < 180 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : -1;
+        const int hy = (y0 >> 1) - 1 + row, hx = (x0 >> 1) - 4 + 4 * cx;
+        uoff = (row < 10 && cx < 6 && hy >= 0 && hy < Hh && hx >= 0 && hx < Wh) ? (hy * Wh + hx) * 4 : -1;
+    }
+    auto dma_plane_at = [&](int jj, int slot) __attribute__((always_inline)) {   // (prologue) this wave's plane DMA of K-block min(jj, nkb - 1) -> slot
+        const int j = jj < nkb ? jj : nkb - 1;
+        const bool up = EIG4_IS_UP(j);
+        const bool s1 = j >= up_hi;
+        // (arithmetic selection: a select between captured variables becomes a select between their ADDRESSES -- a table in scratch memory)
+        const unsigned long long mu = 0ull - (unsigned long long)up, m1 = 0ull - (unsigned long long)s1;
+        const unsigned long long u = sb0 + ((sb1 - sb0) & m1) + ((sbu - sb0) & mu);
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+        const int sz = sz0 + ((sz1 - sz0) & (int)m1) + ((szu - sz0) & (int)mu);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(sz), 0x00020000);
+        const int base = (up_lo & (int)mu) + (up_hi & (int)m1), hw = HW + ((HWh - HW) & (int)mu);
+        const unsigned coff = (unsigned)((j - base) * KC + pch) * (unsigned)(hw * 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + (slot * KC + pch) * PS + ppart * 256), 16,
+                                                 (int)__builtin_elementwise_add_sat((unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (unsigned)mu), coff), 0, 0, 0);
+    };
+    // ---- U fetch (every wave: positions 3 wv .. 3 wv + 2): the 4-channel half of a position of the packed 8-channel K-block = one contiguous KB (NI = 3: 768 B)
+    const int uvo = (NI == 4 || lane < 48) ? lane * 16 : -1;
+    auto dma_u = [&](int jj, int slot) __attribute__((always_inline)) {   // K-block min(jj, nkb - 1) -> slot
+        const int j = jj < nkb ? jj : nkb - 1;
+        constexpr unsigned HALF = 4 * 16 * NI * 4, POS = 8 * 16 * NI * 4;   // bytes
+        const unsigned so = (unsigned)(j >> 1) * (U8 * 4) + (unsigned)(j & 1) * HALF + (unsigned)(3 * wv) * POS;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(Ub + slot * W4_U_FLOATS + (3 * wv + i) * W4_UPOS), 16, uvo,
+                                                     (int)(so + (unsigned)i * POS), 0, 0);
+    };
+
+    // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) = (col >> 2, col & 3) of region rg (MFMA row r = 4 ty + tx: accumulator register = tx)
+    const int t_ty = col >> 2, t_tx = col & 3;
+    const float* const pbase_n = Pb + q * PS + (4 * t_ty) * W4_ROW + 16 * rg + 4 * t_tx + 3;   // patch row 0, column 0 (columns 1 .. 4 are one aligned 16-byte chunk)
+    const float* const pbase_u = Pb + q * PS + (2 * t_ty) * W4_ROW + 8 * rg + 2 * t_tx + 3;    // source row s, column s of an unpooled patch (half-resolution plane)
+
+    // accumulators: position (xi, nu), N-tile ni
+    f32x4 acc[6][NI];
+#pragma unroll
+    for (int p = 0; p < 6; ++p)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int b_off = xi * 6 * W4_UPOS + (q * 16 + col) * NI;   // U[pos = 6 xi + nu][ch = q][col][0 .. NI)
+
+    // ---- prologue: the U slabs of K-blocks 0, 1 and the planes of K-blocks 0, 1, 2
+    dma_u(0, 0);
+    dma_plane_at(0, 0);
+    dma_u(1, 1);
+    dma_plane_at(1, 1);
+    dma_plane_at(2, 2);
+    EIG4_WAITCNT(0x0F71);   // all but the plane of K-block 2
+    EIG4_BARRIER();
+
+    // The K loops exist once per xi (role_tag) behind ONE wave-uniform branch: the patch rows a wave reads and its row combination are compile-time constants of xi,
+    // and so are the positions an unpooled-source K-block skips.
+    auto kloops = [&](auto role_tag) __attribute__((always_inline)) {
+        constexpr int XI = decltype(role_tag)::value;
+        constexpr int NR = w4_nrows(XI);
+        float pr[NR][6];       // the patch rows of the NEXT K-block that row XI of B^T d needs
+        float v[6];            // A operands of the current K-block (built at the end of the previous one)
+        float bq[NI];          // B operand of the current K-block's first chunk, read before the barrier in front of it
+        int rslot = 0;         // plane slot of the K-block whose patch rows are read next
+        int uslot = 0;         // U slot of the current K-block
+        int fu = 2;            // U slot the next fetch goes to
+        // fetch cursor of the planes (K-block pj = kb + 3, clamped to the last one): the descriptor of its source as scalars (a mutable descriptor OBJECT ends in
+        // scratch memory), the byte offset of this wave's channel, the slot
+        int pj = 0, pslot = 0, psz = 0;
+        unsigned pcoff = 0, plo = 0, phi = 0, phw4 = 0;
+        bool pup = false;
+        auto plane_source = [&](int j) __attribute__((always_inline)) {   // (re)position the cursor on K-block j: at the start and where a source begins
+            const bool up = EIG4_IS_UP(j);
+            const bool s1 = j >= up_hi;
+            const unsigned long long mu = 0ull - (unsigned long long)up, m1 = 0ull - (unsigned long long)s1;
+            const unsigned long long u = sb0 + ((sb1 - sb0) & m1) + ((sbu - sb0) & mu);
+            plo = __builtin_amdgcn_readfirstlane((unsigned)u); phi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+            psz = __builtin_amdgcn_readfirstlane(sz0 + ((sz1 - sz0) & (int)m1) + ((szu - sz0) & (int)mu));
+            const int base = (up_lo & (int)mu) + (up_hi & (int)m1);
+            phw4 = (unsigned)((HW + ((HWh - HW) & (int)mu)) * 4);
+            pcoff = (unsigned)((j - base) * KC + pch) * phw4;
+            pup = up; pj = j;
+        };
+        auto dma_plane = [&]() __attribute__((always_inline)) {   // this wave's plane DMA of K-block pj -> slot pslot, then advance the cursor
+            const unsigned o = (unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (0u - (unsigned)pup));
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)phi << 32) | plo), 0, psz, 0x00020000);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + (pslot * KC + pch) * PS + ppart * 256), 16,
+                                                     (int)__builtin_elementwise_add_sat(o, pcoff), 0, 0, 0);
+            pslot = pslot == NPS - 1 ? 0 : pslot + 1;
+            if (pj + 1 < nkb) {
+                if (pj + 1 == up_lo || pj + 1 == up_hi) plane_source(pj + 1);
+                else { ++pj; pcoff += KC * phw4; }
+            }
+        };
+        plane_source(3 < nkb ? 3 : nkb - 1);   // (slot 0 = 3 % 3)
+        // patch rows of the K-block in slot rslot (up: an unpooled-source K-block), then advance rslot
+        auto read_rows = [&](bool up) __attribute__((always_inline)) {
+            const int so = rslot * (KC * PS);
+            rslot = rslot == NPS - 1 ? 0 : rslot + 1;
+            if (EIG_W4_DIAG & 4) return;
+            if (up) {   // rows s + (0, 1, 1, 2, 2, 3), columns likewise: four distinct source values per row
+                const float* const p = pbase_u + so;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const int sr = w4_uprow(w4_rowidx(XI, k));
+                    bool dup = false;
+#pragma unroll
+                    for (int k2 = 0; k2 < k; ++k2)
+                        if (w4_uprow(w4_rowidx(XI, k2)) == sr) { for (int c = 0; c < 6; ++c) pr[k][c] = pr[k2][c]; dup = true; }
+                    if (dup) continue;
+                    const float* const pl = p + sr * W4_ROW;
+                    const float s0 = pl[0], s1_ = pl[1], s2 = pl[2], s3 = pl[3];
+                    pr[k][0] = s0; pr[k][1] = s1_; pr[k][2] = s1_; pr[k][3] = s2; pr[k][4] = s2; pr[k][5] = s3;
+                }
+            } else {
+                const float* const p = pbase_n + so;
+#pragma unroll
+                for (int k = 0; k < NR; ++k) {
+                    const float* const pl = p + w4_rowidx(XI, k) * W4_ROW;
+                    const f32x4 mid = *reinterpret_cast<const f32x4*>(pl + 1);
+                    pr[k][0] = pl[0]; pr[k][1] = mid[0]; pr[k][2] = mid[1]; pr[k][3] = mid[2]; pr[k][4] = mid[3]; pr[k][5] = pl[5];
+                }
+            }
+        };
+        auto build_a = [&]() __attribute__((always_inline)) {   // row XI of B^T d in the six columns, then the 1-D transform along the row
+            if (EIG_W4_DIAG & 4) { for (int c = 0; c < 6; ++c) v[c] = 1.0f; return; }
+            float t[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                float d[NR];
+#pragma unroll
+                for (int k = 0; k < NR; ++k) d[k] = pr[k][c];
+                t[c] = w4_row<XI>(d);
+            }
+            w4_in1d(t[0], t[1], t[2], t[3], t[4], t[5], v);
+        };
+        auto read_b = [&](int slot, int nu, float* dst) __attribute__((always_inline)) {
+            const float* const bsrc = Ub + slot * W4_U_FLOATS + b_off + nu * W4_UPOS;
+            if constexpr (NI == 4) {
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bsrc);
+                dst[0] = b4[0]; dst[1] = b4[1]; dst[2] = b4[2]; dst[3] = b4[3];
+            } else {
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) dst[ni] = bsrc[ni];
+            }
+        };
+        // One K-block.  kind_tag: 0 full, 1 unpooled source, 2 run time; nk_tag: kind of K-block kb + 1 (whose patch rows are read now), same codes; last_tag: the last
+        // K-block (nothing to stage).  On entry v and bq hold the A operands and the first B operand of this K-block: the first instruction behind the barrier is an MFMA,
+        // and the staging work sits in slices BETWEEN the chunks -- patch rows of K-block kb + 1 behind chunk 0, the U fetch behind chunk 1, the plane fetch behind
+        // chunk 2, the A operands of kb + 1 behind the last chunk.
+        auto kiter = [&](const int kb, auto kind_tag, auto nk_tag, auto last_tag) __attribute__((always_inline)) {
+            constexpr int KIND = decltype(kind_tag)::value;
+            constexpr int NK = decltype(nk_tag)::value;
+            constexpr bool LAST = decltype(last_tag)::value;
+            constexpr bool UP = KIND == 1;   // (run-time kind = the last K-block of all: an unpooled-source one there runs the full body on its exact-zero operands -- fma(0, u, M) = M)
+            constexpr bool IDLE = UP && XI == 2;   // nothing to multiply
+            constexpr int NCH = IDLE ? 0 : (UP ? 5 : 6);   // chunks: nu = 0, 1, (2,) 3, 4, 5
+            const int nslot = uslot == NUS - 1 ? 0 : uslot + 1;
+            float bv[2][NI];
+            auto slice = [&](int i) __attribute__((always_inline)) {
+                if constexpr (!LAST) {
+                    if (i == 0) read_rows(NK == 2 ? EIG4_IS_UP(kb + 1) : NK == 1);
+                    if (i == 1) { if (!(EIG_W4_DIAG & 16)) dma_u(kb + 2, fu); fu = fu == NUS - 1 ? 0 : fu + 1; }
+                    if (i == 2) { if (!(EIG_W4_DIAG & 8)) dma_plane(); }
+                }
+            };
+            if constexpr (IDLE) {
+                slice(0); slice(1); slice(2);
+                if constexpr (!LAST) { read_b(nslot, 0, bq); build_a(); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NCH; ++i) {
+                    const int nu = (UP && i >= 2) ? i + 1 : i;
+                    if (i + 1 < NCH) {
+                        const int nu1 = (UP && i + 1 >= 2) ? i + 2 : i + 1;
+                        read_b(uslot, nu1, bv[(i + 1) & 1]);
+                    } else if constexpr (!LAST) read_b(nslot, 0, bq);
+                    const float* const b = i == 0 ? bq : bv[i & 1];
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) acc[nu][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], b[ni], acc[nu][ni], 0, 0, 0);
+                    slice(i);
+                    if (i == NCH - 1) { if constexpr (!LAST) build_a(); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            uslot = nslot;
+            // the U fetch of this K-block has landed (its plane fetch may stay in flight: it is read two K-blocks from now); after the last K-block: everything
+            if (LAST || (EIG_W4_DIAG & (8 | 16))) EIG4_WAITCNT(0x0F70);
+            else if (!(EIG_W4_DIAG & 1)) EIG4_WAITCNT(0x0F71);
+            if (!(EIG_W4_DIAG & 2) || LAST) EIG4_BARRIER();
+        };
+        const std::false_type nl{};
+        const std::integral_constant<int, 2> rt{};
+        int kb = 0;
+        read_rows(EIG4_IS_UP(0));
+        read_b(0, 0, bq);
+        build_a();
+        EIG4_WAITCNT(0xC07F);
+        EIG4_BARRIER();   // (every wave has read plane 0 out of its slot before anyone's K-block 0 fetches into it)
+        // K-blocks [kb, end) of one kind; the LAST K-block of all is left out.  A K-block reads the patch rows of the next one: same kind except at the end of a run.
+        auto run = [&](const int end, auto kind_tag) __attribute__((always_inline)) {
+            for (; kb + 1 < end; ++kb) kiter(kb, kind_tag, kind_tag, nl);
+            if (kb + 1 == end && end < nkb) { kiter(kb, kind_tag, rt, nl); ++kb; }
+        };
+        run(up_lo, std::integral_constant<int, 0>{});
+        run(up_hi, std::integral_constant<int, 1>{});
+        run(nkb, std::integral_constant<int, 0>{});
+        kiter(nkb - 1, rt, rt, std::true_type{});
+    };
+    switch (xi) {
+        case 0: kloops(std::integral_constant<int, 0>{}); break;
+        case 1: kloops(std::integral_constant<int, 1>{}); break;
+        case 2: kloops(std::integral_constant<int, 2>{}); break;
+        case 3: kloops(std::integral_constant<int, 3>{}); break;
+        case 4: kloops(std::integral_constant<int, 4>{}); break;
+        default: kloops(std::integral_constant<int, 5>{}); break;
+    }
+
+    // ---- output transform.  Along nu in-lane: c_xi,b (b = 0..3) of every N-tile.
+    f32x4 cc[4][NI];
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        f32x4 Y[4];
+        w4_out1d(acc[0][ni], acc[1][ni], acc[2][ni], acc[3][ni], acc[4][ni], acc[5][ni], Y);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) cc[b][ni] = Y[b];
+    }
+    // Along xi: the six waves of a region publish their c rows in two rounds (b = 0, 1 then b = 2, 3: [12 waves][2 b][NI][64 lanes] 16-byte vectors = 96 KB each; U / planes
+    // are dead -- every wave is past the last barrier, every DMA has landed); the finishing waves read what their output rows need.
+    float* const xb = lds;
+#define EIG4_C(x, bb, ni) (*reinterpret_cast<const f32x4*>(xb + ((((x) * 2 + rg) * 2 + (bb)) * 4 + (ni)) * 256 + lane * 4))   // c_x,b of N-tile ni, published by wave (xi = x, rg)
+    const int ch0 = (EPI == EPI_LSTM) ? nblk * 16 + col : nblk * NI * 16 + col;   // channel of N-tile 0 (ConvLSTM: of every gate)
+    const size_t cHW = (size_t)HW;
+    // one output row `arow` (0..3) of the four tiles of tile row q: registers e = tx -> pixels x0 + 16 rg + 4 e + b
+    auto finish_row = [&](int arow, int bb, int ni) __attribute__((always_inline)) -> f32x4 {
+        const f32x4 c1 = EIG4_C(1, bb, ni), c2 = EIG4_C(2, bb, ni), c3 = EIG4_C(3, bb, ni), c4 = EIG4_C(4, bb, ni);
+        const f32x4 s = c1 + c2, d = c1 - c2, u = c3 + c4, w = c3 - c4;
+        f32x4 y;
+        if (arow == 0) { const f32x4 c0 = EIG4_C(0, bb, ni); y = (c0 + s) + u; }
+        else if (arow == 1) { for (int e = 0; e < 4; ++e) y[e] = fmaf(2.0f, w[e], d[e]); }
+        else if (arow == 2) { for (int e = 0; e < 4; ++e) y[e] = fmaf(4.0f, u[e], s[e]); }
+        else { const f32x4 c5 = EIG4_C(5, bb, ni); for (int e = 0; e < 4; ++e) y[e] = fmaf(8.0f, w[e], d[e]) + c5[e]; }
+        return y;
+    };
+    if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
+        // wave xi < 4 finishes output row a = xi: y[ni][b] = vectors over e = tx
+        f32x4 y[NI][4];
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (rnd) __syncthreads();   // (everyone has read round 0)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(xb + (((wv * 2 + bb) * 4 + ni) * 256 + lane * 4)) = cc[2 * rnd + bb][ni];
+            __syncthreads();
+            if (xi < 4) {
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                    for (int ni = 0; ni < NI; ++ni) {
+                        f32x4 r;
+                        switch (xi) { case 0: r = finish_row(0, bb, ni); break; case 1: r = finish_row(1, bb, ni); break; case 2: r = finish_row(2, bb, ni); break; default: r = finish_row(3, bb, ni); break; }
+                        y[ni][2 * rnd + bb] = r;
+                    }
+            }
+        }
+        if (xi >= 4) return;
+        const int gy = y0 + 4 * q + xi;
+        if (gy >= a.H) return;
+        if constexpr (EPI == EPI_LSTM) {
+            const int ch = ch0;
+            if (ch >= a.Cout) return;
+            const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
+            const size_t cbase = ((size_t)eb * a.Cout + ch) * cHW, ps = (size_t)a.Cout * cHW, pbase = (size_t)ch * cHW;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // tile tx = e: pixels gx .. gx + 3 (b = 0..3)
+                const int gx = x0 + 16 * rg + 4 * e;
+                if (gx >= a.W) continue;
+                const size_t pix = (size_t)gy * a.W + gx;
+                const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
+                const f32x4 pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
+                const f32x4 pf4 = *reinterpret_cast<const f32x4*>(a.peep + ps + pbase + pix);
+                const f32x4 po4 = *reinterpret_cast<const f32x4*>(a.peep + 2 * ps + pbase + pix);
+                f32x4 cn4, hn4;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    float cn, hn;
+                    lstm_cell(y[0][b][e], y[1][b][e], y[2][b][e], y[3][b][e], bi, bf, bc, bo, cold4[b], pi4[b], pf4[b], po4[b], cn, hn);
+                    cn4[b] = cn; hn4[b] = hn;
+                }
+                *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
+                *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int ch = ch0 + ni * 16;
+                if (ch >= a.Cout) continue;
+                const float bb_ = a.bias[ch];
+                const size_t base = ((size_t)eb * a.Cout + ch) * cHW;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int gx = x0 + 16 * rg + 4 * e;
+                    if (gx >= a.W) continue;
+                    f32x4 v4;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) v4[b] = relu_f(y[ni][b][e] + bb_);
+                    *reinterpret_cast<f32x4*>(a.Pout + base + (size_t)gy * a.W + gx) = v4;
+                }
+            }
+        }
+    } else {
+        // ConvA: wave xi < 4 finishes the row PAIR ap = xi >> 1 (output rows 2 ap, 2 ap + 1) for the N-tiles ni = (xi & 1), (xi & 1) + 2: the 2x2 pooling windows of
+        // the 4x4 tile -- (rows 2 ap, 2 ap + 1) x (columns 2 bp, 2 bp + 1) -- stay in one lane; pooled pixel (2 (4 tyi + q) + ap, (x0 >> 1) + 8 rg + 2 e + bp)
+        const int ap = xi >> 1, np_ = xi & 1;
+        f32x4 y[2][2][4];   // [N-tile k of this wave][row of the pair][b]
+#pragma unroll
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (rnd) __syncthreads();
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(xb + (((wv * 2 + bb) * 4 + ni) * 256 + lane * 4)) = cc[2 * rnd + bb][ni];
+            __syncthreads();
+            if (xi < 4) {
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int ni = np_ + 2 * k;
+                    if (ni >= NI) continue;
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        if (ap == 0) { y[k][0][2 * rnd + bb] = finish_row(0, bb, ni); y[k][1][2 * rnd + bb] = finish_row(1, bb, ni); }
+                        else { y[k][0][2 * rnd + bb] = finish_row(2, bb, ni); y[k][1][2 * rnd + bb] = finish_row(3, bb, ni); }
+                    }
+                }
+            }
+        }
+        if (xi >= 4) return;
+        const int Ho = a.H >> 1, Wo = a.W >> 1;
+        const size_t plane = (size_t)Ho * Wo;
+        const int oy = (y0 >> 1) + 2 * q + ap;
+        if (oy >= Ho) return;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int ni = np_ + 2 * k;
+            if (ni >= NI) continue;
+            const int ch = ch0 + ni * 16;
+            if (ch >= a.Cout) continue;
+            const float bb_ = a.bias[ch];
+            const size_t pb = ((size_t)eb * a.Cout + ch) * plane;
+            const size_t e0 = ((size_t)eb * 2 * a.Cout + ch) * plane, e1 = e0 + (size_t)a.Cout * plane;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {   // tile tx = e: pooled columns ox, ox + 1
+                const int ox = (x0 >> 1) + 8 * rg + 2 * e;
+                if (ox >= Wo) continue;
+                const f32x2 p2 = *reinterpret_cast<const f32x2*>(a.P + pb + (size_t)oy * Wo + ox);
+                f32x2 ea, eb2;
+#pragma unroll
+                for (int bp = 0; bp < 2; ++bp) {
+                    const float v00 = relu_f(y[k][0][2 * bp][e] + bb_), v01 = relu_f(y[k][0][2 * bp + 1][e] + bb_);
+                    const float v10 = relu_f(y[k][1][2 * bp][e] + bb_), v11 = relu_f(y[k][1][2 * bp + 1][e] + bb_);
+                    const float A = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
+                    ea[bp] = relu_f(A - p2[bp]);
+                    eb2[bp] = relu_f(p2[bp] - A);
+                }
+                *reinterpret_cast<f32x2*>(a.E + e0 + (size_t)oy * Wo + ox) = ea;
+                *reinterpret_cast<f32x2*>(a.E + e1 + (size_t)oy * Wo + ox) = eb2;
+            }
+        }
+    }
+#undef EIG4_C
+#undef EIG4_WAITCNT
+#undef EIG4_BARRIER
+#undef EIG4_IS_UP
+}
+
+}  // namespace eig

@@ -18,6 +18,7 @@
 #include "conv_wino.h"
 #include "conv_wino16.h"
 #include "conv_winoh.h"
+#include "conv_wino4.h"
 #ifndef EIGEN_WINO16_DEFAULT
 #define EIGEN_WINO16_DEFAULT 7
 #endif
@@ -63,7 +64,8 @@ struct ConvOp {
     // ConvLSTM with the chain of its unpooled source computed in-kernel (conv_mfma.h: FUSE); the weights live in Layer::d_upw
     bool fused = false;
     int up_C = 0, up_kb = 0;
-    bool wino = false;  // Winograd F(2x2, 3x3) form (conv_wino.h); epi stays the operator's epilogue
+    bool wino = false;  // Winograd form (conv_wino.h / conv_wino4.h); epi stays the operator's epilogue
+    int wino_tile = 2;  // ... F(2x2, 3x3) or F(4x4, 3x3) (bits 25-27 of EIGEN_WINOGRAD; conv_wino4.h)
 };
 
 struct Layer {
@@ -415,15 +417,34 @@ static void wino_weight(const float* g, float* U)  // U = G g G^T: rows first, t
         U[i * 4 + 3] = s[i][2];
     }
 }
-// [n_nblk][K-blocks: 8 channels of one source, sources in order][16 positions][8 channels][16 columns][NI N-tiles]
+// F(4x4, 3x3): U = G g G^T, 6 x 6 (oracle/eig_oracle.c: wino4_w1d / wino4_weights state the same operations in the same order; fmaf = one rounding, this file
+// is compiled with -ffp-contract=off)
+static void wino4_w1d(float g0, float g1, float g2, float* W)
+{
+    const float c6 = -1.0f / 6.0f, c24 = 1.0f / 24.0f;
+    W[0] = 0.25f * g0;
+    const float a = g0 + g2;
+    W[1] = (a + g1) * c6; W[2] = (a - g1) * c6;
+    const float b = fmaf(4.0f, g2, g0);
+    W[3] = fmaf(2.0f, g1, b) * c24; W[4] = fmaf(-2.0f, g1, b) * c24;
+    W[5] = g2;
+}
+static void wino4_weight(const float* g, float* U)
+{
+    float s[6][3], W[6];
+    for (int j = 0; j < 3; ++j) { wino4_w1d(g[j], g[3 + j], g[6 + j], W); for (int i = 0; i < 6; ++i) s[i][j] = W[i]; }
+    for (int i = 0; i < 6; ++i) wino4_w1d(s[i][0], s[i][1], s[i][2], U + i * 6);
+}
+// [n_nblk][K-blocks: 8 channels of one source, sources in order][16 (tile 4: 36) positions][8 channels][16 columns][NI N-tiles]
 // lstm: N-tile = gate, output channel = 16 nb + column (srcw[s][gate]); plain convolution: output channel = 16 (NI nb + N-tile) + column (srcw[s][0])
-static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm, int nsrc, const int* src_C, const int* src_Cw, const float* const srcw[3][4])
+static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm, int nsrc, const int* src_C, const int* src_Cw, const float* const srcw[3][4], int tile = 2)
 {
     int nkb = 0;
     for (int s = 0; s < nsrc; ++s) nkb += src_C[s] / KC;
-    const int uf = wino_u_floats(NI);
+    const int npos = tile == 4 ? 36 : 16;
+    const int uf = tile == 4 ? wino4_u_floats(NI) : wino_u_floats(NI);
     std::vector<float> out((size_t)n_nblk * nkb * uf, 0.0f);
-    float U[16];
+    float U[36];
     for (int nb = 0; nb < n_nblk; ++nb) {
         int kb0 = 0;
         for (int s = 0; s < nsrc; ++s) {
@@ -432,9 +453,10 @@ static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm
                     for (int n = 0; n < 16; ++n) {
                         const int o = lstm ? nb * 16 + n : (nb * NI + ni) * 16 + n;
                         if (o >= C) continue;
-                        wino_weight(srcw[s][lstm ? ni : 0] + ((size_t)o * src_Cw[s] + c) * 9, U);
+                        if (tile == 4) wino4_weight(srcw[s][lstm ? ni : 0] + ((size_t)o * src_Cw[s] + c) * 9, U);
+                        else wino_weight(srcw[s][lstm ? ni : 0] + ((size_t)o * src_Cw[s] + c) * 9, U);
                         float* dst = &out[((size_t)nb * nkb + kb0 + c / KC) * uf];
-                        for (int pos = 0; pos < 16; ++pos) dst[((pos * KC + (c % KC)) * 16 + n) * NI + ni] = U[pos];
+                        for (int pos = 0; pos < npos; ++pos) dst[((pos * KC + (c % KC)) * 16 + n) * NI + ni] = U[pos];
                     }
             kb0 += src_C[s] / KC;
         }
@@ -596,7 +618,21 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         const int cls = op.epi == EPI_LSTM ? 1 : (op.epi == EPI_CONVA ? 2 : 4);
         const bool lstm_ok = op.epi != EPI_LSTM || a.acc_init == nullptr;
         const std::integral_constant<int, 1> k1{}; const std::integral_constant<int, 2> k2{}; const std::integral_constant<int, 4> k4{};
-        if (mode == 8 && (winoh & cls) && lstm_ok) {
+        if (op.wino_tile == 4) {   // F(4x4, 3x3): conv_wino4.h, 16 x 32-pixel blocks, twelve waves
+            if (!lstm_ok) return hipErrorInvalidConfiguration;
+            auto go4 = [&](auto kern) {
+                a.tilesX = (op.W + 31) / 32; a.tilesY = (op.H + 15) / 16;
+                const int g4 = op.n_nblk * ((batch * a.tilesX * a.tilesY + 7) / 8) * 8;
+                static std::unordered_set<const void*> attr_done;
+                if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, wino4_lds_bytes());
+                op.last_grid = g4; op.last_waves = W4_WAVES;
+                hipLaunchKernelGGL(kern, dim3(g4), dim3(W4_THREADS), wino4_lds_bytes(), st, a);
+            };
+            if (op.epi == EPI_LSTM) go4(wino4_kernel<4, EPI_LSTM>);
+            else if (op.epi == EPI_CONVA) { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVA>); else go4(wino4_kernel<3, EPI_CONVA>); }
+            else { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVP>); else go4(wino4_kernel<3, EPI_CONVP>); }
+        }
+        else if (mode == 8 && (winoh & cls) && lstm_ok) {
             if (op.epi == EPI_LSTM) goh(winoh_kernel<4, EPI_LSTM, 2, 1>, k2, k1);
             else if (op.epi == EPI_CONVA) { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVA, 2, 1>, k2, k1); else goh(winoh_kernel<3, EPI_CONVA, 2, 1>, k2, k1); }
             else { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVP, 2, 1>, k2, k1); else goh(winoh_kernel<3, EPI_CONVP, 2, 1>, k2, k1); }
@@ -887,12 +923,14 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             if (wino_op(wino_env, 1, l, e->layer[l - 1].C, C, op.H, op.W, false)) {  // (the step-0 operator reads C_{l-1} channels: multiples of 8 too)
                 const int ni = (C % 64) ? 3 : 4, nb = C / (16 * ni);
                 const int sc[1] = {2 * e->layer[l - 1].C}, scw[1] = {2 * e->layer[l - 1].C}, sc0[1] = {e->layer[l - 1].C};
-                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, scw, sw);
-                std::vector<float> pw0 = pack_weights_wino(C, ni, nb, false, 1, sc0, scw, sw);
+                const int wt = ((wino_env >> 26) & 1) ? 4 : 2;   // F(4x4, 3x3): conv_wino4.h (oracle: eig_wino_tile)
+                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, scw, sw, wt);
+                std::vector<float> pw0 = pack_weights_wino(C, ni, nb, false, 1, sc0, scw, sw, wt);
                 if (upload(&op.d_wpk, pw.data(), pw.size()) || upload(&t0.d_wpk, pw0.data(), pw0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d, Winograd form)", l);
-                for (ConvOp* f : {&op, &t0}) { f->wino = true; f->TW = 16; f->NI = ni; f->n_nblk = nb; }
-                op.macs = (double)(op.H / 2) * (op.W / 2) * 16 * C * sc[0];
-                t0.macs = (double)(op.H / 2) * (op.W / 2) * 16 * C * sc0[0];
+                for (ConvOp* f : {&op, &t0}) { f->wino = true; f->wino_tile = wt; f->TW = 16; f->NI = ni; f->n_nblk = nb; }
+                const double tl = (double)((op.H + wt - 1) / wt) * ((op.W + wt - 1) / wt) * (wt + 2) * (wt + 2);   // tiles x positions
+                op.macs = tl * C * sc[0];
+                t0.macs = tl * C * sc0[0];
             }
         }
         // ---- ConvLSTM_l: 4 gates fused on N.  Chain over E_l, h_l + chain of the unpooled R_{l+1} in its 2x2 form (own launch, Layer::up4)
@@ -958,13 +996,16 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
                 for (int g = 0; g < 4; ++g) { w3[0][g] = wx0[g]; w3[1][g] = wino_fuse ? wx1[g] : wh[g]; w3[2][g] = wino_fuse ? wh[g] : nullptr; }
                 const int sc[3] = {2 * C, wino_fuse ? Cu : C, C}, sw[3] = {2 * C, wino_fuse ? Cu : C, C};
                 const int sc0[2] = {C, Cu}, sw0[2] = {2 * C, Cu};
-                std::vector<float> pw = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 3 : 2, sc, sw, w3);
-                std::vector<float> pw0 = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 2 : 1, sc0, sw0, w3);
+                // F(4x4, 3x3) (conv_wino4.h; oracle: eig_wino_tile): bit 25, and only where the unpooled source rides in the chains (or there is none)
+                const int wt = (((wino_env >> 25) & 1) && (wino_fuse || l == L - 1)) ? 4 : 2;
+                std::vector<float> pw = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 3 : 2, sc, sw, w3, wt);
+                std::vector<float> pw0 = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 2 : 1, sc0, sw0, w3, wt);
                 if (upload(&op.d_wpk, pw.data(), pw.size()) || upload(&t0.d_wpk, pw0.data(), pw0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, Winograd form)", l);
-                op.wino = t0.wino = true; op.TW = t0.TW = 16;
-                const double tiles = (double)((y.H + 1) / 2) * ((y.W + 1) / 2);
-                op.macs = tiles * 16 * 4 * C * (3.0 * C) + tiles * 9 * 4 * C * Cu;   // executed: 16 (unpooled source: 9) multiply-adds per channel and 2x2 outputs
-                t0.macs = tiles * 16 * 4 * C * (1.0 * C) + tiles * 9 * 4 * C * Cu;
+                op.wino = t0.wino = true; op.TW = t0.TW = 16; op.wino_tile = t0.wino_tile = wt;
+                const double tiles = (double)((y.H + wt - 1) / wt) * ((y.W + wt - 1) / wt);
+                const double pf = wt == 4 ? 36 : 16, pu = wt == 4 ? 25 : 9;
+                op.macs = tiles * pf * 4 * C * (3.0 * C) + tiles * pu * 4 * C * Cu;   // executed: 16 / 36 (unpooled source: 9 / 25) multiply-adds per channel and tile
+                t0.macs = tiles * pf * 4 * C * (1.0 * C) + tiles * pu * 4 * C * Cu;
                 if (wino_fuse)
                     for (ConvOp* f : {&op, &t0}) { f->fused = true; f->up_C = Cu; f->up_kb = Cu / KC; }
             }
@@ -1021,10 +1062,11 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             if (wino_op(wino_env, 2, l, C, C, y.H, y.W, l == L - 1)) {
                 const int ni = (C % 64) ? 3 : 4, nb = C / (16 * ni);
                 const int sc[1] = {C};
-                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, sc, sw);
+                const int wt = ((wino_env >> 27) & 1) ? 4 : 2;
+                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, sc, sw, wt);
                 if (upload(&op.d_wpk, pw.data(), pw.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvP%d, Winograd form)", l);
-                op.wino = true; op.TW = 16; op.NI = ni; op.n_nblk = nb;
-                op.macs = (double)((y.H + 1) / 2) * ((y.W + 1) / 2) * 16 * C * C;
+                op.wino = true; op.wino_tile = wt; op.TW = 16; op.NI = ni; op.n_nblk = nb;
+                op.macs = (double)((y.H + wt - 1) / wt) * ((y.W + wt - 1) / wt) * (wt + 2) * (wt + 2) * C * C;
             }
         }
     }

@@ -71,6 +71,7 @@ def lib():
         _LIB.eig_oracle_good_features.restype = ctypes.c_int
         _LIB.eig_oracle_conv_chain.restype = ctypes.c_int
         _LIB.eig_oracle_wino_chain.restype = ctypes.c_int
+        _LIB.eig_oracle_wino_chain_m.restype = ctypes.c_int
         for f in ("eig_oracle_farneback", "eig_oracle_fb_vectors", "eig_oracle_fb_levels", "eig_oracle_fb_grid_step"):
             getattr(_LIB, f).restype = ctypes.c_int
     return _LIB
@@ -186,8 +187,8 @@ def conv_chain(sources, ups, weights, H, W):
     return out
 
 
-def wino_chain(sources, weights, H, W):
-    """out[o,y,x] = the canonical Winograd F(2x2, 3x3) chain over the listed full-resolution sources (eig_oracle.c: wino_*)."""
+def wino_chain(sources, weights, H, W, m=2):
+    """out[o,y,x] = the canonical Winograd F(m x m, 3x3) chain, m = 2 or 4, over the listed full-resolution sources (eig_oracle.c: wino_*)."""
     ns = len(sources)
     srcs = [np.ascontiguousarray(s, dtype=np.float32) for s in sources]
     ws = [np.ascontiguousarray(x, dtype=np.float32) for x in weights]
@@ -196,9 +197,9 @@ def wino_chain(sources, weights, H, W):
     wt = (ctypes.POINTER(ctypes.c_float) * ns)(*[_p(a, ctypes.c_float) for a in ws])
     cin = np.asarray([s.shape[0] for s in srcs], dtype=np.int32)
     out = np.zeros((cout, H, W), dtype=np.float32)
-    rc = lib().eig_oracle_wino_chain(ctypes.c_int(ns), st, _p(cin, ctypes.c_int), wt, ctypes.c_int(cout), ctypes.c_int(H), ctypes.c_int(W), _p(out, ctypes.c_float))
+    rc = lib().eig_oracle_wino_chain_m(ctypes.c_int(ns), st, _p(cin, ctypes.c_int), wt, ctypes.c_int(cout), ctypes.c_int(H), ctypes.c_int(W), _p(out, ctypes.c_float), ctypes.c_int(m))
     if rc != 0:
-        raise ValueError("wino_chain needs even H and W")
+        raise ValueError("wino_chain needs even W (m = 4: W % 4 == 0)")
     return out
 
 

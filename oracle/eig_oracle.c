@@ -332,84 +332,159 @@ static void wino_weights(const float* g /*[3][3]*/, float* U /*[16]*/)
     }
 }
 
-/* M[16][Cout][TH*TW] += chains over the Cin channels of one source (pad: [Cin][H+2][W+2], zero border).  Odd H (a top-layer map,
- * e.g. 20 x 15): TH = (H + 1) / 2 tile rows, the rows below the map read as zeros and the outputs below it are dropped. */
-static float* wino_input(const float* pad, int Cin, int H, int W)   /* -> V[Cin][16][TH*TW] (malloc'ed): B^T d B of every tile of every channel */
+/* ---- Winograd F(4x4, 3x3) (round 5; csrc/conv_wino4.h runs exactly these operations): 36 multiply-adds per channel and 4x4 outputs instead of the 64 of
+ * F(2x2) (144 direct).  Interpolation points 0, +-1, +-2, inf (Lavin & Gray); fp32, ONE fixed order.  Whether the larger tile costs parity was measured BEFORE it
+ * was built (tests/studies/winograd_study.py --large-tiles, profiles/r05_c_winograd_large_tiles_study.json): on the operators that take it (layers >= 1) F(4x4) is
+ * indistinguishable from F(2x2) -- the byte flips against the reference-order implementations are decided in the image layer, which stays direct.
+ * 1-D transforms, applied to rows first, then to columns (fmaf = ONE rounding; this file is compiled with -ffp-contract=off):
+ *   input  (B^T, six values d0..d5 -> six):   T0 = fmaf(4, d0, fmaf(-5, d2, d4));   p = fmaf(-4, d2, d4), q = fmaf(-4, d1, d3):  T1 = p + q, T2 = p - q;
+ *                                             r = d4 - d2, s = d3 - d1:  T3 = fmaf(2, s, r), T4 = fmaf(-2, s, r);   T5 = fmaf(4, d1, fmaf(-5, d3, d5))
+ *   weight (G, three values g0..g2 -> six):   W0 = 0.25 g0;   a = g0 + g2:  W1 = (a + g1) * (-1/6), W2 = (a - g1) * (-1/6);
+ *                                             b = fmaf(4, g2, g0):  W3 = fmaf(2, g1, b) * (1/24), W4 = fmaf(-2, g1, b) * (1/24);   W5 = g2
+ *   output (A^T, six values m0..m5 -> four):  s = m1 + m2, d = m1 - m2, u = m3 + m4, w = m3 - m4:
+ *                                             Y0 = (m0 + s) + u, Y1 = fmaf(2, w, d), Y2 = fmaf(4, u, s), Y3 = fmaf(8, w, d) + m5
+ * 36 independent chains M_ij[o][T] = fmaf(V_ij[c][T], U_ij[o][c], M_ij[o][T]) over the sources in list order, channels ascending.  The patch of a x2
+ * nearest-unpooled map has rows / columns (a, b, b, c, c, d): p and q above are then the SAME operation on the SAME operands, T2 = p - q is an exact zero, so the
+ * positions with xi = 2 or nu = 2 are chains of exact zeros (the HIP kernel skips them): 25 of 36. */
+#define WINO4_C6 (-1.0f / 6.0f)
+#define WINO4_C24 (1.0f / 24.0f)
+static inline void wino4_in1d(const float* d, int st, float* T)   /* six values d[0], d[st], .. -> T[0..5] */
 {
-    const int TH = (H + 1) / 2, TW = W / 2, NT = TH * TW, PW = W + 2, PH = H + 2;
+    const float d0 = d[0], d1 = d[st], d2 = d[2 * st], d3 = d[3 * st], d4 = d[4 * st], d5 = d[5 * st];
+    T[0] = fmaf(4.0f, d0, fmaf(-5.0f, d2, d4));
+    const float p = fmaf(-4.0f, d2, d4), q = fmaf(-4.0f, d1, d3);
+    T[1] = p + q; T[2] = p - q;
+    const float r = d4 - d2, s = d3 - d1;
+    T[3] = fmaf(2.0f, s, r); T[4] = fmaf(-2.0f, s, r);
+    T[5] = fmaf(4.0f, d1, fmaf(-5.0f, d3, d5));
+}
+static inline void wino4_w1d(float g0, float g1, float g2, float* W)
+{
+    W[0] = 0.25f * g0;
+    const float a = g0 + g2;
+    W[1] = (a + g1) * WINO4_C6; W[2] = (a - g1) * WINO4_C6;
+    const float b = fmaf(4.0f, g2, g0);
+    W[3] = fmaf(2.0f, g1, b) * WINO4_C24; W[4] = fmaf(-2.0f, g1, b) * WINO4_C24;
+    W[5] = g2;
+}
+static inline void wino4_out1d(const float* m, int st, float* Y)  /* six values -> Y[0..3] */
+{
+    const float m0 = m[0], m1 = m[st], m2 = m[2 * st], m3 = m[3 * st], m4 = m[4 * st], m5 = m[5 * st];
+    const float s = m1 + m2, d = m1 - m2, u = m3 + m4, w = m3 - m4;
+    Y[0] = (m0 + s) + u; Y[1] = fmaf(2.0f, w, d); Y[2] = fmaf(4.0f, u, s); Y[3] = fmaf(8.0f, w, d) + m5;
+}
+static void wino4_weights(const float* g /*[3][3]*/, float* U /*[36]*/)
+{
+    float s[6][3], W[6];
+    for (int j = 0; j < 3; j++) { wino4_w1d(g[j], g[3 + j], g[6 + j], W); for (int i = 0; i < 6; i++) s[i][j] = W[i]; }   /* G g: down the columns */
+    for (int i = 0; i < 6; i++) wino4_w1d(s[i][0], s[i][1], s[i][2], U + i * 6);                                            /* (G g) G^T: along the rows */
+}
+void eig_oracle_wino4_weights(const float* g, float* U) { wino4_weights(g, U); }   /* (tests: the engine's host code packs the same values) */
+
+/* tile geometry of the two forms: m = 2 or 4 output pixels per tile side, a = m + 2 patch side, a * a positions */
+#define WINO_NPOS(m) (((m) + 2) * ((m) + 2))
+static int wino_th(int H, int m) { return (H + m - 1) / m; }
+static int wino_tw(int W, int m) { return (W + m - 1) / m; }
+
+/* M[npos][Cout][TH*TW] += chains over the Cin channels of one source (pad: [Cin][H+2][W+2], zero border).  A map whose height is not a multiple of m (a
+ * top-layer map, e.g. 20 x 15): the rows below the map read as zeros and the outputs below it are dropped. */
+static float* wino_input(const float* pad, int Cin, int H, int W, int m)   /* -> V[Cin][npos][TH*TW] (malloc'ed): B^T d B of every tile of every channel */
+{
+    const int TH = wino_th(H, m), TW = wino_tw(W, m), NT = TH * TW, PW = W + 2, PH = H + 2, np = WINO_NPOS(m);
     const size_t PP = (size_t)PW * PH;
-    float* V = (float*)malloc(sizeof(float) * (size_t)Cin * 16 * NT);
+    float* V = (float*)malloc(sizeof(float) * (size_t)Cin * np * NT);
 #pragma omp parallel for schedule(static) num_threads(EIG_NT)
     for (int c = 0; c < Cin; c++) {
         const float* pc = pad + (size_t)c * PP;
-        float* vc = V + (size_t)c * 16 * NT;
+        float* vc = V + (size_t)c * np * NT;
         for (int ty = 0; ty < TH; ty++)
             for (int tx = 0; tx < TW; tx++) {
-                float d[4][4], t[4][4];
-                for (int i = 0; i < 4; i++)
-                    for (int j = 0; j < 4; j++) d[i][j] = (2 * ty + i < PH) ? pc[(size_t)(2 * ty + i) * PW + 2 * tx + j] : 0.0f;  /* pad offset +1 absorbs the -1 */
-                for (int j = 0; j < 4; j++) {
-                    t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
-                }
                 const int T = ty * TW + tx;
-                for (int i = 0; i < 4; i++) {
-                    vc[(size_t)(i * 4 + 0) * NT + T] = t[i][0] - t[i][2];
-                    vc[(size_t)(i * 4 + 1) * NT + T] = t[i][1] + t[i][2];
-                    vc[(size_t)(i * 4 + 2) * NT + T] = t[i][2] - t[i][1];
-                    vc[(size_t)(i * 4 + 3) * NT + T] = t[i][1] - t[i][3];
+                if (m == 2) {
+                    float d[4][4], t[4][4];
+                    for (int i = 0; i < 4; i++)
+                        for (int j = 0; j < 4; j++) d[i][j] = (2 * ty + i < PH) ? pc[(size_t)(2 * ty + i) * PW + 2 * tx + j] : 0.0f;  /* pad offset +1 absorbs the -1 */
+                    for (int j = 0; j < 4; j++) {
+                        t[0][j] = d[0][j] - d[2][j]; t[1][j] = d[1][j] + d[2][j]; t[2][j] = d[2][j] - d[1][j]; t[3][j] = d[1][j] - d[3][j];
+                    }
+                    for (int i = 0; i < 4; i++) {
+                        vc[(size_t)(i * 4 + 0) * NT + T] = t[i][0] - t[i][2];
+                        vc[(size_t)(i * 4 + 1) * NT + T] = t[i][1] + t[i][2];
+                        vc[(size_t)(i * 4 + 2) * NT + T] = t[i][2] - t[i][1];
+                        vc[(size_t)(i * 4 + 3) * NT + T] = t[i][1] - t[i][3];
+                    }
+                } else {
+                    float d[6][6], t[6][6], o6[6];
+                    for (int i = 0; i < 6; i++)
+                        for (int j = 0; j < 6; j++) d[i][j] = (4 * ty + i < PH && 4 * tx + j < PW) ? pc[(size_t)(4 * ty + i) * PW + 4 * tx + j] : 0.0f;
+                    for (int j = 0; j < 6; j++) { wino4_in1d(&d[0][j], 6, o6); for (int i = 0; i < 6; i++) t[i][j] = o6[i]; }   /* rows: B^T d */
+                    for (int i = 0; i < 6; i++) { wino4_in1d(&t[i][0], 1, o6); for (int j = 0; j < 6; j++) vc[(size_t)(i * 6 + j) * NT + T] = o6[j]; }   /* columns */
                 }
             }
     }
     return V;
 }
-/* M[16][Cout][TH*TW]: the sixteen chains continue over the Cin channels whose transformed tiles are in V */
-static void wino_chains(float* M, const float* V, const float* w, int Cout, int Cin, int H, int W)
+/* M[npos][Cout][TH*TW]: the chains continue over the Cin channels whose transformed tiles are in V */
+static void wino_chains(float* M, const float* V, const float* w, int Cout, int Cin, int H, int W, int m)
 {
-    const int NT = ((H + 1) / 2) * (W / 2);
-    float* U = (float*)malloc(sizeof(float) * (size_t)Cout * Cin * 16);
-    for (size_t oc = 0; oc < (size_t)Cout * Cin; oc++) wino_weights(w + oc * 9, U + oc * 16);
+    const int NT = wino_th(H, m) * wino_tw(W, m), np = WINO_NPOS(m);
+    float* U = (float*)malloc(sizeof(float) * (size_t)Cout * Cin * np);
+    for (size_t oc = 0; oc < (size_t)Cout * Cin; oc++) { if (m == 2) wino_weights(w + oc * 9, U + oc * np); else wino4_weights(w + oc * 9, U + oc * np); }
 #pragma omp parallel for schedule(static) num_threads(EIG_NT)
-    for (int op = 0; op < Cout * 16; op++) {
-        const int o = op / 16, pos = op - o * 16;
-        float* m = M + ((size_t)pos * Cout + o) * NT;
+    for (int op = 0; op < Cout * np; op++) {
+        const int o = op / np, pos = op - o * np;
+        float* mm = M + ((size_t)pos * Cout + o) * NT;
         for (int c = 0; c < Cin; c++) {
-            const float u = U[((size_t)o * Cin + c) * 16 + pos];
-            const float* v = V + ((size_t)c * 16 + pos) * NT;
-            for (int T = 0; T < NT; T++) m[T] = fmaf(v[T], u, m[T]);
+            const float u = U[((size_t)o * Cin + c) * np + pos];
+            const float* v = V + ((size_t)c * np + pos) * NT;
+            for (int T = 0; T < NT; T++) mm[T] = fmaf(v[T], u, mm[T]);
         }
     }
     free(U);
 }
-static void wino_accumulate(float* M, const float* pad, const float* w, int Cout, int Cin, int H, int W)
+static void wino_accumulate(float* M, const float* pad, const float* w, int Cout, int Cin, int H, int W, int m)
 {
-    float* V = wino_input(pad, Cin, H, W);
-    wino_chains(M, V, w, Cout, Cin, H, W);
+    float* V = wino_input(pad, Cin, H, W, m);
+    wino_chains(M, V, w, Cout, Cin, H, W, m);
     free(V);
 }
 
-/* out[o][2ty+a][2tx+b] = y_ab of the output transform (overwrites out) */
-static void wino_finish(float* out, const float* M, int Cout, int H, int W)
+/* out[o][m ty + a][m tx + b] = y_ab of the output transform (overwrites out) */
+static void wino_finish(float* out, const float* M, int Cout, int H, int W, int m)
 {
-    const int TH = (H + 1) / 2, TW = W / 2, NT = TH * TW;
+    const int TH = wino_th(H, m), TW = wino_tw(W, m), NT = TH * TW;
 #pragma omp parallel for schedule(static) num_threads(EIG_NT)
     for (int o = 0; o < Cout; o++)
         for (int ty = 0; ty < TH; ty++)
             for (int tx = 0; tx < TW; tx++) {
                 const int T = ty * TW + tx;
-                float m[16], c[4][2];
-                for (int p = 0; p < 16; p++) m[p] = M[((size_t)p * Cout + o) * NT + T];
-                for (int i = 0; i < 4; i++) {
-                    c[i][0] = (m[i * 4 + 0] + m[i * 4 + 1]) + m[i * 4 + 2];
-                    c[i][1] = (m[i * 4 + 1] - m[i * 4 + 2]) - m[i * 4 + 3];
-                }
                 float* po = out + (size_t)o * H * W;
-                for (int b = 0; b < 2; b++) {
-                    po[(size_t)(2 * ty) * W + 2 * tx + b] = (c[0][b] + c[1][b]) + c[2][b];
-                    if (2 * ty + 1 < H) po[(size_t)(2 * ty + 1) * W + 2 * tx + b] = c[1][b] - (c[2][b] + c[3][b]);
+                if (m == 2) {
+                    float mv[16], c[4][2];
+                    for (int p = 0; p < 16; p++) mv[p] = M[((size_t)p * Cout + o) * NT + T];
+                    for (int i = 0; i < 4; i++) {
+                        c[i][0] = (mv[i * 4 + 0] + mv[i * 4 + 1]) + mv[i * 4 + 2];
+                        c[i][1] = (mv[i * 4 + 1] - mv[i * 4 + 2]) - mv[i * 4 + 3];
+                    }
+                    for (int b = 0; b < 2; b++) {
+                        po[(size_t)(2 * ty) * W + 2 * tx + b] = (c[0][b] + c[1][b]) + c[2][b];
+                        if (2 * ty + 1 < H) po[(size_t)(2 * ty + 1) * W + 2 * tx + b] = c[1][b] - (c[2][b] + c[3][b]);
+                    }
+                } else {
+                    float mv[36], c[6][4], y4[4];
+                    for (int p = 0; p < 36; p++) mv[p] = M[((size_t)p * Cout + o) * NT + T];
+                    for (int i = 0; i < 6; i++) wino4_out1d(mv + i * 6, 1, c[i]);      /* columns in each row xi: c_xi,b */
+                    for (int b = 0; b < 4; b++) {
+                        wino4_out1d(&c[0][b], 4, y4);                                  /* rows: y_a,b */
+                        for (int aa = 0; aa < 4; aa++)
+                            if (4 * ty + aa < H && 4 * tx + b < W) po[(size_t)(4 * ty + aa) * W + 4 * tx + b] = y4[aa];
+                    }
                 }
             }
 }
-static size_t wino_m_floats(int Cout, int H, int W) { return (size_t)16 * Cout * ((H + 1) / 2) * (W / 2); }
+static size_t wino_m_floats(int Cout, int H, int W, int m) { return (size_t)WINO_NPOS(m) * Cout * wino_th(H, m) * wino_tw(W, m); }
+/* tile size of a Winograd operator of kind 0 ConvLSTM / 1 ConvA / 2 ConvP: bits 25 / 26 / 27 of wino_mask select F(4x4, 3x3) (csrc/conv_wino4.h), else F(2x2, 3x3) */
+static int eig_wino_tile(int wino_mask, int kind) { return ((wino_mask >> (25 + kind)) & 1) ? 4 : 2; }
 
 /* Which operators take the Winograd form (the HIP engine applies the same rule, eigen_engine.hip: wino_op).  wino_mask: bit l =
  * ConvLSTM_l, bit 8 + l = ConvA_l, bit 16 + l = ConvP_l.  kind 0 ConvLSTM_l, 1 ConvA_l, 2 ConvP_l; Cin: every full-resolution source
@@ -434,23 +509,27 @@ static int eig_wino_op(int wino_mask, int kind, int l, int Cin, int Cout, int H,
 static int eig_wino_fuse_up(int wino_mask, int l, int L, int W, int Cup) { return ((wino_mask >> 24) & 1) && l < L - 1 && (W % 8) == 0 && (Cup % 8) == 0; }
 
 /* exported for kernel-level tests: out[Cout][H][W] = Winograd chain over the listed full-resolution sources (canonical order) */
-int eig_oracle_wino_chain(int ns, const float* const* src, const int* cin, const float* const* w, int Cout, int H, int W, float* out)
+int eig_oracle_wino_chain_m(int ns, const float* const* src, const int* cin, const float* const* w, int Cout, int H, int W, float* out, int m)
 {
-    if (W & 1) return -1;
+    if ((W & 1) || (m != 2 && m != 4) || (m == 4 && (W & 3))) return -1;
     size_t maxc = 0;
     for (int s = 0; s < ns; s++) if ((size_t)cin[s] > maxc) maxc = (size_t)cin[s];
     float* pad = (float*)malloc(sizeof(float) * maxc * (H + 2) * (W + 2));
-    float* M = (float*)calloc(wino_m_floats(Cout, H, W), sizeof(float));
+    float* M = (float*)calloc(wino_m_floats(Cout, H, W, m), sizeof(float));
     for (int s = 0; s < ns; s++) {
         const int PW = W + 2;
         memset(pad, 0, sizeof(float) * (size_t)cin[s] * PW * (H + 2));
         for (int c = 0; c < cin[s]; c++)
             for (int y = 0; y < H; y++) memcpy(pad + ((size_t)c * (H + 2) + y + 1) * PW + 1, src[s] + ((size_t)c * H + y) * W, sizeof(float) * W);
-        wino_accumulate(M, pad, w[s], Cout, cin[s], H, W);
+        wino_accumulate(M, pad, w[s], Cout, cin[s], H, W, m);
     }
-    wino_finish(out, M, Cout, H, W);
+    wino_finish(out, M, Cout, H, W, m);
     free(pad); free(M);
     return 0;
+}
+int eig_oracle_wino_chain(int ns, const float* const* src, const int* cin, const float* const* w, int Cout, int H, int W, float* out)
+{
+    return eig_oracle_wino_chain_m(ns, src, cin, w, Cout, H, W, out, 2);
 }
 
 static inline float relu(float v) { return v > 0.0f ? v : 0.0f; }
@@ -570,9 +649,10 @@ static void prednet_step(prednet_t* n, const float* x)
         fill_padded(n->pad, n->E[l - 1], Ci, Hi, Wi, 0);
         memset(n->tmp, 0, sizeof(float) * (size_t)Co * Hi * Wi);
         if (eig_wino_op(n->wino_mask, 1, l, n->ch[l - 1], Co, Hi, Wi, 0)) {  /* Winograd form: the 2x2 tile is the pooling window */
-            float* M = (float*)calloc(wino_m_floats(Co, Hi, Wi), sizeof(float));
-            wino_accumulate(M, n->pad, n->convA_w[l], Co, Ci, Hi, Wi);
-            wino_finish(n->tmp, M, Co, Hi, Wi);
+            const int wm = eig_wino_tile(n->wino_mask, 1);
+            float* M = (float*)calloc(wino_m_floats(Co, Hi, Wi, wm), sizeof(float));
+            wino_accumulate(M, n->pad, n->convA_w[l], Co, Ci, Hi, Wi, wm);
+            wino_finish(n->tmp, M, Co, Hi, Wi, wm);
             free(M);
         } else
         conv3x3_chain(n->tmp, n->pad, n->convA_w[l], Co, Ci, Hi, Wi);
@@ -605,23 +685,25 @@ static void prednet_step(prednet_t* n, const float* x)
         /* one chain over the full-resolution sources E_l, h_l (ConvLSTM.__call__: x_*0, h_*) ... */
         if (eig_wino_op(n->wino_mask, 0, l, C, C, H, W, l == L - 1)) {  /* ... in its Winograd form: 16 chains per 2x2 tile */
             const int fuse = l < L - 1 && eig_wino_fuse_up(n->wino_mask, l, L, W, n->ch[l + 1]);
-            float* M = (float*)calloc(4 * wino_m_floats(C, H, W), sizeof(float));   /* the sixteen chains of each of the four gates */
+            const int wm = (fuse || l == L - 1) ? eig_wino_tile(n->wino_mask, 0) : 2;   /* (F(4x4) only where the unpooled source rides in the chains, or there is none) */
+            const size_t mf = wino_m_floats(C, H, W, wm);
+            float* M = (float*)calloc(4 * mf, sizeof(float));   /* the chains of each of the four gates */
             float* V;
             fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
-            V = wino_input(n->pad, 2 * C, H, W);
-            for (int g = 0; g < 4; g++) wino_chains(M + g * wino_m_floats(C, H, W), V, n->wx0[l][g], C, 2 * C, H, W);
+            V = wino_input(n->pad, 2 * C, H, W, wm);
+            for (int g = 0; g < 4; g++) wino_chains(M + g * mf, V, n->wx0[l][g], C, 2 * C, H, W, wm);
             free(V);
             if (fuse) {   /* x_g1(unpooling_2d(R_{l+1})) in the same chains */
                 fill_padded(n->pad, n->h[l + 1], n->ch[l + 1], H, W, 1);
-                V = wino_input(n->pad, n->ch[l + 1], H, W);
-                for (int g = 0; g < 4; g++) wino_chains(M + g * wino_m_floats(C, H, W), V, n->wx1[l][g], C, n->ch[l + 1], H, W);
+                V = wino_input(n->pad, n->ch[l + 1], H, W, wm);
+                for (int g = 0; g < 4; g++) wino_chains(M + g * mf, V, n->wx1[l][g], C, n->ch[l + 1], H, W, wm);
                 free(V);
             }
             fill_padded(n->pad, n->h[l], C, H, W, 0);
-            V = wino_input(n->pad, C, H, W);
-            for (int g = 0; g < 4; g++) wino_chains(M + g * wino_m_floats(C, H, W), V, n->wh[l][g], C, C, H, W);
+            V = wino_input(n->pad, C, H, W, wm);
+            for (int g = 0; g < 4; g++) wino_chains(M + g * mf, V, n->wh[l][g], C, C, H, W, wm);
             free(V);
-            for (int g = 0; g < 4; g++) wino_finish(n->gate + (size_t)g * C * hw, M + g * wino_m_floats(C, H, W), C, H, W);
+            for (int g = 0; g < 4; g++) wino_finish(n->gate + (size_t)g * C * hw, M + g * mf, C, H, W, wm);
             free(M);
         } else {
         fill_padded(n->pad, n->E[l], 2 * C, H, W, 0);
@@ -679,9 +761,10 @@ static void prednet_step(prednet_t* n, const float* x)
         fill_padded(n->pad, n->h[l], C, H, W, 0);
         memset(n->gate, 0, sizeof(float) * C * hw);
         if (eig_wino_op(n->wino_mask, 2, l, C, C, H, W, l == L - 1)) {
-            float* M = (float*)calloc(wino_m_floats(C, H, W), sizeof(float));
-            wino_accumulate(M, n->pad, n->convP_w[l], C, C, H, W);
-            wino_finish(n->gate, M, C, H, W);
+            const int wm = eig_wino_tile(n->wino_mask, 2);
+            float* M = (float*)calloc(wino_m_floats(C, H, W, wm), sizeof(float));
+            wino_accumulate(M, n->pad, n->convP_w[l], C, C, H, W, wm);
+            wino_finish(n->gate, M, C, H, W, wm);
             free(M);
         } else
         conv3x3_chain(n->gate, n->pad, n->convP_w[l], C, C, H, W);

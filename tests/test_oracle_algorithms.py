@@ -136,6 +136,9 @@ def test_winograd_statement_is_the_same_convolution(oracle_lib):
         scale = np.abs(ref).max()
         assert np.abs(wino - ref).max() <= 3e-6 * scale and np.abs(direct - ref).max() <= 3e-6 * scale
         assert not np.array_equal(wino, direct)   # ... but another order: not the same bits
+        # F(4x4, 3x3) (round 5, csrc/conv_wino4.h): the same convolution again, at the round-off of its larger transforms (~1e-5 relative)
+        wino4 = oracle_lib.wino_chain(srcs, ws, H, W, m=4)
+        assert np.abs(wino4 - ref).max() <= 3e-5 * scale and not np.array_equal(wino4, wino)
     with pytest.raises(ValueError):
         oracle_lib.wino_chain([np.zeros((1, 4, 5), np.float32)], [np.zeros((1, 1, 3, 3), np.float32)], 4, 5)
     ch, w, h = [3, 48, 96], 64, 40   # ConvLSTM 1-2, ConvA 2, ConvP 1-2 eligible; layer 1 has W % 8 == 0: its unpooled source can ride in the chains
@@ -143,11 +146,11 @@ def test_winograd_statement_is_the_same_convolution(oracle_lib):
     img = (rng.random((3, h, w)) * 255).astype(np.uint8)
     _, p_direct = oracle_lib.prednet_rollout(wts, ch, w, h, img, 4, 1, return_float=True, wino_mask=0)
     seen = set()
-    for mask in (0x6, 0x0600, 0x060000, 0x00FFFFFE, 0x01FFFFFE):
+    for mask in (0x6, 0x0600, 0x060000, 0x00FFFFFE, 0x01FFFFFE, 0x0FFFFFFE, 0x03FFFFFE):   # (the last two: F(4x4, 3x3) for every operator / the ConvLSTMs)
         _, p = oracle_lib.prednet_rollout(wts, ch, w, h, img, 4, 1, return_float=True, wino_mask=mask)
-        assert np.abs(p - p_direct).max() <= 2e-6
+        assert np.abs(p - p_direct).max() <= (2e-6 if mask < 0x02000000 else 2e-5)
         seen.add(p.tobytes())
-    assert len(seen) == 5 and p_direct.tobytes() not in seen   # every setting is its own (documented) order
+    assert len(seen) == 7 and p_direct.tobytes() not in seen   # every setting is its own (documented) order
     assert oracle_lib.wino_mask_default() == 0x01FFFFFE or "EIGEN_WINOGRAD" in os.environ or os.environ.get("EIGEN_WINO_FUSEUP") == "0"
 
 
