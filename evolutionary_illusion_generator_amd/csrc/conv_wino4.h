@@ -16,19 +16,21 @@
 // chains: its 6x6 patch has rows / columns (a, b, b, c, c, d), p and q above are then the same operation on the same operands, T2 is an exact zero, and the positions
 // with xi = 2 or nu = 2 are chains of exact zeros -- not built, not read, not multiplied: 25 of 36.
 //
-// Block = 16 x 32 output pixels of one image = 32 tiles of 4x4 = two REGIONS of 16 tiles (the left / right 16 x 16 pixels; MFMA row r = 4 ty + tx) x NI 16-column
-// N-tiles; TWELVE waves (three per SIMD, <= 168 VGPRs), one block per CU.  The structure is conv_winoh.h's: no transformed-input buffer --
+// Block = 16 x 32 output pixels of one image = 32 tiles of 4x4 = two REGIONS of 16 tiles (the upper / lower 8 x 32 pixels = 2 x 8 tiles; MFMA row r = 8 ty + tx:
+// with the 40-float plane rows the sixteen 16-byte patch reads of a lane group fall on sixteen different bank slots) x NI 16-column N-tiles; TWELVE waves (three per
+// SIMD, <= 168 VGPRs), one block per CU.  The structure is conv_winoh.h's: no transformed-input buffer --
 //   wave (rg, xi), xi = 0..5, multiplies region rg for the six positions (xi, nu = 0..5): 6 NI accumulator tiles; it BUILDS its A operands itself: lane (q, col) holds
-//     channel q of the K-block for tile col, reads the three or four patch rows that row xi of B^T d needs (per row a 16-byte read and two 4-byte reads out of the
-//     channel's plane), 12-18 operations for the row, 12 for the column pass;
+//     channel q of the K-block for tile col, reads the three or four patch rows that row xi of B^T d needs (per row three aligned 16-byte reads out of the
+//     channel's plane: conflict-free, where 4-byte reads of the two end columns were 8-way conflicted and cost the first version 25 %), 12-18 operations for the
+//     row, 12 for the column pass;
 //   K-block = FOUR channels (one MFMA k-step): 6 NI MFMAs per wave in six chunks with the operand read of the next chunk, staging in slices between the chunks;
 //   LDS: U ring 3 x 36 KB ([36 pos][4 ch][16 cols][NI]; the packed weights are [K-blocks of 8][36][8][16][NI], the 4-channel half of a position = one contiguous
 //     KB = one LDS-DMA instruction, three per wave and K-block), plane ring 3 x 4 x [18 rows][40 floats] (one DMA instruction per wave and K-block);
 //     U(j) is fetched during K-block j - 2 and waited for at its end, plane(j) during j - 3 and waited for at the end of j - 2 (vmcnt(1)): both are visible to
 //     everyone during K-block j - 1, whose last instructions read the first operands of j in front of the barrier -- the barrier never drains the matrix pipe;
 //   output transform: along nu in-lane (c_xi,b: 4 x NI vectors), then the six waves of a region exchange their c rows through LDS in two rounds of 96 KB
-//     (b = 0, 1 and b = 2, 3); ConvLSTM / ConvP: wave xi < 4 finishes output row a = xi of every tile of its region -- a lane owns 16 CONTIGUOUS pixels of one image
-//     row per channel (four 16-byte accesses per tensor), all four gates in-lane; ConvA: wave xi < 4 finishes the row PAIR xi >> 1 for the N-tiles of parity
+//     (b = 0, 1 and b = 2, 3); ConvLSTM / ConvP: wave xi < 4 finishes output row a = xi of every tile of its region -- a lane (q, col) owns the four tiles
+//     (q >> 1, 4 (q & 1) + e), i.e. 16 CONTIGUOUS pixels of one image row per channel (four 16-byte accesses per tensor), all four gates in-lane; ConvA: wave xi < 4 finishes the row PAIR xi >> 1 for the N-tiles of parity
 //     xi & 1, so that the 2x2 pooling windows of the 4x4 tile stay in one lane.
 #pragma once
 #include "conv_winoh.h"
@@ -93,6 +95,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     constexpr int U8 = wino4_u_floats(NI);
     constexpr int NUS = W4_NUS, NPS = W4_NPS, KC = W4_KC, PS = W4_PS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    const unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py with EIG_TL_WAVES=12)
     float* const Ub = lds;
     float* const Pb = lds + NUS * W4_U_FLOATS;
     const int tid = threadIdx.x;
@@ -171,10 +174,10 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                                                      (int)(so + (unsigned)i * POS), 0, 0);
     };
 
-    // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) = (col >> 2, col & 3) of region rg (MFMA row r = 4 ty + tx: accumulator register = tx)
-    const int t_ty = col >> 2, t_tx = col & 3;
-    const float* const pbase_n = Pb + q * PS + (4 * t_ty) * W4_ROW + 16 * rg + 4 * t_tx + 3;   // patch row 0, column 0 (columns 1 .. 4 are one aligned 16-byte chunk)
-    const float* const pbase_u = Pb + q * PS + (2 * t_ty) * W4_ROW + 8 * rg + 2 * t_tx + 3;    // source row s, column s of an unpooled patch (half-resolution plane)
+    // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) = (col >> 3, col & 7) of region rg (rows 8 rg .. 8 rg + 7 of the block; MFMA row r = 8 ty + tx)
+    const int t_ty = col >> 3, t_tx = col & 7;
+    const float* const pbase_n = Pb + q * PS + (8 * rg + 4 * t_ty) * W4_ROW + 4 * t_tx;        // patch row 0, the aligned chunk that holds patch column 0 in its last float: columns 0 .. 5 = floats 3 .. 8
+    const float* const pbase_u = Pb + q * PS + (4 * rg + 2 * t_ty) * W4_ROW + 2 * t_tx + 3;    // source row s, column s of an unpooled patch (half-resolution plane)
 
     // accumulators: position (xi, nu), N-tile ni
     f32x4 acc[6][NI];
@@ -185,6 +188,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int b_off = xi * 6 * W4_UPOS + (q * 16 + col) * NI;   // U[pos = 6 xi + nu][ch = q][col][0 .. NI)
 
     // ---- prologue: the U slabs of K-blocks 0, 1 and the planes of K-blocks 0, 1, 2
+    const unsigned long long tq_setup = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     dma_u(0, 0);
     dma_plane_at(0, 0);
     dma_u(1, 1);
@@ -192,13 +196,24 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     dma_plane_at(2, 2);
     EIG4_WAITCNT(0x0F71);   // all but the plane of K-block 2
     EIG4_BARRIER();
+    const unsigned long long tq_k0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
+    unsigned long long tq_k1 = 0, tq_x = 0, tq_y = 0;
+    // [entry, set-up done, K loop start, K loop end, first exchange barrier passed, y ready (gates start), exit, HW_ID | XCC_ID << 32]
+    auto timeline = [&]() __attribute__((always_inline)) {
+        if (EIG_TIMING && a.dbg && lane == 0) {
+            unsigned hwid, xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            unsigned long long* dd = a.dbg + ((size_t)blockIdx.x * W4_WAVES + wv) * 8;
+            dd[0] = tq_entry; dd[1] = tq_setup; dd[2] = tq_k0; dd[3] = tq_k1; dd[4] = tq_x; dd[5] = tq_y; dd[6] = __builtin_readcyclecounter();
+            dd[7] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+        }
+    };
 
     // The K loops exist once per xi (role_tag) behind ONE wave-uniform branch: the patch rows a wave reads and its row combination are compile-time constants of xi,
     // and so are the positions an unpooled-source K-block skips.
     auto kloops = [&](auto role_tag) __attribute__((always_inline)) {
         constexpr int XI = decltype(role_tag)::value;
-        constexpr int NR = w4_nrows(XI);
-        float pr[NR][6];       // the patch rows of the NEXT K-block that row XI of B^T d needs
         float v[6];            // A operands of the current K-block (built at the end of the previous one)
         float bq[NI];          // B operand of the current K-block's first chunk, read before the barrier in front of it
         int rslot = 0;         // plane slot of the K-block whose patch rows are read next
@@ -233,45 +248,61 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             }
         };
         plane_source(3 < nkb ? 3 : nkb - 1);   // (slot 0 = 3 % 3)
-        // patch rows of the K-block in slot rslot (up: an unpooled-source K-block), then advance rslot
-        auto read_rows = [&](bool up) __attribute__((always_inline)) {
-            const int so = rslot * (KC * PS);
-            rslot = rslot == NPS - 1 ? 0 : rslot + 1;
+        // Row XI of B^T d of the next K-block's patch in TWO phases (half the registers in flight; the same operations in the same order as w4_row):
+        //   phase 0 reads the patch rows of the INNER operation (xi 1, 2: rows 2, 4 -> p = fmaf(-4, d2, d4); xi 3, 4: r = d4 - d2; xi 0: fmaf(-5, d2, d4); xi 5: fmaf(-5, d3, d5)),
+        //   phase 1 reads the others and finishes (xi 1 / 2: p +- fmaf(-4, d1, d3); xi 3 / 4: fmaf(+-2, d3 - d1, r); xi 0: fmaf(4, d0, .); xi 5: fmaf(4, d1, .)).
+        float pr[2][6];        // the two patch rows of a phase
+        float t[6];            // phase 0: the inner operation; phase 1: row XI of B^T d
+        int rso = 0;           // LDS offset of the plane slot the current K-block reads its patch rows from
+        bool rup = false;
+        // k-th patch row (of w4_rowidx(XI, .)) a phase reads: phase 0 -> k = 1, 3 (xi 0, 5: 1, 2), phase 1 -> k = 0, 2 (xi 0, 5: 0)
+        auto read_rows = [&](int ph) __attribute__((always_inline)) {
             if (EIG_W4_DIAG & 4) return;
-            if (up) {   // rows s + (0, 1, 1, 2, 2, 3), columns likewise: four distinct source values per row
-                const float* const p = pbase_u + so;
+            constexpr bool END = XI == 0 || XI == 5;
 #pragma unroll
-                for (int k = 0; k < NR; ++k) {
-                    const int sr = w4_uprow(w4_rowidx(XI, k));
-                    bool dup = false;
-#pragma unroll
-                    for (int k2 = 0; k2 < k; ++k2)
-                        if (w4_uprow(w4_rowidx(XI, k2)) == sr) { for (int c = 0; c < 6; ++c) pr[k][c] = pr[k2][c]; dup = true; }
-                    if (dup) continue;
-                    const float* const pl = p + sr * W4_ROW;
+            for (int j = 0; j < 2; ++j) {
+                const int k = ph == 0 ? (END ? 1 + j : 1 + 2 * j) : (END ? 0 : 2 * j);
+                if (ph == 1 && END && j == 1) continue;
+                if (rup) {   // rows s + (0, 1, 1, 2, 2, 3), columns likewise: four distinct source values per row
+                    const float* const pl = pbase_u + rso + w4_uprow(w4_rowidx(XI, k)) * W4_ROW;
                     const float s0 = pl[0], s1_ = pl[1], s2 = pl[2], s3 = pl[3];
-                    pr[k][0] = s0; pr[k][1] = s1_; pr[k][2] = s1_; pr[k][3] = s2; pr[k][4] = s2; pr[k][5] = s3;
-                }
-            } else {
-                const float* const p = pbase_n + so;
-#pragma unroll
-                for (int k = 0; k < NR; ++k) {
-                    const float* const pl = p + w4_rowidx(XI, k) * W4_ROW;
-                    const f32x4 mid = *reinterpret_cast<const f32x4*>(pl + 1);
-                    pr[k][0] = pl[0]; pr[k][1] = mid[0]; pr[k][2] = mid[1]; pr[k][3] = mid[2]; pr[k][4] = mid[3]; pr[k][5] = pl[5];
+                    pr[j][0] = s0; pr[j][1] = s1_; pr[j][2] = s1_; pr[j][3] = s2; pr[j][4] = s2; pr[j][5] = s3;
+                } else {
+                    const f32x4* const pl = reinterpret_cast<const f32x4*>(pbase_n + rso + w4_rowidx(XI, k) * W4_ROW);
+                    const f32x4 c0 = pl[0], c1 = pl[1], c2 = pl[2];   // three aligned 16-byte reads: floats 0 .. 11 of which 3 .. 8 are the patch row
+                    pr[j][0] = c0[3]; pr[j][1] = c1[0]; pr[j][2] = c1[1]; pr[j][3] = c1[2]; pr[j][4] = c1[3]; pr[j][5] = c2[0];
                 }
             }
         };
-        auto build_a = [&]() __attribute__((always_inline)) {   // row XI of B^T d in the six columns, then the 1-D transform along the row
-            if (EIG_W4_DIAG & 4) { for (int c = 0; c < 6; ++c) v[c] = 1.0f; return; }
-            float t[6];
+        auto rows_begin = [&](bool up) __attribute__((always_inline)) {   // the next K-block's plane slot, then phase 0's reads
+            rso = rslot * (KC * PS); rup = up;
+            rslot = rslot == NPS - 1 ? 0 : rslot + 1;
+            read_rows(0);
+        };
+        auto rows_mid = [&]() __attribute__((always_inline)) {     // the inner operation from phase 0's rows, then phase 1's reads
+            if (!(EIG_W4_DIAG & 4)) {
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    if constexpr (XI == 0 || XI == 5) t[c] = fmaf(-5.0f, pr[0][c], pr[1][c]);
+                    else if constexpr (XI == 1 || XI == 2) t[c] = fmaf(-4.0f, pr[0][c], pr[1][c]);
+                    else t[c] = pr[1][c] - pr[0][c];
+                }
+            }
+            read_rows(1);
+        };
+        auto rows_end = [&]() __attribute__((always_inline)) {     // row XI of B^T d
+            if (EIG_W4_DIAG & 4) return;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                float d[NR];
-#pragma unroll
-                for (int k = 0; k < NR; ++k) d[k] = pr[k][c];
-                t[c] = w4_row<XI>(d);
+                if constexpr (XI == 0 || XI == 5) t[c] = fmaf(4.0f, pr[0][c], t[c]);
+                else if constexpr (XI == 1) t[c] = t[c] + fmaf(-4.0f, pr[0][c], pr[1][c]);
+                else if constexpr (XI == 2) t[c] = t[c] - fmaf(-4.0f, pr[0][c], pr[1][c]);
+                else if constexpr (XI == 3) t[c] = fmaf(2.0f, pr[1][c] - pr[0][c], t[c]);
+                else t[c] = fmaf(-2.0f, pr[1][c] - pr[0][c], t[c]);
             }
+        };
+        auto build_cols = [&]() __attribute__((always_inline)) {   // ... then the 1-D transform along the row: the six A operands
+            if (EIG_W4_DIAG & 4) { for (int c = 0; c < 6; ++c) v[c] = 1.0f; return; }
             w4_in1d(t[0], t[1], t[2], t[3], t[4], t[5], v);
         };
         auto read_b = [&](int slot, int nu, float* dst) __attribute__((always_inline)) {
@@ -287,7 +318,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         // One K-block.  kind_tag: 0 full, 1 unpooled source, 2 run time; nk_tag: kind of K-block kb + 1 (whose patch rows are read now), same codes; last_tag: the last
         // K-block (nothing to stage).  On entry v and bq hold the A operands and the first B operand of this K-block: the first instruction behind the barrier is an MFMA,
         // and the staging work sits in slices BETWEEN the chunks -- patch rows of K-block kb + 1 behind chunk 0, the U fetch behind chunk 1, the plane fetch behind
-        // chunk 2, the A operands of kb + 1 behind the last chunk.
+        // chunk 2, the A operands of kb + 1 behind the last chunks (see slice below).
         auto kiter = [&](const int kb, auto kind_tag, auto nk_tag, auto last_tag) __attribute__((always_inline)) {
             constexpr int KIND = decltype(kind_tag)::value;
             constexpr int NK = decltype(nk_tag)::value;
@@ -297,16 +328,26 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             constexpr int NCH = IDLE ? 0 : (UP ? 5 : 6);   // chunks: nu = 0, 1, (2,) 3, 4, 5
             const int nslot = uslot == NUS - 1 ? 0 : uslot + 1;
             float bv[2][NI];
+            // slices of staging work behind the chunks: the U fetch behind chunk 0, the plane fetch behind chunk 1, the patch rows of K-block kb + 1 and row XI of
+            // B^T d in two phases behind chunks NCH - 4 .. NCH - 2 (their registers are needed late), the column pass behind the last chunk
             auto slice = [&](int i) __attribute__((always_inline)) {
                 if constexpr (!LAST) {
-                    if (i == 0) read_rows(NK == 2 ? EIG4_IS_UP(kb + 1) : NK == 1);
-                    if (i == 1) { if (!(EIG_W4_DIAG & 16)) dma_u(kb + 2, fu); fu = fu == NUS - 1 ? 0 : fu + 1; }
-                    if (i == 2) { if (!(EIG_W4_DIAG & 8)) dma_plane(); }
+                    if (i == 0) { if (!(EIG_W4_DIAG & 16)) dma_u(kb + 2, fu); fu = fu == NUS - 1 ? 0 : fu + 1; }
+                    if (i == 1) { if (!(EIG_W4_DIAG & 8)) dma_plane(); }
+                    if (i == NCH - 4) rows_begin(NK == 2 ? EIG4_IS_UP(kb + 1) : NK == 1);
+                    if (i == NCH - 3) rows_mid();
+                    if (i == NCH - 2) rows_end();
+                    if (i == NCH - 1) build_cols();
                 }
             };
             if constexpr (IDLE) {
-                slice(0); slice(1); slice(2);
-                if constexpr (!LAST) { read_b(nslot, 0, bq); build_a(); }
+                if constexpr (!LAST) {
+                    if (!(EIG_W4_DIAG & 16)) dma_u(kb + 2, fu);
+                    fu = fu == NUS - 1 ? 0 : fu + 1;
+                    if (!(EIG_W4_DIAG & 8)) dma_plane();
+                    rows_begin(NK == 2 ? EIG4_IS_UP(kb + 1) : NK == 1); rows_mid(); rows_end();
+                    read_b(nslot, 0, bq); build_cols();
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < NCH; ++i) {
@@ -319,7 +360,6 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) acc[nu][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], b[ni], acc[nu][ni], 0, 0, 0);
                     slice(i);
-                    if (i == NCH - 1) { if constexpr (!LAST) build_a(); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -332,9 +372,9 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         const std::false_type nl{};
         const std::integral_constant<int, 2> rt{};
         int kb = 0;
-        read_rows(EIG4_IS_UP(0));
+        rows_begin(EIG4_IS_UP(0)); rows_mid(); rows_end();
         read_b(0, 0, bq);
-        build_a();
+        build_cols();
         EIG4_WAITCNT(0xC07F);
         EIG4_BARRIER();   // (every wave has read plane 0 out of its slot before anyone's K-block 0 fetches into it)
         // K-blocks [kb, end) of one kind; the LAST K-block of all is left out.  A K-block reads the patch rows of the next one: same kind except at the end of a run.
@@ -355,6 +395,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         case 4: kloops(std::integral_constant<int, 4>{}); break;
         default: kloops(std::integral_constant<int, 5>{}); break;
     }
+    if (EIG_TIMING) tq_k1 = __builtin_readcyclecounter();
 
     // ---- output transform.  Along nu in-lane: c_xi,b (b = 0..3) of every N-tile.
     f32x4 cc[4][NI];
@@ -371,7 +412,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #define EIG4_C(x, bb, ni) (*reinterpret_cast<const f32x4*>(xb + ((((x) * 2 + rg) * 2 + (bb)) * 4 + (ni)) * 256 + lane * 4))   // c_x,b of N-tile ni, published by wave (xi = x, rg)
     const int ch0 = (EPI == EPI_LSTM) ? nblk * 16 + col : nblk * NI * 16 + col;   // channel of N-tile 0 (ConvLSTM: of every gate)
     const size_t cHW = (size_t)HW;
-    // one output row `arow` (0..3) of the four tiles of tile row q: registers e = tx -> pixels x0 + 16 rg + 4 e + b
+    // one output row `arow` (0..3) of the lane's four tiles (ty = q >> 1, tx = 4 (q & 1) + e): register e -> pixels x0 + 16 (q & 1) + 4 e + b of image row y0 + 8 rg + 4 ty + arow
     auto finish_row = [&](int arow, int bb, int ni) __attribute__((always_inline)) -> f32x4 {
         const f32x4 c1 = EIG4_C(1, bb, ni), c2 = EIG4_C(2, bb, ni), c3 = EIG4_C(3, bb, ni), c4 = EIG4_C(4, bb, ni);
         const f32x4 s = c1 + c2, d = c1 - c2, u = c3 + c4, w = c3 - c4;
@@ -393,6 +434,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(xb + (((wv * 2 + bb) * 4 + ni) * 256 + lane * 4)) = cc[2 * rnd + bb][ni];
             __syncthreads();
+            if (EIG_TIMING && rnd == 0) tq_x = __builtin_readcyclecounter();
             if (xi < 4) {
 #pragma unroll
                 for (int bb = 0; bb < 2; ++bb)
@@ -404,17 +446,18 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                     }
             }
         }
-        if (xi >= 4) return;
-        const int gy = y0 + 4 * q + xi;
-        if (gy >= a.H) return;
+        if (EIG_TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq_y = __builtin_readcyclecounter(); }
+        if (xi >= 4) { timeline(); return; }
+        const int gy = y0 + 8 * rg + 4 * (q >> 1) + xi;
+        if (gy >= a.H) { timeline(); return; }
         if constexpr (EPI == EPI_LSTM) {
             const int ch = ch0;
-            if (ch >= a.Cout) return;
+            if (ch >= a.Cout) { timeline(); return; }
             const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
             const size_t cbase = ((size_t)eb * a.Cout + ch) * cHW, ps = (size_t)a.Cout * cHW, pbase = (size_t)ch * cHW;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {   // tile tx = e: pixels gx .. gx + 3 (b = 0..3)
-                const int gx = x0 + 16 * rg + 4 * e;
+            for (int e = 0; e < 4; ++e) {   // tile tx = 4 (q & 1) + e: pixels gx .. gx + 3 (b = 0..3)
+                const int gx = x0 + 16 * (q & 1) + 4 * e;
                 if (gx >= a.W) continue;
                 const size_t pix = (size_t)gy * a.W + gx;
                 const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
@@ -431,6 +474,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                 *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
                 *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
             }
+            timeline();
         } else {
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
@@ -440,7 +484,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                 const size_t base = ((size_t)eb * a.Cout + ch) * cHW;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int gx = x0 + 16 * rg + 4 * e;
+                    const int gx = x0 + 16 * (q & 1) + 4 * e;
                     if (gx >= a.W) continue;
                     f32x4 v4;
 #pragma unroll
@@ -451,7 +495,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         }
     } else {
         // ConvA: wave xi < 4 finishes the row PAIR ap = xi >> 1 (output rows 2 ap, 2 ap + 1) for the N-tiles ni = (xi & 1), (xi & 1) + 2: the 2x2 pooling windows of
-        // the 4x4 tile -- (rows 2 ap, 2 ap + 1) x (columns 2 bp, 2 bp + 1) -- stay in one lane; pooled pixel (2 (4 tyi + q) + ap, (x0 >> 1) + 8 rg + 2 e + bp)
+        // the 4x4 tile -- (rows 2 ap, 2 ap + 1) x (columns 2 bp, 2 bp + 1) -- stay in one lane; pooled pixel ((y0 >> 1) + 4 rg + 2 (q >> 1) + ap, (x0 >> 1) + 8 (q & 1) + 2 e + bp)
         const int ap = xi >> 1, np_ = xi & 1;
         f32x4 y[2][2][4];   // [N-tile k of this wave][row of the pair][b]
 #pragma unroll
@@ -478,7 +522,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         if (xi >= 4) return;
         const int Ho = a.H >> 1, Wo = a.W >> 1;
         const size_t plane = (size_t)Ho * Wo;
-        const int oy = (y0 >> 1) + 2 * q + ap;
+        const int oy = (y0 >> 1) + 4 * rg + 2 * (q >> 1) + ap;
         if (oy >= Ho) return;
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
@@ -490,8 +534,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             const size_t pb = ((size_t)eb * a.Cout + ch) * plane;
             const size_t e0 = ((size_t)eb * 2 * a.Cout + ch) * plane, e1 = e0 + (size_t)a.Cout * plane;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {   // tile tx = e: pooled columns ox, ox + 1
-                const int ox = (x0 >> 1) + 8 * rg + 2 * e;
+            for (int e = 0; e < 4; ++e) {   // tile tx = 4 (q & 1) + e: pooled columns ox, ox + 1
+                const int ox = (x0 >> 1) + 8 * (q & 1) + 2 * e;
                 if (ox >= Wo) continue;
                 const f32x2 p2 = *reinterpret_cast<const f32x2*>(a.P + pb + (size_t)oy * Wo + ox);
                 f32x2 ea, eb2;

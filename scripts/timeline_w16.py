@@ -23,7 +23,7 @@ if "--analyze-only" not in sys.argv:
     cfg = synth.make_config(2, 3)
     genomes = [g for _, g in synth.make_population(pop, cfg, seed=0)]
     wts = weights.synthetic_prednet_weights(ch, W, H, seed=0)
-    fitness.evaluate_population(1, genomes, wts, cfg, W, H, ch, c_dim=3, max_batch=pop)
+    fitness.evaluate_population(1, genomes, wts, cfg, W, H, ch, c_dim=3, max_batch=pop)   # (EIGEN_WINOGRAD / EIGEN_WINOH select the kernel: set EIG_TL_WAVES = 16 / 8 / 12 to match)
     torch.cuda.synchronize()
 
 
