@@ -385,7 +385,7 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
 //   kind 0 ConvLSTM_l, 1 ConvA_l, 2 ConvP_l; Cin = channels of the full-resolution sources (multiples of 8 each), Cout per gate;
 //   H x W = the resolution the convolution runs at; odd H only for an operator of the TOP layer (nothing is pooled / unpooled from it)
 #ifndef EIGEN_WINO_DEFAULT
-#define EIGEN_WINO_DEFAULT 0x01FFFFFE
+#define EIGEN_WINO_DEFAULT 0x0FFFFFFE   // every eligible operator in Winograd form, the unpooled source inside the ConvLSTM chains (bit 24), F(4x4, 3x3) tiles (bits 25-27)
 #endif
 #ifndef EIGEN_WINOH_DEFAULT
 #define EIGEN_WINOH_DEFAULT 0   // (conv_winoh.h, half tiles; bit mask 1 ConvLSTM, 2 ConvA, 4 ConvP)

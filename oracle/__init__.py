@@ -117,8 +117,9 @@ def tensor_names(n_layers):
 
 
 # EIGEN_WINOGRAD unset: every eligible operator -- bit l ConvLSTM_l, bit 8 + l ConvA_l, bit 16 + l ConvP_l (eig_oracle.c: eig_wino_op; the
-# engine's default is the same mask); bit 24: the unpooled source inside the Winograd ConvLSTM's chains (eig_wino_fuse_up)
-WINO_AUTO = 0x01FFFFFE
+# engine's default is the same mask); bit 24: the unpooled source inside the Winograd ConvLSTM's chains (eig_wino_fuse_up); bits 25 / 26 / 27:
+# ConvLSTM / ConvA / ConvP in F(4x4, 3x3) instead of F(2x2, 3x3) (eig_wino_tile; round 5)
+WINO_AUTO = 0x0FFFFFFE
 
 
 def wino_mask_default():

@@ -151,7 +151,7 @@ def test_winograd_statement_is_the_same_convolution(oracle_lib):
         assert np.abs(p - p_direct).max() <= (2e-6 if mask < 0x02000000 else 2e-5)
         seen.add(p.tobytes())
     assert len(seen) == 7 and p_direct.tobytes() not in seen   # every setting is its own (documented) order
-    assert oracle_lib.wino_mask_default() == 0x01FFFFFE or "EIGEN_WINOGRAD" in os.environ or os.environ.get("EIGEN_WINO_FUSEUP") == "0"
+    assert oracle_lib.wino_mask_default() == 0x0FFFFFFE or "EIGEN_WINOGRAD" in os.environ or os.environ.get("EIGEN_WINO_FUSEUP") == "0"
 
 
 def test_prednet_rejects_sizes_the_pooling_cannot_halve(oracle_lib):
