@@ -29,8 +29,9 @@
 //     U(j) is fetched during K-block j - 2 and waited for at its end, plane(j) during j - 3 and waited for at the end of j - 2 (vmcnt(1)): both are visible to
 //     everyone during K-block j - 1, whose last instructions read the first operands of j in front of the barrier -- the barrier never drains the matrix pipe;
 //   output transform: along nu in-lane (c_xi,b: 4 x NI vectors), then the six waves of a region exchange their c rows through LDS in two rounds of 96 KB
-//     (b = 0, 1 and b = 2, 3); ConvLSTM / ConvP: wave xi < 4 finishes output row a = xi of every tile of its region -- a lane (q, col) owns the four tiles
-//     (q >> 1, 4 (q & 1) + e), i.e. 16 CONTIGUOUS pixels of one image row per channel (four 16-byte accesses per tensor), all four gates in-lane; ConvA: wave xi < 4 finishes the row PAIR xi >> 1 for the N-tiles of parity
+//     (b = 0, 1 and b = 2, 3); ConvLSTM / ConvP: a lane (q, col) owns the four tiles (q >> 1, 4 (q & 1) + e), i.e. 16 CONTIGUOUS pixels of an image row per
+//     channel and output row a; wave xi < 4 finishes row a = xi of the tiles e = 0, 1, 2, waves 4 and 5 the tile e = 3 of rows 0, 1 / 2, 3 -- twelve waves share the
+//     gate math (12 / 8 LSTM cells per lane; on eight waves it was 10 us of a block), 16-byte accesses per tensor, all four gates in-lane; ConvA: wave xi < 4 finishes the row PAIR xi >> 1 for the N-tiles of parity
 //     xi & 1, so that the 2x2 pooling windows of the 4x4 tile stay in one lane.
 #pragma once
 #include "conv_winoh.h"
@@ -424,8 +425,19 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         return y;
     };
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
-        // wave xi < 4 finishes output row a = xi: y[ni][b] = vectors over e = tx
-        f32x4 y[NI][4];
+        // All twelve waves finish outputs: wave xi < 4 takes output row a = xi of the lane's tiles e = 0, 1, 2 (12 pixels per channel), wave xi = 4 the tile e = 3 of
+        // rows 0 and 1, wave xi = 5 the tile e = 3 of rows 2 and 3 (8 pixels): 12 / 8 LSTM cells per lane instead of 16 on eight waves and none on four.
+        // ys[ni][b][e]: the lane's pre-activations; waves 4, 5: index e = output row 2 (xi - 4) + e, e = 0, 1
+        float ys[NI][4][3];
+        auto finish_elem = [&](int arow, int bb, int ni) __attribute__((always_inline)) -> float {   // element e = 3 only (4-byte reads)
+            auto C1 = [&](int x) __attribute__((always_inline)) { return xb[((((x) * 2 + rg) * 2 + bb) * 4 + ni) * 256 + lane * 4 + 3]; };
+            const float c1 = C1(1), c2 = C1(2), c3 = C1(3), c4 = C1(4);
+            const float s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
+            if (arow == 0) return (C1(0) + s_) + u_;
+            if (arow == 1) return fmaf(2.0f, w_, d_);
+            if (arow == 2) return fmaf(4.0f, u_, s_);
+            return fmaf(8.0f, w_, d_) + C1(5);
+        };
 #pragma unroll
         for (int rnd = 0; rnd < 2; ++rnd) {
             if (rnd) __syncthreads();   // (everyone has read round 0)
@@ -435,31 +447,35 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                 for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(xb + (((wv * 2 + bb) * 4 + ni) * 256 + lane * 4)) = cc[2 * rnd + bb][ni];
             __syncthreads();
             if (EIG_TIMING && rnd == 0) tq_x = __builtin_readcyclecounter();
-            if (xi < 4) {
 #pragma unroll
-                for (int bb = 0; bb < 2; ++bb)
+            for (int bb = 0; bb < 2; ++bb)
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) {
+                for (int ni = 0; ni < NI; ++ni) {
+                    if (xi < 4) {
                         f32x4 r;
                         switch (xi) { case 0: r = finish_row(0, bb, ni); break; case 1: r = finish_row(1, bb, ni); break; case 2: r = finish_row(2, bb, ni); break; default: r = finish_row(3, bb, ni); break; }
-                        y[ni][2 * rnd + bb] = r;
+                        ys[ni][2 * rnd + bb][0] = r[0]; ys[ni][2 * rnd + bb][1] = r[1]; ys[ni][2 * rnd + bb][2] = r[2];
+                    } else if (xi == 4) {
+                        ys[ni][2 * rnd + bb][0] = finish_elem(0, bb, ni); ys[ni][2 * rnd + bb][1] = finish_elem(1, bb, ni);
+                    } else {
+                        ys[ni][2 * rnd + bb][0] = finish_elem(2, bb, ni); ys[ni][2 * rnd + bb][1] = finish_elem(3, bb, ni);
                     }
-            }
+                }
         }
         if (EIG_TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq_y = __builtin_readcyclecounter(); }
-        if (xi >= 4) { timeline(); return; }
-        const int gy = y0 + 8 * rg + 4 * (q >> 1) + xi;
-        if (gy >= a.H) { timeline(); return; }
-        if constexpr (EPI == EPI_LSTM) {
-            const int ch = ch0;
-            if (ch >= a.Cout) { timeline(); return; }
-            const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
-            const size_t cbase = ((size_t)eb * a.Cout + ch) * cHW, ps = (size_t)a.Cout * cHW, pbase = (size_t)ch * cHW;
+        const int nun = xi < 4 ? 3 : 2;   // units of 4 pixels this wave finishes
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {   // tile tx = 4 (q & 1) + e: pixels gx .. gx + 3 (b = 0..3)
-                const int gx = x0 + 16 * (q & 1) + 4 * e;
-                if (gx >= a.W) continue;
-                const size_t pix = (size_t)gy * a.W + gx;
+        for (int un = 0; un < 3; ++un) {
+            if (un >= nun) break;
+            const int arow = xi < 4 ? xi : 2 * (xi - 4) + un, e = xi < 4 ? un : 3;
+            const int gy = y0 + 8 * rg + 4 * (q >> 1) + arow, gx = x0 + 16 * (q & 1) + 4 * e;
+            if (gy >= a.H || gx >= a.W) continue;
+            const size_t pix = (size_t)gy * a.W + gx;
+            if constexpr (EPI == EPI_LSTM) {
+                const int ch = ch0;
+                if (ch >= a.Cout) continue;
+                const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
+                const size_t cbase = ((size_t)eb * a.Cout + ch) * cHW, ps = (size_t)a.Cout * cHW, pbase = (size_t)ch * cHW;
                 const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
                 const f32x4 pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
                 const f32x4 pf4 = *reinterpret_cast<const f32x4*>(a.peep + ps + pbase + pix);
@@ -468,31 +484,25 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     float cn, hn;
-                    lstm_cell(y[0][b][e], y[1][b][e], y[2][b][e], y[3][b][e], bi, bf, bc, bo, cold4[b], pi4[b], pf4[b], po4[b], cn, hn);
+                    lstm_cell(ys[0][b][un], ys[1][b][un], ys[2][b][un], ys[3][b][un], bi, bf, bc, bo, cold4[b], pi4[b], pf4[b], po4[b], cn, hn);
                     cn4[b] = cn; hn4[b] = hn;
                 }
                 *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
                 *reinterpret_cast<f32x4*>(a.h_out + cbase + pix) = hn4;
-            }
-            timeline();
-        } else {
+            } else {
 #pragma unroll
-            for (int ni = 0; ni < NI; ++ni) {
-                const int ch = ch0 + ni * 16;
-                if (ch >= a.Cout) continue;
-                const float bb_ = a.bias[ch];
-                const size_t base = ((size_t)eb * a.Cout + ch) * cHW;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int gx = x0 + 16 * (q & 1) + 4 * e;
-                    if (gx >= a.W) continue;
+                for (int ni = 0; ni < NI; ++ni) {
+                    const int ch = ch0 + ni * 16;
+                    if (ch >= a.Cout) continue;
+                    const float bb_ = a.bias[ch];
                     f32x4 v4;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) v4[b] = relu_f(y[ni][b][e] + bb_);
-                    *reinterpret_cast<f32x4*>(a.Pout + base + (size_t)gy * a.W + gx) = v4;
+                    for (int b = 0; b < 4; ++b) v4[b] = relu_f(ys[ni][b][un] + bb_);
+                    *reinterpret_cast<f32x4*>(a.Pout + ((size_t)eb * a.Cout + ch) * cHW + pix) = v4;
                 }
             }
         }
+        timeline();
     } else {
         // ConvA: wave xi < 4 finishes the row PAIR ap = xi >> 1 (output rows 2 ap, 2 ap + 1) for the N-tiles ni = (xi & 1), (xi & 1) + 2: the 2x2 pooling windows of
         // the 4x4 tile -- (rows 2 ap, 2 ap + 1) x (columns 2 bp, 2 bp + 1) -- stay in one lane; pooled pixel ((y0 >> 1) + 4 rg + 2 (q >> 1) + ap, (x0 >> 1) + 8 (q & 1) + 2 e + bp)
