@@ -40,7 +40,8 @@ PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, den
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
 LSTM_KERNEL_TAG = "conv3x3_mfma<4, 16, 1"  # the dominant kernel's name in rocprofv3 output (EPI_LSTM = 1)
 WINO_KERNEL_TAG = "wino_kernel<4, 1,"       # ... when the ConvLSTM chains run in their Winograd form (EIGEN_WINOGRAD): the eight-wave kernel (EIGEN_WINO16=0)
-WINO16_KERNEL_TAG = "wino16_kernel<4, 1>"    # ... and the sixteen-wave kernel (csrc/conv_wino16.h, the default)
+WINO16_KERNEL_TAG = "wino16_kernel<4, 1>"    # ... the sixteen-wave F(2x2, 3x3) kernel (csrc/conv_wino16.h; EIGEN_WINOGRAD without bits 25-27)
+WINO4_KERNEL_TAG = "wino4_kernel<4, 1>"      # ... and the F(4x4, 3x3) kernel (csrc/conv_wino4.h, the default)
 N_STEPS_PREDNET = 21          # steps 1-20 + first extension (the 22nd step is never read on the population path)
 
 SHAPES = {
@@ -360,7 +361,7 @@ def make_workload(shape_name, global_pop):
     return cfg, population, wts
 
 
-def supplementary_shape(name, pop, steps, warmup=1):
+def supplementary_shape(name, pop, steps, warmup=1, report_memory=False):
     """One of the other BASELINE.json configurations, single GPU, a few seconds: evals/s through the same drop-in path and the
     all-conv roofline fraction of one profiled pass.  Never part of `value`."""
     import torch
@@ -388,6 +389,10 @@ def supplementary_shape(name, pop, steps, warmup=1):
            "nonzero_fitness": int((fit != 0).sum()),
            "all_conv_frac": allc["frac"], "all_conv_tflops": allc["achieved"], "conv_launches": allc["launches"],
            "tflops_on_survey_8d_flops": flops_ref * pop * steps / dt / 1e12}
+    if report_memory:
+        free, total = torch.cuda.mem_get_info()
+        out["device_memory_in_use_gb"] = (total - free) / 1e9   # everything this process holds on the device while the engine of this shape exists
+        out["device_batches"] = -(-pop // max_batch)
     return out
 
 
@@ -497,6 +502,13 @@ def main():
         seen = torch.empty(2 * world, dtype=torch.int64, device=ids.device)
         dist.all_gather_into_tensor(seen, ids)
         seen = seen.cpu().numpy().reshape(world, 2)
+        # every rank must run the same canonical arithmetic (EIGEN_WINOGRAD selects it): gathered beside the ranks
+        mk = torch.tensor([int(os.environ.get("EIGEN_WINOGRAD") or "0x0FFFFFFE", 0)], dtype=torch.int64, device=ids.device)
+        masks = torch.empty(world, dtype=torch.int64, device=ids.device)
+        dist.all_gather_into_tensor(masks, mk)
+        masks = [int(x) for x in masks.cpu().numpy()]
+        if len(set(masks)) != 1:
+            raise SystemExit("bench.py: the ranks run different EIGEN_WINOGRAD settings (%s): their fitness values are not comparable" % ["0x%08X" % m for m in masks])
         try:
             rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
         except Exception:  # noqa: BLE001
@@ -504,6 +516,7 @@ def main():
         loc = np.asarray([s_["local_ms"] for s_ in shard_stats], dtype=np.float64).mean(axis=0)
         multi = {"backend": backend, "rccl_version": rccl_version, "world_size": dist.get_world_size(), "ranks_seen": [int(x) for x in seen[:, 0]],
                  "devices_seen": [int(x) for x in seen[:, 1]], "hsa_ipc_mode_legacy": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"),
+                 "winograd_mask_all_ranks": "0x%08X" % masks[0],
                  "per_rank_device_ms": [round(float(x), 3) for x in loc], "device_ms_max": float(loc.max()), "device_ms_min": float(loc.min()),
                  "collective_ms_rank0": float(np.mean([s_["collective_ms"] for s_ in shard_stats])),
                  "note": "per-rank evaluate() wall time of its shard (flatten/slice + render + roll-out + flow + score + D2H), mean over the timed "
@@ -514,6 +527,24 @@ def main():
         dist.destroy_process_group()
         if rank != 0:
             return
+        if world > 1:
+            # the SCALE line carries its own N = 1 anchor -- rank 0, now alone, evaluates the WHOLE population on its one GPU (one warm-up
+            # + one timed generation, untimed by the driver), so that a mismatch with the N = 1 BENCH record is visible in one record
+            fitness.clear_engines()
+            torch.cuda.empty_cache()
+            mb1 = min(global_pop, 256)
+            run1 = lambda: fitness.population_fitness(STRUCTURE, genomes, wts, cfg, W, H, CHANNELS, c_dim=C_DIM, gradient=1, max_batch=mb1)
+            run1()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            fit1 = run1()
+            torch.cuda.synchronize()
+            dt1 = time.perf_counter() - t1
+            multi["n1_same_box_evals_s"] = global_pop / dt1
+            multi["n1_same_box_ms_per_step"] = 1e3 * dt1
+            multi["n1_same_box_fitness_equal"] = bool(np.array_equal(np.asarray(fit1), np.asarray(fit)))
+            eng = fitness.get_engine(wts, W, H, CHANNELS, max_batch=mb1)
+            max_batch = mb1
     stage = eng.timings()
 
     out = {
@@ -561,7 +592,7 @@ def main():
             elif pm.get("pop") != nb:
                 traffic_note = "PMC summary is for a device batch of %s genomes, this run uses %d: not reported" % (pm.get("pop"), nb)
             else:
-                tags = (WINO16_KERNEL_TAG, WINO_KERNEL_TAG) if any(r.get("wino") for r in lstm) else (LSTM_KERNEL_TAG,)
+                tags = (WINO4_KERNEL_TAG, WINO16_KERNEL_TAG, WINO_KERNEL_TAG) if any(r.get("wino") for r in lstm) else (LSTM_KERNEL_TAG,)
                 for tag in tags:   # (the first tag the summary holds: the kernel that ran the ConvLSTMs of that build)
                     hit = [kv for kname, kv in pm["kernels"].items() if tag in kname]
                     if hit:
@@ -581,8 +612,12 @@ def main():
         alg_bytes = {l_: convlstm_algorithmic_bytes(CHANNELS, W, H, l_) * nb for l_ in s8d_layer}
         launches_l = {l_: sum(r["launches"] for r in lstm if r["layer"] == l_) for l_ in s8d_layer}
         alg_bytes_avg = sum(alg_bytes[l_] * launches_l[l_] for l_ in alg_bytes) / max(n_l, 1)
-        out["roofline"] = {"bound": "mfma", "kernel": ("wino16_kernel<4,EPI_LSTM> (EIGEN_WINO16=0: wino_kernel<4,EPI_LSTM,8>) (ConvLSTM, E / unpooled R / h chains as Winograd F(2x2,3x3): 16 of 36 multiply-adds, fused gates, v_mfma_f32_16x16x4_f32)"
+        wmask = int(os.environ.get("EIGEN_WINOGRAD") or "0x0FFFFFFE", 0)
+        out["roofline"] = {"bound": "mfma", "kernel": (("wino4_kernel<4,EPI_LSTM> (ConvLSTM, E / unpooled R / h chains as Winograd F(4x4,3x3): 36 multiply-adds per channel and 4x4 outputs where the direct form needs 144, fused gates, v_mfma_f32_16x16x4_f32)"
+                                                        if (wmask >> 25) & 1 else
+                                                        "wino16_kernel<4,EPI_LSTM> (ConvLSTM, E / unpooled R / h chains as Winograd F(2x2,3x3): 16 of 36 multiply-adds, fused gates, v_mfma_f32_16x16x4_f32)")
                                                        if wino_rows else "conv3x3_mfma<4,16,EPI_LSTM> (fused ConvLSTM gates, v_mfma_f32_16x16x4_f32)"),
+                           "winograd_mask": "0x%08X" % wmask,
                            "winograd_layers": sorted({r["layer"] for r in wino_rows}),
                            # `achieved` / `frac`: the multiply-adds the kernel EXECUTES (= SQ_INSTS_MFMA x 2048 FLOP, checkable below) over its HIP-event time
                            "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
@@ -675,9 +710,11 @@ def main():
         torch.cuda.empty_cache()
         for name, pop_s, steps_s, key in (("ref160", 50, 10, "ref160 (the reference's own default shape, pop 50)"), ("c1", 10, 20, "configs[0] (on the GPU path)"), ("c2", 50, 20, "configs[1]"),
                                           ("ref640", 16, 4, "ref640 (the reference's `--size big`, 640x480 colour, pop 16)"),
-                                          ("c4", 512, 2, "configs[3] (single-GPU: two device batches of 256)"), ("c5", 64, 2, "configs[4] (single-GPU sample: one device batch of 64)")):
+                                          ("c4", 512, 2, "configs[3] (single-GPU: two device batches of 256)"), ("c5", 64, 2, "configs[4] (single-GPU sample: one device batch of 64)"),
+                                          # configs[4] at ITS population once -- 1024 genomes at 512x512 = four device batches of 256, one generation
+                                          ("c5_full", 1024, 1, "configs[4] at its stated population (single GPU: four device batches of 256, ONE generation, warm-up = one more)")):
             try:
-                r = supplementary_shape(name, pop_s, steps_s)
+                r = supplementary_shape("c5" if name == "c5_full" else name, pop_s, steps_s, report_memory=(name == "c5_full"))
                 r["config"] = key
                 sup[name] = r
             except Exception as e:  # noqa: BLE001  (a supplementary failure must not cost the headline line)

@@ -34,7 +34,7 @@
 //     gate math (12 / 8 LSTM cells per lane; on eight waves it was 10 us of a block), 16-byte accesses per tensor, all four gates in-lane; ConvA: wave xi < 4 finishes the row PAIR xi >> 1 for the N-tiles of parity
 //     xi & 1, so that the 2x2 pooling windows of the 4x4 tile stay in one lane.
 #pragma once
-#include "conv_winoh.h"
+#include "conv_wino16.h"
 
 namespace eig {
 

@@ -17,7 +17,6 @@
 #include "conv_mfma.h"
 #include "conv_wino.h"
 #include "conv_wino16.h"
-#include "conv_winoh.h"
 #include "conv_wino4.h"
 #ifndef EIGEN_WINO16_DEFAULT
 #define EIGEN_WINO16_DEFAULT 7
@@ -134,12 +133,6 @@ struct eigen_engine {
     // timing
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pev0 = nullptr, pev1 = nullptr;
-    // Side stream of the roll-out: ConvP_l (l > 0) only feeds ConvA_l of the NEXT step, so it leaves the critical chain
-    // ConvA_1..L -> ConvLSTM_L..0 -> ConvP_0 and runs beside the ConvLSTMs of the layers below it (fork / join with events;
-    // same kernels, same arguments: results are untouched).  Worth most where a launch does not fill the chip.
-    hipStream_t aux = nullptr;
-    hipEvent_t ev_h[EIGEN_MAX_LAYERS] = {nullptr}, ev_p[EIGEN_MAX_LAYERS] = {nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_mid = nullptr;  // two half-populations on two streams (eigen_prednet_rollout)
     int n_cu = 256;  // compute units of the device (launch-shape heuristics)
     bool profile_convs = false;
     double ms[6] = {0, 0, 0, 0, 0, 0};
@@ -387,12 +380,6 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
 #ifndef EIGEN_WINO_DEFAULT
 #define EIGEN_WINO_DEFAULT 0x0FFFFFFE   // every eligible operator in Winograd form, the unpooled source inside the ConvLSTM chains (bit 24), F(4x4, 3x3) tiles (bits 25-27)
 #endif
-#ifndef EIGEN_WINOH_DEFAULT
-#define EIGEN_WINOH_DEFAULT 0   // (conv_winoh.h, half tiles; bit mask 1 ConvLSTM, 2 ConvA, 4 ConvP)
-#endif
-#ifndef EIGEN_WINOF_DEFAULT
-#define EIGEN_WINOF_DEFAULT 0   // (conv_winoh.h, full tiles; bit mask 1 ConvLSTM, 2 ConvA, 4 ConvP)
-#endif
 static bool wino_op(int mask, int kind, int l, int Cin, int Cout, int H, int W, bool top)
 {
     if (!((mask >> (8 * kind + l)) & 1) || l < 1) return false;
@@ -579,51 +566,13 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     op.last_grid = grid; op.last_waves = (w8 == 1) ? 8 : 4;
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
-    if (op.wino) {  // Winograd form (conv_wino.h): 16 x 16-pixel blocks of one image, eight waves, one block per CU
-        static const int mode = getenv("EIGEN_WINO_MODE") ? atoi(getenv("EIGEN_WINO_MODE")) : 8;  // conv_wino.h: MODE (A/B; 0, 4, 8: same results; 5-7: measurement only)
-        a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
-        const int nt = batch * a.tilesX * a.tilesY;
-        const int g = op.n_nblk * ((nt + 7) / 8) * 8;
-        op.last_grid = g; op.last_waves = 8;
-        auto go = [&](auto kern, int ni, bool raw = false) {
-            const int lds = wino_lds_bytes(ni, raw);
-            static std::unordered_set<const void*> attr_done;   // (the handle is not thread-safe anyway: one rank, one host thread)
-            if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            hipLaunchKernelGGL(kern, dim3(g), dim3(WINO_THREADS), lds, st, a);
-        };
-        const bool m4 = mode != 0;
-        // EIGEN_WINO16: bit mask of the operators on sixteen waves per block (conv_wino16.h; same results): 1 ConvLSTM, 2 ConvA, 4 ConvP
-        static const int wino16 = getenv("EIGEN_WINO16") ? atoi(getenv("EIGEN_WINO16")) : EIGEN_WINO16_DEFAULT;
-        auto go16 = [&](auto kern, int ni) {
-            const int lds = wino16_lds_bytes(ni);
-            static std::unordered_set<const void*> attr_done;
-            if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            op.last_waves = 16;
-            hipLaunchKernelGGL(kern, dim3(g), dim3(WINO16_THREADS), lds, st, a);
-        };
-        // conv_winoh.h (A operands built in-wave, no transformed-input buffer; same results).  EIGEN_WINOH: bit mask of the operators on HALF tiles, two co-resident
-        // eight-wave blocks per CU; EIGEN_WINOF: ... on full 16 x 16 tiles, sixteen waves, K-blocks of eight channels -- 1 ConvLSTM, 2 ConvA, 4 ConvP each
-        static const int winoh = getenv("EIGEN_WINOH") ? atoi(getenv("EIGEN_WINOH")) : EIGEN_WINOH_DEFAULT;
-        static const int winof = getenv("EIGEN_WINOF") ? atoi(getenv("EIGEN_WINOF")) : EIGEN_WINOF_DEFAULT;
-        auto goh = [&](auto kern, auto rg_tag, auto ks_tag) {
-            constexpr int RG = decltype(rg_tag)::value, KS = decltype(ks_tag)::value;
-            a.tilesY = (op.H + 4 * RG - 1) / (4 * RG);
-            const int gh = op.n_nblk * ((batch * a.tilesX * a.tilesY + 7) / 8) * 8;
-            constexpr int ldsb = winoh_lds_bytes<RG, KS>(), nthr = 256 * RG;
-            static std::unordered_set<const void*> attr_done;
-            if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
-            op.last_grid = gh; op.last_waves = 4 * RG;
-            hipLaunchKernelGGL(kern, dim3(gh), dim3(nthr), ldsb, st, a);
-        };
-        const int cls = op.epi == EPI_LSTM ? 1 : (op.epi == EPI_CONVA ? 2 : 4);
-        const bool lstm_ok = op.epi != EPI_LSTM || a.acc_init == nullptr;
-        const std::integral_constant<int, 1> k1{}; const std::integral_constant<int, 2> k2{}; const std::integral_constant<int, 4> k4{};
-        if (op.wino_tile == 4) {   // F(4x4, 3x3): conv_wino4.h, 16 x 32-pixel blocks, twelve waves
-            if (!lstm_ok) return hipErrorInvalidConfiguration;
+    if (op.wino) {  // Winograd form: F(4x4, 3x3) conv_wino4.h; F(2x2, 3x3) conv_wino16.h (sixteen waves), or conv_wino.h (eight waves) for a ConvLSTM whose unpooled source is a chain of its own
+        if (op.wino_tile == 4) {   // 16 x 32-pixel blocks, twelve waves
+            if (op.epi == EPI_LSTM && a.acc_init != nullptr) return hipErrorInvalidConfiguration;   // (set_weights never pairs F(4x4) with a separate unpooled chain)
             auto go4 = [&](auto kern) {
                 a.tilesX = (op.W + 31) / 32; a.tilesY = (op.H + 15) / 16;
                 const int g4 = op.n_nblk * ((batch * a.tilesX * a.tilesY + 7) / 8) * 8;
-                static std::unordered_set<const void*> attr_done;
+                static std::unordered_set<const void*> attr_done;   // (the handle is not thread-safe anyway: one rank, one host thread)
                 if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, wino4_lds_bytes());
                 op.last_grid = g4; op.last_waves = W4_WAVES;
                 hipLaunchKernelGGL(kern, dim3(g4), dim3(W4_THREADS), wino4_lds_bytes(), st, a);
@@ -631,35 +580,35 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             if (op.epi == EPI_LSTM) go4(wino4_kernel<4, EPI_LSTM>);
             else if (op.epi == EPI_CONVA) { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVA>); else go4(wino4_kernel<3, EPI_CONVA>); }
             else { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVP>); else go4(wino4_kernel<3, EPI_CONVP>); }
+        } else {
+            a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
+            const int nt = batch * a.tilesX * a.tilesY;
+            const int g = op.n_nblk * ((nt + 7) / 8) * 8;
+            op.last_grid = g; op.last_waves = 8;
+            auto go = [&](auto kern, int ni) {
+                const int lds = wino_lds_bytes(ni, true);
+                static std::unordered_set<const void*> attr_done;
+                if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                hipLaunchKernelGGL(kern, dim3(g), dim3(WINO_THREADS), lds, st, a);
+            };
+            // EIGEN_WINO16: bit mask of the F(2x2) operators on sixteen waves per block (conv_wino16.h; same results): 1 ConvLSTM, 2 ConvA, 4 ConvP
+            static const int wino16 = getenv("EIGEN_WINO16") ? atoi(getenv("EIGEN_WINO16")) : EIGEN_WINO16_DEFAULT;
+            auto go16 = [&](auto kern, int ni) {
+                const int lds = wino16_lds_bytes(ni);
+                static std::unordered_set<const void*> attr_done;
+                if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+                op.last_waves = 16;
+                hipLaunchKernelGGL(kern, dim3(g), dim3(WINO16_THREADS), lds, st, a);
+            };
+            if ((wino16 & 1) && op.epi == EPI_LSTM && a.acc_init == nullptr) go16(wino16_kernel<4, EPI_LSTM>, 4);
+            else if ((wino16 & 2) && op.epi == EPI_CONVA) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVA>, 4); else go16(wino16_kernel<3, EPI_CONVA>, 3); }
+            else if ((wino16 & 4) && op.epi == EPI_CONVP) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVP>, 4); else go16(wino16_kernel<3, EPI_CONVP>, 3); }
+            else if (op.epi == EPI_LSTM) go(wino_kernel<4, EPI_LSTM, 8>, 4);
+            else if (op.epi == EPI_CONVA && op.NI == 4) go(wino_kernel<4, EPI_CONVA, 8>, 4);
+            else if (op.epi == EPI_CONVA) go(wino_kernel<3, EPI_CONVA, 8>, 3);
+            else if (op.NI == 4) go(wino_kernel<4, EPI_CONVP, 8>, 4);
+            else go(wino_kernel<3, EPI_CONVP, 8>, 3);
         }
-        else if (mode == 8 && (winoh & cls) && lstm_ok) {
-            if (op.epi == EPI_LSTM) goh(winoh_kernel<4, EPI_LSTM, 2, 1>, k2, k1);
-            else if (op.epi == EPI_CONVA) { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVA, 2, 1>, k2, k1); else goh(winoh_kernel<3, EPI_CONVA, 2, 1>, k2, k1); }
-            else { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVP, 2, 1>, k2, k1); else goh(winoh_kernel<3, EPI_CONVP, 2, 1>, k2, k1); }
-        }
-        else if (mode == 8 && (winof & cls) && lstm_ok) {
-            if (op.epi == EPI_LSTM) goh(winoh_kernel<4, EPI_LSTM, 4, 2>, k4, k2);
-            else if (op.epi == EPI_CONVA) { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVA, 4, 2>, k4, k2); else goh(winoh_kernel<3, EPI_CONVA, 4, 2>, k4, k2); }
-            else { if (op.NI == 4) goh(winoh_kernel<4, EPI_CONVP, 4, 2>, k4, k2); else goh(winoh_kernel<3, EPI_CONVP, 4, 2>, k4, k2); }
-        }
-        else if (mode == 8 && (wino16 & 1) && op.epi == EPI_LSTM && a.acc_init == nullptr) go16(wino16_kernel<4, EPI_LSTM>, 4);
-        else if (mode == 8 && (wino16 & 2) && op.epi == EPI_CONVA) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVA>, 4); else go16(wino16_kernel<3, EPI_CONVA>, 3); }
-        else if (mode == 8 && (wino16 & 4) && op.epi == EPI_CONVP) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVP>, 4); else go16(wino16_kernel<3, EPI_CONVP>, 3); }
-        else if (mode == 8) {
-            if (op.epi == EPI_LSTM) go(wino_kernel<4, EPI_LSTM, 8>, 4, true);
-            else if (op.epi == EPI_CONVA && op.NI == 4) go(wino_kernel<4, EPI_CONVA, 8>, 4, true);
-            else if (op.epi == EPI_CONVA) go(wino_kernel<3, EPI_CONVA, 8>, 3, true);
-            else if (op.NI == 4) go(wino_kernel<4, EPI_CONVP, 8>, 4, true);
-            else go(wino_kernel<3, EPI_CONVP, 8>, 3, true);
-        }
-        else if (op.epi == EPI_LSTM && mode == 5) go(wino_kernel<4, EPI_LSTM, 5>, 4);        // (measurement builds of the ConvLSTM kernel: wrong results)
-        else if (op.epi == EPI_LSTM && mode == 6) go(wino_kernel<4, EPI_LSTM, 6>, 4);
-        else if (op.epi == EPI_LSTM && mode == 7) go(wino_kernel<4, EPI_LSTM, 7>, 4);
-        else if (op.epi == EPI_LSTM) { if (m4) go(wino_kernel<4, EPI_LSTM, 4>, 4); else go(wino_kernel<4, EPI_LSTM, 0>, 4); }
-        else if (op.epi == EPI_CONVA && op.NI == 4) { if (m4) go(wino_kernel<4, EPI_CONVA, 4>, 4); else go(wino_kernel<4, EPI_CONVA, 0>, 4); }
-        else if (op.epi == EPI_CONVA) { if (m4) go(wino_kernel<3, EPI_CONVA, 4>, 3); else go(wino_kernel<3, EPI_CONVA, 0>, 3); }
-        else if (op.NI == 4) { if (m4) go(wino_kernel<4, EPI_CONVP, 4>, 4); else go(wino_kernel<4, EPI_CONVP, 0>, 4); }
-        else { if (m4) go(wino_kernel<3, EPI_CONVP, 4>, 3); else go(wino_kernel<3, EPI_CONVP, 0>, 3); }
         r = hipGetLastError();
     } else {
     static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
@@ -725,13 +674,6 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     return r;
 }
 
-// Two half-populations on two streams: worth it where the top of the network cannot fill the chip by itself.  (Filled in from
-// same-box A/Bs: profiles/r04_*.)
-static bool pipe2_pays(const eigen_engine* e, int batch)
-{
-    (void)e; (void)batch;
-    return false;
-}
 
 // ------------------------------------------------------------------------------------------------ ABI
 extern "C" {
@@ -771,10 +713,6 @@ int eigen_destroy(eigen_engine* e)
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->pev0) (void)hipEventDestroy(e->pev0);
     if (e->pev1) (void)hipEventDestroy(e->pev1);
-    for (auto& ev : e->ev_h) if (ev) (void)hipEventDestroy(ev);
-    for (auto& ev : e->ev_p) if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {e->ev_fork, e->ev_join, e->ev_mid}) if (ev) (void)hipEventDestroy(ev);
-    if (e->aux) (void)hipStreamDestroy(e->aux);
     delete e;
     return EIGEN_OK;
 }
@@ -857,12 +795,6 @@ int eigen_create(const eigen_config* cfg, eigen_engine** out)
     for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
     HIPCHK(hipEventCreate(&e->pev0));
     HIPCHK(hipEventCreate(&e->pev1));
-    HIPCHK(hipStreamCreateWithFlags(&e->aux, hipStreamNonBlocking));  // no implicit ordering against the caller's (possibly NULL) stream: events only
-    for (hipEvent_t* ev : {&e->ev_fork, &e->ev_join, &e->ev_mid}) HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
-    for (int l = 0; l < L; ++l) {
-        HIPCHK(hipEventCreateWithFlags(&e->ev_h[l], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&e->ev_p[l], hipEventDisableTiming));
-    }
     *out = e;
     return EIGEN_OK;
 }
@@ -979,8 +911,10 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             // the pass's prologue / epilogue and its round trip save); where the pass is a SHORT kernel its fixed costs dominate and
             // the in-kernel form wins: 160x120 colour pop 50 +2.3 %, 160x120 gray +5 %.  Hence: in-kernel iff the pass would
             // execute < 2.5e10 multiply-adds per launch at this engine's device batch (~0.35 ms); EIGEN_FUSEUP=0 / 1 force it.
-            // EIGEN_WINOGRAD = bit mask of layers whose chain over E_l / h_l runs in its Winograd F(2x2, 3x3) form (conv_wino.h): 2.25x fewer
-            // multiply-adds, ANOTHER canonical summation order (oracle: wino_mask) -- opt-in.  Such a layer keeps the separate 2x2 pass.
+            // EIGEN_WINOGRAD = bit mask of the operators that run in Winograd form (bit l ConvLSTM_l, 8 + l ConvA_l, 16 + l ConvP_l; bit 24: the unpooled source inside the
+            // ConvLSTM's chains; bits 25-27: F(4x4, 3x3) tiles) -- ANOTHER canonical summation order per setting, which the oracle follows through the same variable.
+            // DEFAULT ON for every eligible operator (EIGEN_WINO_DEFAULT); EIGEN_WINOGRAD=0 restores the direct chains of rounds 1-3.  Every rank of a multi-GPU
+            // run must use the same value (bench.py gathers it beside ranks_seen).
             const bool wino = op.epi == EPI_LSTM && wino_op(wino_env, 0, l, 3 * C, C, y.H, y.W, l == L - 1);
             bool wino_fuse = false;
             if (wino) {
@@ -988,9 +922,6 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
                 // bit 24 of the switch (EIGEN_WINO_FUSEUP=0 clears it), 16-byte rows at the source resolution, 8-channel K-blocks
                 static const bool fuse_bit = ((wino_env >> 24) & 1) && !(getenv("EIGEN_WINO_FUSEUP") && !atoi(getenv("EIGEN_WINO_FUSEUP")));
                 wino_fuse = fuse_bit && l < L - 1 && (y.W % 8) == 0 && (e->layer[l + 1].C % 8) == 0;
-                static const int wmode = getenv("EIGEN_WINO_MODE") ? atoi(getenv("EIGEN_WINO_MODE")) : 8;
-                if (wino_fuse && wmode != 8)
-                    return fail(EIGEN_ERR_INVALID, "EIGEN_WINO_MODE=%d has no fused unpooled source: set EIGEN_WINO_FUSEUP=0 with it (the oracle reads the same variable)", wmode);
                 const int Cu = wino_fuse ? e->layer[l + 1].C : 0;
                 const float* w3[3][4];
                 for (int g = 0; g < 4; ++g) { w3[0][g] = wx0[g]; w3[1][g] = wino_fuse ? wx1[g] : wh[g]; w3[2][g] = wino_fuse ? wh[g] : nullptr; }
@@ -1204,27 +1135,13 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
         HIPCHK(hipMemsetAsync(y.P, 0, n, st));
     }
     int cur = 0;  // h[cur] holds the state of the previous step
-    // EIGEN_SIDE_STREAM=1 forks ConvP_l (l > 0) onto the side stream.  OFF by default: measured on one box (profiles/r03_b_ab_w8.txt,
-    // run 2) it changes nothing at 256^2 / 256 genomes (177.6 vs 177.8 evals/s) and nothing where launches under-fill the chip
-    // (160x120 colour 430.6 vs 435.2, gray 2452 vs 2472): a launch's blocks occupy the CUs in dispatch order, and the time of an
-    // under-filled launch is the CU that holds two of its blocks -- a second queue adds blocks to CUs, it does not balance them.
-    static const bool side_env = getenv("EIGEN_SIDE_STREAM") && atoi(getenv("EIGEN_SIDE_STREAM"));
-    // Two half-populations on two streams (round 4): genomes [0, nA) run on the caller's stream, [nA, batch) on
-    // the side stream, the second half started half a step late (it waits for the first half's top-layer ConvLSTM of step 0), so
-    // that the under-filled top-layer launches of one half co-run with the chip-filling layer-0/1 launches of the other.  Same
-    // kernels on disjoint genomes: every frame is the byte it was.  EIGEN_PIPE2 = 1 / 0 forces it on / off; default: pipe2_pays().
-    static const int pipe_env = getenv("EIGEN_PIPE2") ? atoi(getenv("EIGEN_PIPE2")) : -1;
-    static const bool pipe_sync = getenv("EIGEN_PIPE2_SYNC") && atoi(getenv("EIGEN_PIPE2_SYNC"));  // A/B: re-impose the half-step offset at every step
-    const bool pipe = !e->profile_convs && batch >= 2 && L > 1 && (pipe_env >= 0 ? pipe_env != 0 : pipe2_pays(e, batch));
-    const bool side = side_env && !e->profile_convs && L > 1 && !pipe;
-    bool p_pending[EIGEN_MAX_LAYERS] = {false};  // ConvP_l of the previous step is in flight on the side stream
+    // (One stream: the device is busy 99.9 % of a generation and the step's dependency chain is serial.  Round 3 / 4 measured a side stream for the off-chain
+    // ConvP_l and two half-populations on two streams -- byte-identical, slower or equal at every shape: profiles/r03_b_ab_w8.txt, r04_b_ab_pipe2.txt; removed in round 5.)
     static const bool skip_zero_sources = !(getenv("EIGEN_NO_T0") && atoi(getenv("EIGEN_NO_T0")));  // A/B measurements only
     hipLaunchKernelGGL(e0_init_kernel, dim3(1024), dim3(256), 0, st, d_images, e->layer[0].E, e->C0, (int)HW, batch);
     HIPCHK(hipGetLastError());
-    // One PredNet step of genomes [b0, b0 + nb) on stream s; raw4: that range's partial-chain scratch.  mid: recorded on s after the
-    // top-layer ConvLSTM launch (the other half's phase reference); wait: waited for before the first launch.
-    auto run_step = [&](int t, int b0, int nb, hipStream_t s, float* raw4, hipEvent_t mid, hipEvent_t wait) -> int {
-        if (wait) HIPCHK(hipStreamWaitEvent(s, wait, 0));
+    // One PredNet step of genomes [b0, b0 + nb) on stream s; raw4: that range's partial-chain scratch.
+    auto run_step = [&](int t, int b0, int nb, hipStream_t s, float* raw4) -> int {
         auto off = [&](float* p, const Layer& y, int mult = 1) { return p + (size_t)b0 * mult * y.C * y.H * y.W; };
         // bottom-up: E_l from E_{l-1} and the previous prediction P_l
         for (int l = 1; l < L; ++l) {
@@ -1233,7 +1150,6 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
             memset(&a, 0, sizeof(a));
             a.src[0].ptr = off(e->layer[l - 1].E, e->layer[l - 1], 2);
             a.bias = y.biasA; a.P = off(y.P, y); a.E = off(y.E, y, 2);
-            if (p_pending[l]) { HIPCHK(hipStreamWaitEvent(s, e->ev_p[l], 0)); p_pending[l] = false; }  // join: P_l of the previous step
             HIPCHK(launch_conv(e, (t == 0 && skip_zero_sources) ? y.convA_t0 : y.convA, a, nb, s));
         }
         // top-down: R_l, then P_l
@@ -1259,7 +1175,6 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
                 if (!t0) a.src[k++].ptr = off(y.h[cur], y);
                 a.bias = y.bias_lstm; a.c_state = off(y.c, y); a.h_out = off(y.h[cur ^ 1], y); a.peep = y.peep;
                 HIPCHK(launch_conv(e, t0 ? y.lstm_t0 : y.lstm, a, nb, s));
-                if (l == L - 1 && mid) HIPCHK(hipEventRecord(mid, s));
             }
             // P_l (l > 0) is only read by ConvA_l of the NEXT step: nothing reads it after the last one
             if (l == 0 || t + 1 < n_steps) {
@@ -1267,14 +1182,6 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
                 memset(&a, 0, sizeof(a));
                 a.src[0].ptr = off(y.h[cur ^ 1], y);
                 a.bias = y.biasP; a.Pout = off(y.P, y); a.clip = (l == 0) ? 1 : 0;
-                if (side && l > 0) {  // fork: ConvP_l beside the ConvLSTMs below it
-                    HIPCHK(hipEventRecord(e->ev_h[l], s));
-                    HIPCHK(hipStreamWaitEvent(e->aux, e->ev_h[l], 0));
-                    HIPCHK(launch_conv(e, y.convP, a, nb, e->aux));
-                    HIPCHK(hipEventRecord(e->ev_p[l], e->aux));
-                    p_pending[l] = true;
-                    continue;
-                }
                 if (l == 0) {
                     if (t + 1 < n_steps) {  // error units of the next step
                         a.E0 = off(y.E, y, 2);
@@ -1291,29 +1198,11 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
         }
         return EIGEN_OK;
     };
-    if (!pipe) {
-        for (int t = 0; t < n_steps; ++t) {
-            const int rc = run_step(t, 0, batch, st, e->d_raw4, nullptr, nullptr);
-            if (rc) return rc;
-            cur ^= 1;
-        }
-    } else {
-        const int nA = (batch + 1) / 2, nB = batch - nA;
-        float* raw4B = e->d_raw4 ? e->d_raw4 + (size_t)nA * (e->raw4_floats / (size_t)e->B) : nullptr;  // (per-image stride of the widest layer)
-        HIPCHK(hipEventRecord(e->ev_fork, st));           // reset_state() and E_0 of step 0 are on the caller's stream
-        HIPCHK(hipStreamWaitEvent(e->aux, e->ev_fork, 0));
-        for (int t = 0; t < n_steps; ++t) {
-            int rc = run_step(t, 0, nA, st, e->d_raw4, (t == 0 || pipe_sync) ? e->ev_mid : nullptr, nullptr);
-            if (rc) return rc;
-            rc = run_step(t, nA, nB, e->aux, raw4B, nullptr, (t == 0 || pipe_sync) ? e->ev_mid : nullptr);
-            if (rc) return rc;
-            cur ^= 1;
-        }
-        HIPCHK(hipEventRecord(e->ev_join, e->aux));
-        HIPCHK(hipStreamWaitEvent(st, e->ev_join, 0));
+    for (int t = 0; t < n_steps; ++t) {
+        const int rc = run_step(t, 0, batch, st, e->d_raw4);
+        if (rc) return rc;
+        cur ^= 1;
     }
-    for (int l = 1; l < L; ++l)  // (nothing is pending after the last step -- its ConvP_l are not launched -- but keep the join explicit)
-        if (p_pending[l]) HIPCHK(hipStreamWaitEvent(st, e->ev_p[l], 0));
     e->hflip = cur;
     return EIGEN_OK;
 }

@@ -23,6 +23,8 @@ import os
 
 import numpy as np
 
+import time
+
 from . import grids
 from .engine import PAIR_POPULATION, PAIR_SINGLE, Engine, EngineError
 from .genome import GenomeBatch
@@ -34,6 +36,28 @@ DEFAULT_MAX_BATCH = 256
 
 _engines = {}
 _dict_digests = {}
+FULL_CHECK_INTERVAL_S = 2.0   # a weight dict's full content hash is re-checked when its last full check is older than this (see _weights_key)
+
+
+def _content_digest(d):
+    """Hash of every array of a weight dict (names, shapes, bytes): xxh3 where the module is installed, sha1 otherwise."""
+    try:
+        import xxhash
+        hsh = xxhash.xxh3_128()
+    except ImportError:
+        import hashlib
+        hsh = hashlib.sha1()
+    for k in sorted(d):
+        a = np.ascontiguousarray(d[k])
+        hsh.update(k.encode()); hsh.update(str(a.shape).encode()); hsh.update(memoryview(a).cast("B"))
+    return hsh.hexdigest()
+
+
+def invalidate_weights(model_dict):
+    """Forget the cached digest of a weight dict that was edited in place: the next lookup hashes it again (and builds a new engine if the
+    content changed).  Needed only for edits that must take effect within FULL_CHECK_INTERVAL_S."""
+    _dict_digests.pop(id(model_dict), None)
+
 
 
 def _weights_key(model_name):
@@ -41,23 +65,22 @@ def _weights_key(model_name):
     generation, and a 33 MB npz (0.2 s) or a synthetic set (0.6 s) must only be materialised on a cache miss."""
     if isinstance(model_name, dict):
         # content digest, computed once per dict OBJECT (the table keeps the dict alive, so its id cannot be reused): two equal
-        # weight dicts resolve to ONE engine instead of two 9.5 GB ones
-        # A dict that was MUTATED after its first use must not keep resolving to the engine holding the old weights (ADVICE r3): a
-        # cheap fingerprint -- per array: buffer address, shape and a strided sample of 64 elements -- is checked on every lookup
-        # and the full digest recomputed when it moved.  (Weight dicts are best treated as immutable; INTEGRATION.md section 1.)
+        # weight dicts resolve to ONE engine instead of two 9.5 GB ones.
+        # A dict that was MUTATED after its first use must not keep resolving to the engine holding the old weights (ADVICE r3 / r4).  Two checks:
+        # a cheap fingerprint on EVERY lookup -- per array: buffer address, shape and a strided sample of 64 elements -- and a FULL content hash
+        # (xxh3 over every buffer: 5 ms for the 46 MB of the headline network) whenever the last full check of this dict is older than
+        # FULL_CHECK_INTERVAL_S.  A single-element in-place edit is therefore picked up at the latest that many seconds later, or at once
+        # after invalidate_weights(d).  (Weight dicts are best treated as immutable; INTEGRATION.md section 1.)
         def probe(a):
             a = np.asarray(a)
             flat = a.reshape(-1)
             return (a.__array_interface__["data"][0], a.shape, flat[::max(1, flat.size // 64)][:64].tobytes())
         fp = tuple((k, probe(model_name[k])) for k in sorted(model_name))
         ent = _dict_digests.get(id(model_name))
-        if ent is None or ent[0] is not model_name or ent[2] != fp:
-            import hashlib
-            hsh = hashlib.sha1()
-            for k in sorted(model_name):
-                a = np.ascontiguousarray(model_name[k])
-                hsh.update(k.encode()); hsh.update(str(a.shape).encode()); hsh.update(a.tobytes())
-            ent = _dict_digests[id(model_name)] = (model_name, hsh.hexdigest(), fp)
+        now = time.monotonic()
+        stale = ent is None or ent[0] is not model_name or ent[2] != fp
+        if stale or now - ent[3] > FULL_CHECK_INTERVAL_S:
+            ent = _dict_digests[id(model_name)] = (model_name, _content_digest(model_name), fp, now)
         return ("dict", ent[1])
     name = str(model_name)
     if name.startswith("synthetic"):

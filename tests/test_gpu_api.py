@@ -240,15 +240,10 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
     for switch in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA", "EIGEN_FUSEUP"):
         assert run({switch: "1"}) == base, switch
     # round 3: the eight-wave instantiations (chosen by launch size: these small roll-outs take them by default) forced off / on
-    # for every operator class, with and without the separate 2x2 pass; ConvP_l forked onto the side stream
-    for env in ({"EIGEN_W8": "0"}, {"EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_SIDE_STREAM": "1"},
+    # for every operator class, with and without the separate 2x2 pass
+    # (round 5: the side stream, the two-streams-per-population pipeline and the schedule variants of the eight-wave Winograd kernel lost their A/Bs and are gone)
+    for env in ({"EIGEN_W8": "0"}, {"EIGEN_W8": "31", "EIGEN_FUSEUP": "0"},
                 {"EIGEN_H4": "1", "EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_H4": "0", "EIGEN_W8": "31"},  # half blocks forced on / off
-                {"EIGEN_NO_TW4": "1"},                                                                          # 4-column strips off: 8 x 8 tiles on the 20 x 16 maps
-                # round 4: the population as two halves on two streams (B = 3: halves of 2 and 1 genomes), forced on / off, with the
-                # half-step offset re-imposed at every step, and with the separate 2x2 pass (the halves' partial-chain scratch is disjoint)
-                {"EIGEN_PIPE2": "1"}, {"EIGEN_PIPE2": "0"}, {"EIGEN_PIPE2": "1", "EIGEN_PIPE2_SYNC": "1"}, {"EIGEN_PIPE2": "1", "EIGEN_FUSEUP": "0", "EIGEN_W8": "0"},
-                # the schedules of the Winograd ConvLSTM kernel (conv_wino.h: MODE; the 48- and 16-channel top layers of the first two
-                # roll-outs take it): which wave issues what when -- never which operations
-                {"EIGEN_WINO_MODE": "0"}, {"EIGEN_WINO_MODE": "4"}, {"EIGEN_WINO_MODE": "8"}):
+                {"EIGEN_NO_TW4": "1"}):                                                                         # 4-column strips off: 8 x 8 tiles on the 20 x 16 maps
         assert run(env) == base, env
     assert run({"EIGEN_FUSEUP": "0"}) == base  # these small roll-outs take the in-kernel chain by default: the separate pass

@@ -454,7 +454,7 @@ print("WINO_OK" if ok else "WINO_FAIL")
 """
 
 
-@pytest.mark.parametrize("switch", ["14", None, "0x0E0E00", "0x0100000E", "0x01FFFFFE", "wino16=0", "winoh=0", "winoh=7", "winof=7", "0x03FFFFFE", "0x0DFEFEFE"])
+@pytest.mark.parametrize("switch", ["14", None, "0x0E0E00", "0x0100000E", "0x01FFFFFE", "wino16=0", "0x03FFFFFE", "0x0DFEFEFE"])
 def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     """The Winograd F(2x2, 3x3) form of the 3x3 convolutions (csrc/conv_wino.h) against the oracle's statement of exactly that arithmetic
     (eig_oracle.c: wino_*; the oracle follows the same environment switch): all frames of four small roll-outs, bit for bit -- incl.
@@ -463,23 +463,13 @@ def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     ConvLSTM / ConvA / ConvP with the unpooled source inside the ConvLSTM's chains; 0x0E0E00: ConvA and ConvP only; 0x0100000E: the ConvLSTMs
     with their unpooled source fused, everything else direct.  The ConvLSTMs run on the sixteen-wave kernel (csrc/conv_wino16.h) wherever it
     applies; "wino16=0": the default operators with the eight-wave ConvLSTM kernel (EIGEN_WINO16=0) -- same arithmetic, same bits;
-    "winoh=0" / "winoh=7": the half-tile shape of csrc/conv_winoh.h (A operands built in-wave; two co-resident eight-wave blocks per CU) off / on for
-    every operator class, whatever the build's default; "winof=7": its full-tile shape (sixteen waves, K-blocks of eight channels) for every operator
-    class -- same arithmetic, same bits.  0x0FFFFFFE: every eligible operator as Winograd F(4x4, 3x3) (csrc/conv_wino4.h; bits 25 / 26 / 27 = ConvLSTM / ConvA /
+    unset (the default, 0x0FFFFFFE): every eligible operator as Winograd F(4x4, 3x3) (csrc/conv_wino4.h; bits 25 / 26 / 27 = ConvLSTM / ConvA /
     ConvP) -- ANOTHER canonical order, which the oracle states and follows through the same mask; 0x03FFFFFE: the ConvLSTMs only; 0x0DFEFEFE: ConvA and ConvP in
     F(4x4), the ConvLSTMs in F(2x2) without the fused unpooled source."""
     import subprocess
     env = dict(os.environ)
     env.pop("EIGEN_WINOGRAD", None)
     env.pop("EIGEN_WINO16", None)
-    env.pop("EIGEN_WINOH", None)
-    env.pop("EIGEN_WINOF", None)
-    if switch in ("winoh=0", "winoh=7"):
-        env["EIGEN_WINOH"], env["EIGEN_WINOF"] = switch[-1], "0"
-        switch = None
-    if switch == "winof=7":
-        env["EIGEN_WINOH"], env["EIGEN_WINOF"] = "0", "7"
-        switch = None
     if switch == "wino16=0":
         env["EIGEN_WINO16"] = "0"
         switch = None

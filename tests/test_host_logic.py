@@ -498,6 +498,22 @@ def test_equal_weight_dicts_share_one_engine_key():
     k1 = fitness._weights_key(a)
     a[name][...] = 0.25
     assert k0 != k1 != fitness._weights_key(a) and fitness._weights_key(b) == k0
+    # a SINGLE-element in-place edit that misses the cheap strided sample -- picked up by the full content hash, which runs when the dict's
+    # last full check is older than FULL_CHECK_INTERVAL_S, or at once after invalidate_weights()
+    big = {"w": np.zeros((300, 300), np.float32), "b": np.ones(5, np.float32)}
+    kb = fitness._weights_key(big)
+    big["w"][3, 5] = 1.0   # (300 * 300 // 64 = 1406: index 905 is not on the stride)
+    assert fitness._weights_key(big) == kb                      # inside the interval the cheap probe cannot see it ...
+    fitness.invalidate_weights(big)
+    kb2 = fitness._weights_key(big)
+    assert kb2 != kb                                            # ... invalidate_weights() makes it take effect now,
+    old = fitness.FULL_CHECK_INTERVAL_S
+    try:
+        fitness.FULL_CHECK_INTERVAL_S = 0.0
+        big["w"][7, 11] = 2.0
+        assert fitness._weights_key(big) != kb2                 # and an elapsed interval does too
+    finally:
+        fitness.FULL_CHECK_INTERVAL_S = old
     fitness._dict_digests.clear()
 
 

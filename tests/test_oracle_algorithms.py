@@ -289,6 +289,66 @@ def test_fitness_deviation_under_the_reference_element_order_is_explained_genome
     assert s["within_1e-4"] >= 0.9 * s["genomes"] and s["within_1e-4_of_nonzero_both"] >= 0.85 * s["nonzero_both"]  # (measured here: 23 of 24, 13 of 14)
 
 
+def test_attribution_accepts_a_constructed_single_byte_deviation_and_rejects_unrelated_ones(oracle_lib):
+    """the classifier's positive branch on a CONSTRUCTED case, independent of which bytes the host's BLAS happens to flip.  A genome's canonical frame
+    pair, and an "other implementation" that is the same pair with ONE byte changed where that moves the fitness: classify.attribute must find that byte's effect and
+    classify.explained must accept the deviation; a deviation in the OPPOSITE direction, one three times as large, and a claimed deviation whose only flipped byte
+    does not move the fitness must all be rejected."""
+    from evolutionary_illusion_generator_amd import synth, weights
+    from oracle import classify, scores
+    st, c_dim, w, h, ch = 1, 1, 160, 120, [1, 16, 32, 64]
+    cfg = synth.make_config(2, 1)
+    wts = weights.synthetic_prednet_weights(ch, w, h, seed=0)
+    genomes = [g for _, g in synth.make_population(8, cfg, seed=0)]
+    imgs, frames, vecs, fits = _canonical_population(oracle_lib, st, c_dim, w, h, ch, genomes, cfg, wts)
+    k = int(np.argmax(fits != 0))
+    assert fits[k] != 0
+    ours = frames[k]
+    fit_of = lambda fr: (lambda v: (v, scores.fitness_from_vectors(st, v.astype(np.float64), w, h)))(oracle_lib.lucas_kanade(fr[0], fr[1]))
+    # a byte whose +-1 flip moves the fitness: search the 7 x 7 neighbourhood of the first tracked corners in the second frame
+    found = None
+    for x, y in np.asarray(vecs[k])[:6, :2]:
+        for dy in range(-3, 4):
+            for dx in range(-3, 4):
+                yy, xx = int(round(y)) + dy, int(round(x)) + dx
+                if not (0 <= yy < h and 0 <= xx < w):
+                    continue
+                other = ours.copy()
+                other[1, 0, yy, xx] = other[1, 0, yy, xx] + 1 if other[1, 0, yy, xx] < 255 else 254
+                v2, f2 = fit_of(other)
+                if f2 != 0 and abs(f2 - fits[k]) / abs(fits[k]) > 1.5e-4:
+                    found = (other, v2, f2)
+                    break
+            if found:
+                break
+        if found:
+            break
+    assert found, "no single byte near the tracked corners moves the fitness by 1.5e-4: the fixture population changed?"
+    other, v2, f2 = found
+    r = classify.classify(st, ours, vecs[k], float(fits[k]), other, v2, float(f2))
+    assert r["flips"] == 1 and r["max_byte_diff"] == 1 and r["rel"] > 1e-4
+    r["fit_ours"], r["fit_other"] = float(fits[k]), float(f2)
+    r["single_lsb_effects"] = [float(e) for e in classify.attribute(st, w, h, ours, other, float(fits[k]))]
+    assert len(r["single_lsb_effects"]) == 1
+    dev = (f2 - fits[k]) / abs(fits[k])
+    assert abs(r["single_lsb_effects"][0] - dev) <= 1e-12 * max(1.0, abs(dev))   # the flip, applied alone, IS the deviation
+    assert classify.explained(r)
+    # the same flipped byte cannot explain a deviation the other way, nor one three times as large
+    for claimed in (fits[k] - (f2 - fits[k]), fits[k] + 3.0 * (f2 - fits[k])):
+        bad = dict(r, fit_other=float(claimed))
+        assert not classify.explained(bad), claimed
+    # ... and a byte that does not move the fitness explains nothing
+    flat = ours.copy()
+    yy, xx = (2, 2) if abs(float(np.asarray(vecs[k])[0, 1]) - 2) > 20 else (h - 3, w - 3)
+    flat[0, 0, yy, xx] = flat[0, 0, yy, xx] + 1 if flat[0, 0, yy, xx] < 255 else 254
+    eff = [float(e) for e in classify.attribute(st, w, h, ours, flat, float(fits[k]))]
+    assert len(eff) == 1
+    if abs(eff[0]) < 1e-7:   # (a corner that far from every feature: the usual case)
+        assert not classify.explained(dict(r, single_lsb_effects=eff, fit_other=float(fits[k] * (1 + 1e-3))))
+    # no attribution at all is never an explanation
+    assert not classify.explained(dict(r, single_lsb_effects=[]))
+
+
 def test_reference_order_is_stated_twice_and_deviates_from_the_canonical_one_by_ulps(oracle_lib):
     """The reference's element-wise ConvLSTM order (separate convolution tensors, plain unpool -> 9-tap, un-fused products,
     sigmoid = tanh(x/2)/2 + 1/2) in C (eig_oracle.c: lstm_reference_order, fma-chain convolutions, libm tanh) and in torch
