@@ -108,8 +108,21 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int tiles = a.tilesX * a.tilesY;
     const int ntile = a.B * tiles;
     const int xcd = blockIdx.x & 7, xi_ = blockIdx.x >> 3;
-    const int nblk = xi_ % a.n_nblk;
-    const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + xi_ / a.n_nblk : (xi_ / a.n_nblk) * 8 + xcd;
+    int nblk = xi_ % a.n_nblk;
+    int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + xi_ / a.n_nblk : (xi_ / a.n_nblk) * 8 + xcd;
+    if (a.tile_map >= 2 && a.n_nblk % a.tile_map == 0) {
+        // b = tile_map N-blocks x a = 32 / b tiles in flight on an XCD's 32 CUs instead of all n_nblk N-blocks of 32 / n_nblk tiles: the a blocks of an N-block stream ONE
+        // U slab through the L2 in step, the b blocks of a tile ONE set of planes.  Measured at the headline shape (profiles/r05_e_tile_map.txt): b = 2 380.5 -> 385.7
+        // evals/s (layers 2, 3: 6 / 12 N-blocks), b = 3, 4, 6: +0.5 %, b = 1 (planes re-read per N-block): +0.2 %; the window a (32 .. 128 tiles) does not matter
+        const int b = a.tile_map, at = 32 / b;
+        const int tx = (ntile + 7) >> 3;                   // tiles of this XCD
+        const int chunk = xi_ / (at * a.n_nblk), base = chunk * at;
+        const int ae = min(at, tx - base);
+        const int r = xi_ - chunk * at * a.n_nblk;
+        const int g = r / (ae * b), r2 = r - g * ae * b;
+        nblk = g * b + r2 % b;
+        tlin = xcd * tx + base + r2 / b;
+    }
     if (tlin >= ntile) return;
     const int eb = tlin / tiles;
     const int t_ = tlin - eb * tiles;

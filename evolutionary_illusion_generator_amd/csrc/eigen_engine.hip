@@ -533,8 +533,9 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     }
 #endif
     {
-        static const int tile_map = getenv("EIGEN_TILE_MAP") ? atoi(getenv("EIGEN_TILE_MAP")) : 1;  // 0 only for A/B measurements
-        a.tile_map = tile_map;
+        // 0 only for A/B measurements; F(4x4) kernel: value = N-blocks of a tile in flight on an XCD (conv_wino4.h; 2 measured best: profiles/r05_e_tile_map.txt)
+        static const int tile_map = getenv("EIGEN_TILE_MAP") ? atoi(getenv("EIGEN_TILE_MAP")) : -1;
+        a.tile_map = tile_map >= 0 ? tile_map : (op.wino_tile == 4 ? 2 : 1);
     }
     // Eight-wave instantiations (conv_mfma.h: W8).  Measured (profiles/r03_b_ab_w8.txt): where a launch fills the chip many times
     // over they change nothing (256 genomes at 256^2: every operator within +-0.5 %), where it does not they gain 4-5 % (160x120,
