@@ -438,54 +438,82 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         return y;
     };
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
-        // All twelve waves finish outputs: wave xi < 4 takes output row a = xi of the lane's tiles e = 0, 1, 2 (12 pixels per channel), wave xi = 4 the tile e = 3 of
-        // rows 0 and 1, wave xi = 5 the tile e = 3 of rows 2 and 3 (8 pixels): 12 / 8 LSTM cells per lane instead of 16 on eight waves and none on four.
-        // ys[ni][b][e]: the lane's pre-activations; waves 4, 5: index e = output row 2 (xi - 4) + e, e = 0, 1
-        float ys[NI][4][3];
-        auto finish_elem = [&](int arow, int bb, int ni) __attribute__((always_inline)) -> float {   // element e = 3 only (4-byte reads)
-            auto C1 = [&](int x) __attribute__((always_inline)) { return xb[((((x) * 2 + rg) * 2 + bb) * 4 + ni) * 256 + lane * 4 + 3]; };
-            const float c1 = C1(1), c2 = C1(2), c3 = C1(3), c4 = C1(4);
-            const float s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
-            if (arow == 0) return (C1(0) + s_) + u_;
-            if (arow == 1) return fmaf(2.0f, w_, d_);
-            if (arow == 2) return fmaf(4.0f, u_, s_);
-            return fmaf(8.0f, w_, d_) + C1(5);
+        // All twelve waves finish outputs, and they finish them in IMAGE order: the exchange is laid out so that a finishing lane reads the four pixels b = 0..3 of ONE tile
+        // as a 16-byte vector, and finishing lane L takes the 16-byte chunk j = L & 7 of a 32-pixel block row (tile tx = j, writer lane q = 2 ty + (j >> 2), register e =
+        // j & 3) of channel 8 chh + (L >> 3): the eight lanes j = 0..7 of a channel read / write ONE 128-byte line of c, the peepholes, h or P (lane = (tile group, channel)
+        // as the accumulators lie touched 64 lines per instruction, and the 7-9 us that cost per block were half of the time between two K loops:
+        // profiles/r05_f_w4_timeline.txt).  Units of 64 chunks: wave xi < 4 takes output row a = xi of (tile row ty, channel half chh) = (0,0), (0,1), (1,0); waves 4 / 5
+        // take (1,1) of rows 0, 1 / 2, 3 -- 12 or 8 cells per lane.  Rounds: N-tiles (gates) 0, 1 then 2, 3: [12 waves][2][4 e][64 lanes] 16-byte vectors = 96 KB each; the
+        // slot of writer lane (q, col) in plane e is q 16 + ((col + 4 e + 8 (q & 1)) & 15), which spreads every 16-lane service group of the b128 reads over all 16 slots.
+        const int j = lane & 7, chl = lane >> 3, e_r = j & 3, ql = j >> 2;
+        const int nun = xi < 4 ? 3 : 2;
+        int roff[3];
+#pragma unroll
+        for (int un = 0; un < 3; ++un) {
+            const int ty = xi < 4 ? (un >> 1) : 1, chh = xi < 4 ? (un & 1) : 1;
+            roff[un] = (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
+        }
+        int woff[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) woff[e] = ((wv * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + 8 * (q & 1)) & 15)) * 4;
+        auto finish = [&](int arow, int nr, int off) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3
+            auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + ((x * 2 + rg) * 2 + nr) * 1024 + off); };
+            const f32x4 c1 = C(1), c2 = C(2), c3 = C(3), c4 = C(4);
+            const f32x4 s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
+            f32x4 y;
+            if (arow == 0) { const f32x4 c0 = C(0); y = (c0 + s_) + u_; }
+            else if (arow == 1) { for (int b = 0; b < 4; ++b) y[b] = fmaf(2.0f, w_[b], d_[b]); }
+            else if (arow == 2) { for (int b = 0; b < 4; ++b) y[b] = fmaf(4.0f, u_[b], s_[b]); }
+            else { const f32x4 c5 = C(5); for (int b = 0; b < 4; ++b) y[b] = fmaf(8.0f, w_[b], d_[b]) + c5[b]; }
+            return y;
         };
+        f32x4 ys[NI][3];   // [N-tile][unit]: the four pixels of the lane's chunk
 #pragma unroll
         for (int rnd = 0; rnd < 2; ++rnd) {
+            if (2 * rnd >= NI) break;
             if (rnd) __syncthreads();   // (everyone has read round 0)
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
+            for (int nr = 0; nr < 2; ++nr) {
+                const int ni = 2 * rnd + nr;
+                if (ni >= NI) break;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(xb + (((wv * 2 + bb) * 4 + ni) * 256 + lane * 4)) = cc[2 * rnd + bb][ni];
+                for (int e = 0; e < 4; ++e) {
+                    f32x4 t;
+                    t[0] = cc[0][ni][e]; t[1] = cc[1][ni][e]; t[2] = cc[2][ni][e]; t[3] = cc[3][ni][e];
+                    *reinterpret_cast<f32x4*>(xb + woff[e] + nr * 1024) = t;
+                }
+            }
             __syncthreads();
             if (EIG_TIMING && rnd == 0) tq_x = __builtin_readcyclecounter();
 #pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
+            for (int nr = 0; nr < 2; ++nr) {
+                const int ni = 2 * rnd + nr;
+                if (ni >= NI) break;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni) {
-                    if (xi < 4) {
-                        f32x4 r;
-                        switch (xi) { case 0: r = finish_row(0, bb, ni); break; case 1: r = finish_row(1, bb, ni); break; case 2: r = finish_row(2, bb, ni); break; default: r = finish_row(3, bb, ni); break; }
-                        ys[ni][2 * rnd + bb][0] = r[0]; ys[ni][2 * rnd + bb][1] = r[1]; ys[ni][2 * rnd + bb][2] = r[2];
-                    } else if (xi == 4) {
-                        ys[ni][2 * rnd + bb][0] = finish_elem(0, bb, ni); ys[ni][2 * rnd + bb][1] = finish_elem(1, bb, ni);
-                    } else {
-                        ys[ni][2 * rnd + bb][0] = finish_elem(2, bb, ni); ys[ni][2 * rnd + bb][1] = finish_elem(3, bb, ni);
+                for (int un = 0; un < 3; ++un) {
+                    if (un >= nun) break;
+                    switch (xi) {
+                        case 0: ys[ni][un] = finish(0, nr, roff[un]); break;
+                        case 1: ys[ni][un] = finish(1, nr, roff[un]); break;
+                        case 2: ys[ni][un] = finish(2, nr, roff[un]); break;
+                        case 3: ys[ni][un] = finish(3, nr, roff[un]); break;
+                        case 4: ys[ni][un] = un ? finish(1, nr, roff[un]) : finish(0, nr, roff[un]); break;
+                        default: ys[ni][un] = un ? finish(3, nr, roff[un]) : finish(2, nr, roff[un]); break;
                     }
                 }
+            }
         }
         if (EIG_TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq_y = __builtin_readcyclecounter(); }
-        const int nun = xi < 4 ? 3 : 2;   // units of 4 pixels this wave finishes
 #pragma unroll
         for (int un = 0; un < 3; ++un) {
             if (un >= nun) break;
-            const int arow = xi < 4 ? xi : 2 * (xi - 4) + un, e = xi < 4 ? un : 3;
-            const int gy = y0 + 8 * rg + 4 * (q >> 1) + arow, gx = x0 + 16 * (q & 1) + 4 * e;
+            const int ty = xi < 4 ? (un >> 1) : 1, chh = xi < 4 ? (un & 1) : 1;
+            const int arow = xi < 4 ? xi : 2 * (xi - 4) + un;
+            const int gy = y0 + 8 * rg + 4 * ty + arow, gx = x0 + 4 * j;
             if (gy >= a.H || gx >= a.W) continue;
             const size_t pix = (size_t)gy * a.W + gx;
             if constexpr (EPI == EPI_LSTM) {
-                const int ch = ch0;
+                const int ch = nblk * 16 + 8 * chh + chl;
                 if (ch >= a.Cout) continue;
                 const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
                 const size_t cbase = ((size_t)eb * a.Cout + ch) * cHW, ps = (size_t)a.Cout * cHW, pbase = (size_t)ch * cHW;
@@ -497,7 +525,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
                     float cn, hn;
-                    lstm_cell(ys[0][b][un], ys[1][b][un], ys[2][b][un], ys[3][b][un], bi, bf, bc, bo, cold4[b], pi4[b], pf4[b], po4[b], cn, hn);
+                    lstm_cell(ys[0][un][b], ys[1][un][b], ys[2][un][b], ys[3][un][b], bi, bf, bc, bo, cold4[b], pi4[b], pf4[b], po4[b], cn, hn);
                     cn4[b] = cn; hn4[b] = hn;
                 }
                 *reinterpret_cast<f32x4*>(a.c_state + cbase + pix) = cn4;
@@ -505,12 +533,12 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             } else {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const int ch = ch0 + ni * 16;
+                    const int ch = (nblk * NI + ni) * 16 + 8 * chh + chl;
                     if (ch >= a.Cout) continue;
                     const float bb_ = a.bias[ch];
                     f32x4 v4;
 #pragma unroll
-                    for (int b = 0; b < 4; ++b) v4[b] = relu_f(ys[ni][b][un] + bb_);
+                    for (int b = 0; b < 4; ++b) v4[b] = relu_f(ys[ni][un][b] + bb_);
                     *reinterpret_cast<f32x4*>(a.Pout + ((size_t)eb * a.Cout + ch) * cHW + pix) = v4;
                 }
             }

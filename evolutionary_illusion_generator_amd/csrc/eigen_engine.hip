@@ -526,7 +526,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     const bool vec = (op.W % 4) == 0;
 #if EIG_TIMING
     unsigned long long* tl_dbg = nullptr;
-    if (getenv("EIGEN_TIMELINE") && (op.epi == EPI_LSTM || (op.epi == EPI_UP4 && op.NI == 4)) && ++op.tl_seen == 6) {  // a steady-state launch of every ConvLSTM op and 2x2-form pass
+    if (getenv("EIGEN_TIMELINE") && (op.epi == EPI_LSTM || (op.epi == EPI_UP4 && op.NI == 4) || (op.wino_tile == 4 && getenv("EIGEN_TIMELINE_ALL"))) && ++op.tl_seen == 6) {  // a steady-state launch of every ConvLSTM op and 2x2-form pass
         (void)hipMalloc((void**)&tl_dbg, (size_t)grid * 2 * 64 * 8);  // half blocks double the grid, W8 blocks have 8 waves
         (void)hipMemset(tl_dbg, 0, (size_t)grid * 2 * 64 * 8);
         a.dbg = tl_dbg;
@@ -659,7 +659,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         std::vector<unsigned long long> h((size_t)op.last_grid * op.last_waves * 8);
         (void)hipMemcpy(h.data(), tl_dbg, h.size() * 8, hipMemcpyDeviceToHost);
         char name[256];
-        snprintf(name, sizeof(name), "%s/timeline_H%d_C%d%s.bin", getenv("EIGEN_TIMELINE"), op.H, op.Cout, op.epi == EPI_UP4 ? "_up4" : "");
+        snprintf(name, sizeof(name), "%s/timeline_H%d_C%d%s.bin", getenv("EIGEN_TIMELINE"), op.H, op.Cout, op.epi == EPI_UP4 ? "_up4" : op.epi == EPI_CONVA ? "_convA" : op.epi == EPI_CONVP ? "_convP" : "");
         if (FILE* f = fopen(name, "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
         (void)hipFree(tl_dbg);
         a.dbg = nullptr;
