@@ -420,23 +420,15 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) cc[b][ni] = Y[b];
     }
-    // Along xi: the six waves of a region publish their c rows in two rounds (b = 0, 1 then b = 2, 3: [12 waves][2 b][NI][64 lanes] 16-byte vectors = 96 KB each; U / planes
-    // are dead -- every wave is past the last barrier, every DMA has landed); the finishing waves read what their output rows need.
+    // Along xi: the six waves of a region publish their c rows in two rounds (N-tiles 0, 1 then 2, 3: [12 waves][2 N-tiles][4 e][64 lanes] 16-byte vectors over b = 96 KB
+    // each; U / planes are dead -- every wave is past the last barrier, every DMA has landed); the finishing lanes read what their output rows need:
+    // y0 = (c0 + s) + u, y1 = fma(2, w, d), y2 = fma(4, u, s), y3 = fma(8, w, d) + c5 with s = c1 + c2, d = c1 - c2, u = c3 + c4, w = c3 - c4.
     float* const xb = lds;
-#define EIG4_C(x, bb, ni) (*reinterpret_cast<const f32x4*>(xb + ((((x) * 2 + rg) * 2 + (bb)) * 4 + (ni)) * 256 + lane * 4))   // c_x,b of N-tile ni, published by wave (xi = x, rg)
-    const int ch0 = (EPI == EPI_LSTM) ? nblk * 16 + col : nblk * NI * 16 + col;   // channel of N-tile 0 (ConvLSTM: of every gate)
     const size_t cHW = (size_t)HW;
-    // one output row `arow` (0..3) of the lane's four tiles (ty = q >> 1, tx = 4 (q & 1) + e): register e -> pixels x0 + 16 (q & 1) + 4 e + b of image row y0 + 8 rg + 4 ty + arow
-    auto finish_row = [&](int arow, int bb, int ni) __attribute__((always_inline)) -> f32x4 {
-        const f32x4 c1 = EIG4_C(1, bb, ni), c2 = EIG4_C(2, bb, ni), c3 = EIG4_C(3, bb, ni), c4 = EIG4_C(4, bb, ni);
-        const f32x4 s = c1 + c2, d = c1 - c2, u = c3 + c4, w = c3 - c4;
-        f32x4 y;
-        if (arow == 0) { const f32x4 c0 = EIG4_C(0, bb, ni); y = (c0 + s) + u; }
-        else if (arow == 1) { for (int e = 0; e < 4; ++e) y[e] = fmaf(2.0f, w[e], d[e]); }
-        else if (arow == 2) { for (int e = 0; e < 4; ++e) y[e] = fmaf(4.0f, u[e], s[e]); }
-        else { const f32x4 c5 = EIG4_C(5, bb, ni); for (int e = 0; e < 4; ++e) y[e] = fmaf(8.0f, w[e], d[e]) + c5[e]; }
-        return y;
-    };
+    const int j = lane & 7, chl = lane >> 3, e_r = j & 3, ql = j >> 2;   // finishing lane: chunk j of the block row, channel 8 chh + chl (see below)
+    int woff[4];                                                           // publishing lane (q, col): its slot in plane e
+#pragma unroll
+    for (int e = 0; e < 4; ++e) woff[e] = ((wv * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + 8 * (q & 1)) & 15)) * 4;
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
         // All twelve waves finish outputs, and they finish them in IMAGE order: the exchange is laid out so that a finishing lane reads the four pixels b = 0..3 of ONE tile
         // as a 16-byte vector, and finishing lane L takes the 16-byte chunk j = L & 7 of a 32-pixel block row (tile tx = j, writer lane q = 2 ty + (j >> 2), register e =
@@ -445,7 +437,6 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         // profiles/r05_f_w4_timeline.txt).  Units of 64 chunks: wave xi < 4 takes output row a = xi of (tile row ty, channel half chh) = (0,0), (0,1), (1,0); waves 4 / 5
         // take (1,1) of rows 0, 1 / 2, 3 -- 12 or 8 cells per lane.  Rounds: N-tiles (gates) 0, 1 then 2, 3: [12 waves][2][4 e][64 lanes] 16-byte vectors = 96 KB each; the
         // slot of writer lane (q, col) in plane e is q 16 + ((col + 4 e + 8 (q & 1)) & 15), which spreads every 16-lane service group of the b128 reads over all 16 slots.
-        const int j = lane & 7, chl = lane >> 3, e_r = j & 3, ql = j >> 2;
         const int nun = xi < 4 ? 3 : 2;
         int roff[3];
 #pragma unroll
@@ -453,9 +444,6 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             const int ty = xi < 4 ? (un >> 1) : 1, chh = xi < 4 ? (un & 1) : 1;
             roff[un] = (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
         }
-        int woff[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) woff[e] = ((wv * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + 8 * (q & 1)) & 15)) * 4;
         auto finish = [&](int arow, int nr, int off) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3
             auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + ((x * 2 + rg) * 2 + nr) * 1024 + off); };
             const f32x4 c1 = C(1), c2 = C(2), c3 = C(3), c4 = C(4);
@@ -545,65 +533,71 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         }
         timeline();
     } else {
-        // ConvA: wave xi < 4 finishes the row PAIR ap = xi >> 1 (output rows 2 ap, 2 ap + 1) for the N-tiles ni = (xi & 1), (xi & 1) + 2: the 2x2 pooling windows of
-        // the 4x4 tile -- (rows 2 ap, 2 ap + 1) x (columns 2 bp, 2 bp + 1) -- stay in one lane; pooled pixel ((y0 >> 1) + 4 rg + 2 (q >> 1) + ap, (x0 >> 1) + 8 (q & 1) + 2 e + bp)
-        const int ap = xi >> 1, np_ = xi & 1;
-        f32x4 y[2][2][4];   // [N-tile k of this wave][row of the pair][b]
-#pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            if (rnd) __syncthreads();
-#pragma unroll
-            for (int bb = 0; bb < 2; ++bb)
-#pragma unroll
-                for (int ni = 0; ni < NI; ++ni) *reinterpret_cast<f32x4*>(xb + (((wv * 2 + bb) * 4 + ni) * 256 + lane * 4)) = cc[2 * rnd + bb][ni];
-            __syncthreads();
-            if (xi < 4) {
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int ni = np_ + 2 * k;
-                    if (ni >= NI) continue;
-#pragma unroll
-                    for (int bb = 0; bb < 2; ++bb) {
-                        if (ap == 0) { y[k][0][2 * rnd + bb] = finish_row(0, bb, ni); y[k][1][2 * rnd + bb] = finish_row(1, bb, ni); }
-                        else { y[k][0][2 * rnd + bb] = finish_row(2, bb, ni); y[k][1][2 * rnd + bb] = finish_row(3, bb, ni); }
-                    }
-                }
-            }
-        }
-        if (xi >= 4) return;
+        // ConvA, in image order as well: a finishing lane takes the chunk j of the output-row PAIR ap (rows 2 ap, 2 ap + 1) of tile row ty for one channel -- the two 2x2
+        // pooling windows of its four pixels -- i.e. two pooled pixels (8 bytes); the eight lanes of a channel cover 16 pooled pixels = 64 contiguous bytes of P and of both
+        // halves of E.  Units of 64 such lanes per round (N-tiles 2 rnd, 2 rnd + 1): g = (nr, ty, ap, chh), 16 of them (8 when the round holds one N-tile) over the six waves
+        // of the region as 3,3,3,3,2,2 (2,2,1,1,1,1).  (Before: lane = (tile group, channel), 8-byte accesses to 64 different lines per instruction, and only xi < 4 worked.)
         const int Ho = a.H >> 1, Wo = a.W >> 1;
         const size_t plane = (size_t)Ho * Wo;
-        const int oy = (y0 >> 1) + 4 * rg + 2 * (q >> 1) + ap;
-        if (oy >= Ho) return;
+        const int ox = (x0 >> 1) + 2 * j;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int ni = np_ + 2 * k;
-            if (ni >= NI) continue;
-            const int ch = ch0 + ni * 16;
-            if (ch >= a.Cout) continue;
-            const float bb_ = a.bias[ch];
-            const size_t pb = ((size_t)eb * a.Cout + ch) * plane;
-            const size_t e0 = ((size_t)eb * 2 * a.Cout + ch) * plane, e1 = e0 + (size_t)a.Cout * plane;
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (2 * rnd >= NI) break;
+            const int nval = NI - 2 * rnd >= 2 ? 2 : 1;
+            if (rnd) __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {   // tile tx = 4 (q & 1) + e: pooled columns ox, ox + 1
-                const int ox = (x0 >> 1) + 8 * (q & 1) + 2 * e;
-                if (ox >= Wo) continue;
-                const f32x2 p2 = *reinterpret_cast<const f32x2*>(a.P + pb + (size_t)oy * Wo + ox);
+            for (int nr = 0; nr < 2; ++nr) {
+                if (nr >= nval) break;
+                const int ni = 2 * rnd + nr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x4 t;
+                    t[0] = cc[0][ni][e]; t[1] = cc[1][ni][e]; t[2] = cc[2][ni][e]; t[3] = cc[3][ni][e];
+                    *reinterpret_cast<f32x4*>(xb + woff[e] + nr * 1024) = t;
+                }
+            }
+            __syncthreads();
+            const int g0 = nval == 2 ? (xi < 4 ? 3 * xi : 12 + 2 * (xi - 4)) : (xi < 2 ? 2 * xi : xi + 2);
+            const int cnt = nval == 2 ? (xi < 4 ? 3 : 2) : (xi < 2 ? 2 : 1);
+#pragma unroll
+            for (int un = 0; un < 3; ++un) {
+                if (un >= cnt) break;
+                const int g = g0 + un;
+                const int nr = g >> 3, ty = (g >> 2) & 1, ap = (g >> 1) & 1, chh = g & 1;
+                const int off = ((nr + 2 * rg) * 256 + e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
+                auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + x * 4096 + off); };
+                const f32x4 c1 = C(1), c2 = C(2), c3 = C(3), c4 = C(4);
+                const f32x4 s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
+                f32x4 ya, yb;   // output rows 2 ap, 2 ap + 1
+                if (ap == 0) {
+                    const f32x4 c0 = C(0);
+                    ya = (c0 + s_) + u_;
+                    for (int b = 0; b < 4; ++b) yb[b] = fmaf(2.0f, w_[b], d_[b]);
+                } else {
+                    const f32x4 c5 = C(5);
+                    for (int b = 0; b < 4; ++b) { ya[b] = fmaf(4.0f, u_[b], s_[b]); yb[b] = fmaf(8.0f, w_[b], d_[b]) + c5[b]; }
+                }
+                const int ch = (nblk * NI + 2 * rnd + nr) * 16 + 8 * chh + chl;
+                const int oy = (y0 >> 1) + 4 * rg + 2 * ty + ap;
+                if (oy >= Ho || ox >= Wo || ch >= a.Cout) continue;
+                const float bb_ = a.bias[ch];
+                const size_t pb = ((size_t)eb * a.Cout + ch) * plane + (size_t)oy * Wo + ox;
+                const size_t e0 = ((size_t)eb * 2 * a.Cout + ch) * plane + (size_t)oy * Wo + ox, e1 = e0 + (size_t)a.Cout * plane;
+                const f32x2 p2 = *reinterpret_cast<const f32x2*>(a.P + pb);
                 f32x2 ea, eb2;
 #pragma unroll
                 for (int bp = 0; bp < 2; ++bp) {
-                    const float v00 = relu_f(y[k][0][2 * bp][e] + bb_), v01 = relu_f(y[k][0][2 * bp + 1][e] + bb_);
-                    const float v10 = relu_f(y[k][1][2 * bp][e] + bb_), v11 = relu_f(y[k][1][2 * bp + 1][e] + bb_);
+                    const float v00 = relu_f(ya[2 * bp] + bb_), v01 = relu_f(ya[2 * bp + 1] + bb_);
+                    const float v10 = relu_f(yb[2 * bp] + bb_), v11 = relu_f(yb[2 * bp + 1] + bb_);
                     const float A = fmaxf(fmaxf(v00, v01), fmaxf(v10, v11));
                     ea[bp] = relu_f(A - p2[bp]);
                     eb2[bp] = relu_f(p2[bp] - A);
                 }
-                *reinterpret_cast<f32x2*>(a.E + e0 + (size_t)oy * Wo + ox) = ea;
-                *reinterpret_cast<f32x2*>(a.E + e1 + (size_t)oy * Wo + ox) = eb2;
+                *reinterpret_cast<f32x2*>(a.E + e0) = ea;
+                *reinterpret_cast<f32x2*>(a.E + e1) = eb2;
             }
         }
     }
-#undef EIG4_C
 #undef EIG4_WAITCNT
 #undef EIG4_BARRIER
 #undef EIG4_IS_UP
