@@ -96,6 +96,9 @@ struct ConvArgs {
     int H, W, B;
     int tilesX, tilesY;
     int n_nblk;
+    // conv_wino4.h: reciprocals ceil(2^32 / d) of the divisors of the block -> (N-block, image, tile) map (0 = not exact for this launch's range: divide), d = n_nblk,
+    // tilesX * tilesY, tilesX, at * n_nblk, at * b, b with b = tile_map and at = 32 / b tiles in flight per XCD
+    unsigned mg[6];
     int krows;          // packed weight rows per N-block (sum of Cpad*9)
     const float* wpk;   // [n_nblk][krows][NB]
     int Cout;           // real output channels (per gate for the LSTM)

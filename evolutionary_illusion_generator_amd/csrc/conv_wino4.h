@@ -108,25 +108,30 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int tiles = a.tilesX * a.tilesY;
     const int ntile = a.B * tiles;
     const int xcd = blockIdx.x & 7, xi_ = blockIdx.x >> 3;
-    int nblk = xi_ % a.n_nblk;
-    int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + xi_ / a.n_nblk : (xi_ / a.n_nblk) * 8 + xcd;
-    if (a.tile_map >= 2 && a.n_nblk % a.tile_map == 0) {
+    // (divisions by launch constants through their host-side reciprocals, ConvArgs::mg: a run-time integer division is ~25 dependent scalar instructions, and the ten of
+    // them here were most of the 1.4 - 1.8 us a block spent before its first fetch: profiles/r05_f_w4_timeline.txt)
+    auto dv = [&](int x, int d, unsigned m) __attribute__((always_inline)) { return m ? (int)__umulhi((unsigned)x, m) : x / d; };
+    const int q0 = dv(xi_, a.n_nblk, a.mg[0]);
+    int nblk = xi_ - q0 * a.n_nblk;
+    int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + q0 : q0 * 8 + xcd;
+    if (a.tile_map >= 2 && a.mg[5]) {   // (mg[5] != 0: tile_map divides n_nblk, set by the host)
         // b = tile_map N-blocks x a = 32 / b tiles in flight on an XCD's 32 CUs instead of all n_nblk N-blocks of 32 / n_nblk tiles: the a blocks of an N-block stream ONE
         // U slab through the L2 in step, the b blocks of a tile ONE set of planes.  Measured at the headline shape (profiles/r05_e_tile_map.txt): b = 2 380.5 -> 385.7
         // evals/s (layers 2, 3: 6 / 12 N-blocks), b = 3, 4, 6: +0.5 %, b = 1 (planes re-read per N-block): +0.2 %; the window a (32 .. 128 tiles) does not matter
-        const int b = a.tile_map, at = 32 / b;
+        const int b = a.tile_map, at = b == 2 ? 16 : 32 / b;
         const int tx = (ntile + 7) >> 3;                   // tiles of this XCD
-        const int chunk = xi_ / (at * a.n_nblk), base = chunk * at;
+        const int chunk = dv(xi_, at * a.n_nblk, a.mg[3]), base = chunk * at;
         const int ae = min(at, tx - base);
         const int r = xi_ - chunk * at * a.n_nblk;
-        const int g = r / (ae * b), r2 = r - g * ae * b;
-        nblk = g * b + r2 % b;
-        tlin = xcd * tx + base + r2 / b;
+        const int g = ae == at ? dv(r, at * b, a.mg[4]) : r / (ae * b), r2 = r - g * ae * b;
+        const int r2b = dv(r2, b, a.mg[5]);
+        nblk = g * b + (r2 - r2b * b);
+        tlin = xcd * tx + base + r2b;
     }
     if (tlin >= ntile) return;
-    const int eb = tlin / tiles;
+    const int eb = dv(tlin, tiles, a.mg[1]);
     const int t_ = tlin - eb * tiles;
-    const int tyi = t_ / a.tilesX, txi = t_ - tyi * a.tilesX;
+    const int tyi = dv(t_, a.tilesX, a.mg[2]), txi = t_ - tyi * a.tilesX;
     const int y0 = tyi * 16, x0 = txi * 32;
     const int HW = a.H * a.W;
 

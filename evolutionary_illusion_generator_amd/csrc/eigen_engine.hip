@@ -573,6 +573,12 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             auto go4 = [&](auto kern) {
                 a.tilesX = (op.W + 31) / 32; a.tilesY = (op.H + 15) / 16;
                 const int g4 = op.n_nblk * ((batch * a.tilesX * a.tilesY + 7) / 8) * 8;
+                {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
+                    auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };
+                    const int b = a.tile_map >= 2 && op.n_nblk % a.tile_map == 0 ? a.tile_map : 0, at = b ? 32 / b : 0;
+                    a.mg[0] = magic(op.n_nblk); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
+                    a.mg[3] = b ? magic((long long)at * op.n_nblk) : 0u; a.mg[4] = b ? magic((long long)at * b) : 0u; a.mg[5] = b ? magic(b) : 0u;
+                }
                 static std::unordered_set<const void*> attr_done;   // (the handle is not thread-safe anyway: one rank, one host thread)
                 if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, wino4_lds_bytes());
                 op.last_grid = g4; op.last_waves = W4_WAVES;
