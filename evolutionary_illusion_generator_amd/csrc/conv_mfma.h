@@ -1189,7 +1189,8 @@ __global__ void __launch_bounds__(L0_TX * L0_TY) lstm0_direct_kernel(const float
     const size_t up_hw = (size_t)Hs * Ws;
     const float* up = a.acc_init ? a.acc_init + (((size_t)b * 4 + ((gy & 1) * 2 + (gx & 1))) * 16) * up_hw + (size_t)(gy >> 1) * Ws + (gx >> 1) : nullptr;
     // one chain at a time (measured: feeding all 4 x C chains from each staged value is slower -- 972 scalar weight operands
-    // in flight instead of a stream of them: 1.21 vs 1.07 ms per launch)
+    // in flight instead of a stream of them: 1.21 vs 1.07 ms per launch; round 5: the 81 staged values of a pixel held in registers across the chains, 81 LDS reads
+    // instead of 972 but 110 VGPRs instead of 56: 1.44 vs 1.08 ms -- half the waves to hide the scalar weight loads behind)
 #pragma unroll
     for (int o = 0; o < C; ++o) {
         float z[4];
