@@ -48,7 +48,7 @@ constexpr int W4_NUS = 3, W4_NPS = 3;
 constexpr int W4_ROW = 40;                          // floats per plane row: aligned chunks x0-4 .. x0+35
 constexpr int W4_PS = 768;                          // floats per channel plane: 18 rows x 40 = 720 -> three DMA instructions of 256
 constexpr int wino4_lds_bytes() { return (W4_NUS * W4_U_FLOATS + W4_NPS * W4_KC * W4_PS) * 4; }   // 147456 (one exchange round: 12 waves x 8 KB = 98304)
-constexpr int wino4_u_floats(int NI) { return W4_NPOS * 8 * 16 * NI; }   // one 8-channel K-block of the packed weights: [36 pos][8 ch][16 cols][NI]
+constexpr int wino4_u_floats(int NI) { return W4_NPOS * 4 * 16 * NI; }   // one 4-channel K-block of the packed weights: [36 pos][4 ch][16 cols][NI] (the buffer ends in one K-block of padding: the fetch runs one K-block past the end)
 #ifndef EIG_W4_DIAG
 #define EIG_W4_DIAG 0   // measurement builds only (WRONG RESULTS): 1 no wait for the K loop's DMAs, 2 no barrier in the K loop, 4 no A-operand build, 8 no plane DMA, 16 no U DMA
 #endif
@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     static_assert(EPI == EPI_LSTM || EPI == EPI_CONVA || EPI == EPI_CONVP, "conv_wino4.h: ConvLSTM, ConvA, ConvP");
     static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
     static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
-    constexpr int U8 = wino4_u_floats(NI);
+    constexpr int U4 = wino4_u_floats(NI);
     constexpr int NUS = W4_NUS, NPS = W4_NPS, KC = W4_KC, PS = W4_PS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py with EIG_TL_WAVES=12)
@@ -144,8 +144,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #define EIG4_WAITCNT(imm) do { __builtin_amdgcn_s_waitcnt(imm); asm volatile("" ::: "memory"); } while (0)
 #define EIG4_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define EIG4_IS_UP(kb) ((kb) >= up_lo && (kb) < up_hi)
-    const int nkb8 = nkb / 2;
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb8 * U8), 0, nkb8 * U8 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // ---- plane fetch (every wave: channel wv / 3 of the K-block, part wv % 3 of its plane): lane = 16-byte chunk of the 18 x 10-chunk haloed plane (unpooled source:
@@ -181,16 +180,18 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + (slot * KC + pch) * PS + ppart * 256), 16,
                                                  (int)__builtin_elementwise_add_sat((unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (unsigned)mu), coff), 0, 0, 0);
     };
-    // ---- U fetch (every wave: positions 3 wv .. 3 wv + 2): the 4-channel half of a position of the packed 8-channel K-block = one contiguous KB (NI = 3: 768 B)
+    // ---- U fetch (every wave: positions 3 wv .. 3 wv + 2 of the next K-block in line): one position of a packed 4-channel K-block = one contiguous KB (NI = 3: 768 B).
+    // The scalar offset runs along the packed K-blocks (no index arithmetic in the K loop; the last two fetches read the next N-block's first K-blocks or the
+    // buffer's padding into slots nobody reads).
     const int uvo = (NI == 4 || lane < 48) ? lane * 16 : -1;
-    auto dma_u = [&](int jj, int slot) __attribute__((always_inline)) {   // K-block min(jj, nkb - 1) -> slot
-        const int j = jj < nkb ? jj : nkb - 1;
-        constexpr unsigned HALF = 4 * 16 * NI * 4, POS = 8 * 16 * NI * 4;   // bytes
-        const unsigned so = (unsigned)(j >> 1) * (U8 * 4) + (unsigned)(j & 1) * HALF + (unsigned)(3 * wv) * POS;
+    constexpr unsigned W4_POSB = 4 * 16 * NI * 4;   // bytes per position
+    unsigned u_so = (unsigned)(3 * wv) * W4_POSB;
+    auto dma_u = [&](int slot_off) __attribute__((always_inline)) {   // -> the U slot at float offset slot_off
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(Ub + slot * W4_U_FLOATS + (3 * wv + i) * W4_UPOS), 16, uvo,
-                                                     (int)(so + (unsigned)i * POS), 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(Ub + slot_off + (3 * wv + i) * W4_UPOS), 16, uvo,
+                                                     (int)(u_so + (unsigned)i * W4_POSB), 0, 0);
+        u_so += (unsigned)U4 * 4;
     };
 
     // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) = (col >> 3, col & 7) of region rg (rows 8 rg .. 8 rg + 7 of the block; MFMA row r = 8 ty + tx)
@@ -208,9 +209,9 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 
     // ---- prologue: the U slabs of K-blocks 0, 1 and the planes of K-blocks 0, 1, 2
     const unsigned long long tq_setup = EIG_TIMING ? __builtin_readcyclecounter() : 0;
-    dma_u(0, 0);
+    dma_u(0);
     dma_plane_at(0, 0);
-    dma_u(1, 1);
+    dma_u(W4_U_FLOATS);
     dma_plane_at(1, 1);
     dma_plane_at(2, 2);
     EIG4_WAITCNT(0x0F71);   // all but the plane of K-block 2
@@ -235,12 +236,14 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         constexpr int XI = decltype(role_tag)::value;
         float v[6];            // A operands of the current K-block (built at the end of the previous one)
         float bq[NI];          // B operand of the current K-block's first chunk, read before the barrier in front of it
-        int rslot = 0;         // plane slot of the K-block whose patch rows are read next
-        int uslot = 0;         // U slot of the current K-block
-        int fu = 2;            // U slot the next fetch goes to
+        // Rings of three, all in the phase kb % 3, as ROTATING float offsets (one set of moves per K-block; slot counters cost an add, a compare, a select and a multiply
+        // each, in every K-block's instruction stream): U slots of K-blocks kb, kb + 1 and of the fetch (kb + 2); plane slots of the fetch (kb + 3 -> slot kb % 3), of the
+        // patch rows read next (kb + 1) and the third
+        int uo0 = 0, uo1 = W4_U_FLOATS, uo2 = 2 * W4_U_FLOATS;
+        int po0 = 0, po1 = KC * PS, po2 = 2 * KC * PS;
         // fetch cursor of the planes (K-block pj = kb + 3, clamped to the last one): the descriptor of its source as scalars (a mutable descriptor OBJECT ends in
         // scratch memory), the byte offset of this wave's channel, the slot
-        int pj = 0, pslot = 0, psz = 0;
+        int pj = 0, psz = 0;
         unsigned pcoff = 0, plo = 0, phi = 0, phw4 = 0;
         bool pup = false;
         auto plane_source = [&](int j) __attribute__((always_inline)) {   // (re)position the cursor on K-block j: at the start and where a source begins
@@ -255,12 +258,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             pcoff = (unsigned)((j - base) * KC + pch) * phw4;
             pup = up; pj = j;
         };
-        auto dma_plane = [&]() __attribute__((always_inline)) {   // this wave's plane DMA of K-block pj -> slot pslot, then advance the cursor
+        auto dma_plane = [&]() __attribute__((always_inline)) {   // this wave's plane DMA of K-block pj -> the slot at po0, then advance the cursor
             const unsigned o = (unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (0u - (unsigned)pup));
             const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)phi << 32) | plo), 0, psz, 0x00020000);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + (pslot * KC + pch) * PS + ppart * 256), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + pch * PS + ppart * 256), 16,
                                                      (int)__builtin_elementwise_add_sat(o, pcoff), 0, 0, 0);
-            pslot = pslot == NPS - 1 ? 0 : pslot + 1;
             if (pj + 1 < nkb) {
                 if (pj + 1 == up_lo || pj + 1 == up_hi) plane_source(pj + 1);
                 else { ++pj; pcoff += KC * phw4; }
@@ -293,9 +295,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                 }
             }
         };
-        auto rows_begin = [&](bool up) __attribute__((always_inline)) {   // the next K-block's plane slot, then phase 0's reads
-            rso = rslot * (KC * PS); rup = up;
-            rslot = rslot == NPS - 1 ? 0 : rslot + 1;
+        auto rows_begin = [&](int slot_off, bool up) __attribute__((always_inline)) {   // the plane slot of the K-block whose patch rows are read, then phase 0's reads
+            rso = slot_off; rup = up;
             read_rows(0);
         };
         auto rows_mid = [&]() __attribute__((always_inline)) {     // the inner operation from phase 0's rows, then phase 1's reads
@@ -324,8 +325,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             if (EIG_W4_DIAG & 4) { for (int c = 0; c < 6; ++c) v[c] = 1.0f; return; }
             w4_in1d(t[0], t[1], t[2], t[3], t[4], t[5], v);
         };
-        auto read_b = [&](int slot, int nu, float* dst) __attribute__((always_inline)) {
-            const float* const bsrc = Ub + slot * W4_U_FLOATS + b_off + nu * W4_UPOS;
+        auto read_b = [&](int slot_off, int nu, float* dst) __attribute__((always_inline)) {
+            const float* const bsrc = Ub + slot_off + b_off + nu * W4_UPOS;
             if constexpr (NI == 4) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(bsrc);
                 dst[0] = b4[0]; dst[1] = b4[1]; dst[2] = b4[2]; dst[3] = b4[3];
@@ -345,15 +346,14 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             constexpr bool UP = KIND == 1;   // (run-time kind = the last K-block of all: an unpooled-source one there runs the full body on its exact-zero operands -- fma(0, u, M) = M)
             constexpr bool IDLE = UP && XI == 2;   // nothing to multiply
             constexpr int NCH = IDLE ? 0 : (UP ? 5 : 6);   // chunks: nu = 0, 1, (2,) 3, 4, 5
-            const int nslot = uslot == NUS - 1 ? 0 : uslot + 1;
             float bv[2][NI];
             // slices of staging work behind the chunks: the U fetch behind chunk 0, the plane fetch behind chunk 1, the patch rows of K-block kb + 1 and row XI of
             // B^T d in two phases behind chunks NCH - 4 .. NCH - 2 (their registers are needed late), the column pass behind the last chunk
             auto slice = [&](int i) __attribute__((always_inline)) {
                 if constexpr (!LAST) {
-                    if (i == 0) { if (!(EIG_W4_DIAG & 16)) dma_u(kb + 2, fu); fu = fu == NUS - 1 ? 0 : fu + 1; }
+                    if (i == 0) { if (!(EIG_W4_DIAG & 16)) dma_u(uo2); }
                     if (i == 1) { if (!(EIG_W4_DIAG & 8)) dma_plane(); }
-                    if (i == NCH - 4) rows_begin(NK == 2 ? EIG4_IS_UP(kb + 1) : NK == 1);
+                    if (i == NCH - 4) rows_begin(po1, NK == 2 ? EIG4_IS_UP(kb + 1) : NK == 1);
                     if (i == NCH - 3) rows_mid();
                     if (i == NCH - 2) rows_end();
                     if (i == NCH - 1) build_cols();
@@ -361,11 +361,10 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             };
             if constexpr (IDLE) {
                 if constexpr (!LAST) {
-                    if (!(EIG_W4_DIAG & 16)) dma_u(kb + 2, fu);
-                    fu = fu == NUS - 1 ? 0 : fu + 1;
+                    if (!(EIG_W4_DIAG & 16)) dma_u(uo2);
                     if (!(EIG_W4_DIAG & 8)) dma_plane();
-                    rows_begin(NK == 2 ? EIG4_IS_UP(kb + 1) : NK == 1); rows_mid(); rows_end();
-                    read_b(nslot, 0, bq); build_cols();
+                    rows_begin(po1, NK == 2 ? EIG4_IS_UP(kb + 1) : NK == 1); rows_mid(); rows_end();
+                    read_b(uo1, 0, bq); build_cols();
                 }
             } else {
 #pragma unroll
@@ -373,8 +372,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                     const int nu = (UP && i >= 2) ? i + 1 : i;
                     if (i + 1 < NCH) {
                         const int nu1 = (UP && i + 1 >= 2) ? i + 2 : i + 1;
-                        read_b(uslot, nu1, bv[(i + 1) & 1]);
-                    } else if constexpr (!LAST) read_b(nslot, 0, bq);
+                        read_b(uo0, nu1, bv[(i + 1) & 1]);
+                    } else if constexpr (!LAST) read_b(uo1, 0, bq);
                     const float* const b = i == 0 ? bq : bv[i & 1];
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) acc[nu][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], b[ni], acc[nu][ni], 0, 0, 0);
@@ -382,7 +381,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            uslot = nslot;
+            { const int t0 = uo0; uo0 = uo1; uo1 = uo2; uo2 = t0; }
+            { const int t0 = po0; po0 = po1; po1 = po2; po2 = t0; }
             // the U fetch of this K-block has landed (its plane fetch may stay in flight: it is read two K-blocks from now); after the last K-block: everything
             if (LAST || (EIG_W4_DIAG & (8 | 16))) EIG4_WAITCNT(0x0F70);
             else if (!(EIG_W4_DIAG & 1)) EIG4_WAITCNT(0x0F71);
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         const std::false_type nl{};
         const std::integral_constant<int, 2> rt{};
         int kb = 0;
-        rows_begin(EIG4_IS_UP(0)); rows_mid(); rows_end();
+        rows_begin(0, EIG4_IS_UP(0)); rows_mid(); rows_end();
         read_b(0, 0, bq);
         build_cols();
         EIG4_WAITCNT(0xC07F);

@@ -422,15 +422,16 @@ static void wino4_weight(const float* g, float* U)
     for (int j = 0; j < 3; ++j) { wino4_w1d(g[j], g[3 + j], g[6 + j], W); for (int i = 0; i < 6; ++i) s[i][j] = W[i]; }
     for (int i = 0; i < 6; ++i) wino4_w1d(s[i][0], s[i][1], s[i][2], U + i * 6);
 }
-// [n_nblk][K-blocks: 8 channels of one source, sources in order][16 (tile 4: 36) positions][8 channels][16 columns][NI N-tiles]
+// [n_nblk][K-blocks: 8 (tile 4: 4) channels of one source, sources in order][16 (tile 4: 36) positions][8 (4) channels][16 columns][NI N-tiles]
 // lstm: N-tile = gate, output channel = 16 nb + column (srcw[s][gate]); plain convolution: output channel = 16 (NI nb + N-tile) + column (srcw[s][0])
 static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm, int nsrc, const int* src_C, const int* src_Cw, const float* const srcw[3][4], int tile = 2)
 {
+    const int kc = tile == 4 ? 4 : KC;   // channels of a packed K-block: F(4x4) 4 (conv_wino4.h streams them with a running offset, and one K-block past the end: padding)
     int nkb = 0;
-    for (int s = 0; s < nsrc; ++s) nkb += src_C[s] / KC;
+    for (int s = 0; s < nsrc; ++s) nkb += src_C[s] / kc;
     const int npos = tile == 4 ? 36 : 16;
     const int uf = tile == 4 ? wino4_u_floats(NI) : wino_u_floats(NI);
-    std::vector<float> out((size_t)n_nblk * nkb * uf, 0.0f);
+    std::vector<float> out((size_t)n_nblk * nkb * uf + (tile == 4 ? uf : 0), 0.0f);
     float U[36];
     for (int nb = 0; nb < n_nblk; ++nb) {
         int kb0 = 0;
@@ -442,10 +443,10 @@ static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm
                         if (o >= C) continue;
                         if (tile == 4) wino4_weight(srcw[s][lstm ? ni : 0] + ((size_t)o * src_Cw[s] + c) * 9, U);
                         else wino_weight(srcw[s][lstm ? ni : 0] + ((size_t)o * src_Cw[s] + c) * 9, U);
-                        float* dst = &out[((size_t)nb * nkb + kb0 + c / KC) * uf];
-                        for (int pos = 0; pos < npos; ++pos) dst[((pos * KC + (c % KC)) * 16 + n) * NI + ni] = U[pos];
+                        float* dst = &out[((size_t)nb * nkb + kb0 + c / kc) * uf];
+                        for (int pos = 0; pos < npos; ++pos) dst[((pos * kc + (c % kc)) * 16 + n) * NI + ni] = U[pos];
                     }
-            kb0 += src_C[s] / KC;
+            kb0 += src_C[s] / kc;
         }
     }
     return out;
