@@ -243,7 +243,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         int po0 = 0, po1 = KC * PS, po2 = 2 * KC * PS;
         // fetch cursor of the planes (K-block pj = kb + 3, clamped to the last one): the descriptor of its source as scalars (a mutable descriptor OBJECT ends in
         // scratch memory), the byte offset of this wave's channel, the slot
-        int pj = 0, psz = 0;
+        int pj = 0, psz = 0, pbound = 0;
         unsigned pcoff = 0, plo = 0, phi = 0, phw4 = 0;
         bool pup = false;
         auto plane_source = [&](int j) __attribute__((always_inline)) {   // (re)position the cursor on K-block j: at the start and where a source begins
@@ -257,16 +257,15 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             phw4 = (unsigned)((HW + ((HWh - HW) & (int)mu)) * 4);
             pcoff = (unsigned)((j - base) * KC + pch) * phw4;
             pup = up; pj = j;
+            pbound = j < up_lo ? up_lo : (j < up_hi ? up_hi : nkb);   // where the next source begins (or the K-blocks end)
         };
         auto dma_plane = [&]() __attribute__((always_inline)) {   // this wave's plane DMA of K-block pj -> the slot at po0, then advance the cursor
             const unsigned o = (unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (0u - (unsigned)pup));
             const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)phi << 32) | plo), 0, psz, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + pch * PS + ppart * 256), 16,
                                                      (int)__builtin_elementwise_add_sat(o, pcoff), 0, 0, 0);
-            if (pj + 1 < nkb) {
-                if (pj + 1 == up_lo || pj + 1 == up_hi) plane_source(pj + 1);
-                else { ++pj; pcoff += KC * phw4; }
-            }
+            if (__builtin_expect(pj + 1 == pbound, 0)) { if (pbound < nkb) plane_source(pj + 1); }   // (at the end the cursor stays on the last K-block)
+            else { ++pj; pcoff += KC * phw4; }
         };
         plane_source(3 < nkb ? 3 : nkb - 1);   // (slot 0 = 3 % 3)
         // Row XI of B^T d of the next K-block's patch in TWO phases (half the registers in flight; the same operations in the same order as w4_row):
