@@ -243,7 +243,7 @@ def cpu_baseline(cfg, pop, wts, grid, shape, min_genomes=8, seconds_budget=20.0,
     return out, fits
 
 
-def classify_population(eng, fitness_mod, genomes, cfg, wts, shape, n_max=256, batch=8, n_cpu_control=12):
+def classify_population(eng, fitness_mod, genomes, cfg, wts, shape, n_max=256, batch=8, n_cpu_control=12, n_c_reference=4):
     """north_star's "within 1e-4 relative" as a property checked for EVERY genome of the benchmark population (untimed leg):
     the HIP path's frames / vectors / fitness against the reference's element-wise order (chainer ConvLSTM: separate
     convolution tensors added left to right, un-fused gate products, sigmoid = tanh(x/2)/2 + 1/2, plain unpool -> 9-tap)
@@ -304,6 +304,18 @@ def classify_population(eng, fitness_mod, genomes, cfg, wts, shape, n_max=256, b
         ctl["hip_vs_cpu_reference_order"] = {k: s_c[k] for k in ("genomes", "within_1e-4", "outside_1e-4", "outside_1e-4_unexplained", "byte_flip_rate", "identical_frames")}
         ctl["control_seconds"] = time.time() - t2
         summ["control_cpu"] = ctl
+    if n_c_reference:
+        # north_star's bar against the TORCH-FREE C statement of the reference's element-wise order (oracle.PredNetC, host-independent: plain loops, one
+        # fp32 fma chain per output in (channel, ky, kx) order), on the first genomes that score non-zero (the test of the same name asserts it)
+        import oracle
+        t3 = time.time()
+        nz = [i for i in range(n) if fit[i] != 0][:n_c_reference]
+        if nz:
+            s_r, _ = classify.population_report(STRUCTURE, W, H, imgs[nz], frames[nz], [vecs[i] for i in nz], np.asarray(fit)[nz], oracle.PredNetC(wts, CHANNELS, W, H, order="chainer"), batch=1)
+            summ["vs_c_reference_order"] = dict({k: s_r[k] for k in ("genomes", "within_1e-4", "outside_1e-4", "outside_1e-4_unexplained", "byte_flip_rate", "max_byte_diff",
+                                                                       "identical_frames", "max_rel", "nonzero_both")},
+                                                genome_indices=nz, seconds=time.time() - t3,
+                                                against="reference element-wise order, torch-free C statement (oracle/eig_oracle.c order=chainer), CPU")
     return summ, fit
 
 
@@ -504,12 +516,14 @@ def main():
         dist.all_gather_into_tensor(seen, ids)
         seen = seen.cpu().numpy().reshape(world, 2)
         # every rank must run the same canonical arithmetic (EIGEN_WINOGRAD selects it): gathered beside the ranks
-        mk = torch.tensor([int(os.environ.get("EIGEN_WINOGRAD") or "0x0FFFFFFE", 0)], dtype=torch.int64, device=ids.device)
+        # (the EFFECTIVE mask as the library resolved it -- EIGEN_WINO_FUSEUP=0 clears bit 24 and moves the ConvLSTMs below the top to another order: ADVICE r5)
+        from evolutionary_illusion_generator_amd import engine as engine_mod
+        mk = torch.tensor([int(engine_mod.load_library().eigen_winograd_mask()) & 0xFFFFFFFF], dtype=torch.int64, device=ids.device)
         masks = torch.empty(world, dtype=torch.int64, device=ids.device)
         dist.all_gather_into_tensor(masks, mk)
         masks = [int(x) for x in masks.cpu().numpy()]
         if len(set(masks)) != 1:
-            raise SystemExit("bench.py: the ranks run different EIGEN_WINOGRAD settings (%s): their fitness values are not comparable" % ["0x%08X" % m for m in masks])
+            raise SystemExit("bench.py: the ranks run different EIGEN_WINOGRAD / EIGEN_WINO_FUSEUP settings (%s): their fitness values are not comparable" % ["0x%08X" % m for m in masks])
         try:
             rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if backend == "nccl" else None
         except Exception:  # noqa: BLE001
@@ -544,7 +558,7 @@ def main():
             multi["n1_same_box_evals_s"] = global_pop / dt1
             multi["n1_same_box_ms_per_step"] = 1e3 * dt1
             multi["n1_same_box_fitness_equal"] = bool(np.array_equal(np.asarray(fit1), np.asarray(fit)))
-            eng = fitness.get_engine(wts, W, H, CHANNELS, max_batch=mb1)
+            eng = fitness.get_engine(wts, W, H, CHANNELS, max_batch=mb1, **({} if args.flow == "lk" else {"flow": args.flow}))
             max_batch = mb1   # (rank 0's untimed legs below run at the single-GPU device batch; config.device_batch stays the timed region's)
     stage = eng.timings()
 

@@ -96,9 +96,10 @@ struct ConvArgs {
     int H, W, B;
     int tilesX, tilesY;
     int n_nblk;
-    // conv_wino4.h: reciprocals ceil(2^32 / d) of the divisors of the block -> (N-block, image, tile) map (0 = not exact for this launch's range: divide), d = n_nblk,
-    // tilesX * tilesY, tilesX, at * n_nblk, at * b, b with b = tile_map and at = 32 / b tiles in flight per XCD
-    unsigned mg[6];
+    // conv_wino4.h: a block computes nwalk consecutive N-blocks of its tile, nparts = n_nblk / nwalk blocks per tile; mg = reciprocals ceil(2^32 / d) of the divisors
+    // of the block -> (tile, part, image) map (0 = not exact for this launch's range: divide), d = nparts, tilesX * tilesY, tilesX
+    int nwalk, nparts;
+    unsigned mg[3];
     int krows;          // packed weight rows per N-block (sum of Cpad*9)
     const float* wpk;   // [n_nblk][krows][NB]
     int Cout;           // real output channels (per gate for the LSTM)

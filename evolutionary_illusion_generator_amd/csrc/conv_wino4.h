@@ -1,5 +1,5 @@
 // conv_wino4.h -- the 3x3 convolutions of PredNet layers >= 1 (ConvLSTM over E_l / unpooled R_{l+1} / h_l, ConvA, ConvP) as Winograd F(4x4, 3x3) on the fp32
-// matrix pipe: 36 multiply-adds per channel and 4x4 output pixels where F(2x2, 3x3) (conv_wino16.h / conv_winoh.h) needs 64 and the direct form 144.
+// matrix pipe: 36 multiply-adds per channel and 4x4 output pixels where F(2x2, 3x3) (conv_wino16.h) needs 64 and the direct form 144.
 // DESIGN.md section 3.1.
 //
 // Why: at fp32 only FEWER multiply-adds make the roll-out faster, and the parity half of the question was answered BEFORE this kernel was written
@@ -18,21 +18,22 @@
 //
 // Block = 16 x 32 output pixels of one image = 32 tiles of 4x4 = two REGIONS of 16 tiles (the upper / lower 8 x 32 pixels = 2 x 8 tiles; MFMA row r = 8 ty + tx:
 // with the 40-float plane rows the sixteen 16-byte patch reads of a lane group fall on sixteen different bank slots) x NI 16-column N-tiles; TWELVE waves (three per
-// SIMD, <= 168 VGPRs), one block per CU.  The structure is conv_winoh.h's: no transformed-input buffer --
+// SIMD, <= 168 VGPRs), one block per CU.  No transformed-input buffer --
 //   wave (rg, xi), xi = 0..5, multiplies region rg for the six positions (xi, nu = 0..5): 6 NI accumulator tiles; it BUILDS its A operands itself: lane (q, col) holds
 //     channel q of the K-block for tile col, reads the three or four patch rows that row xi of B^T d needs (per row three aligned 16-byte reads out of the
 //     channel's plane: conflict-free, where 4-byte reads of the two end columns were 8-way conflicted and cost the first version 25 %), 12-18 operations for the
 //     row, 12 for the column pass;
 //   K-block = FOUR channels (one MFMA k-step): 6 NI MFMAs per wave in six chunks with the operand read of the next chunk, staging in slices between the chunks;
-//   LDS: U ring 3 x 36 KB ([36 pos][4 ch][16 cols][NI]; the packed weights are [K-blocks of 8][36][8][16][NI], the 4-channel half of a position = one contiguous
-//     KB = one LDS-DMA instruction, three per wave and K-block), plane ring 3 x 4 x [18 rows][40 floats] (one DMA instruction per wave and K-block);
+//   LDS (156 KB): plane ring 3 x 4 x [18 rows][40 floats] (one DMA instruction per wave and K-block), then U ring 3 x 36 KB ([36 pos][4 ch][16 cols][NI]; the packed
+//     weights are [N-blocks][K-blocks of 4][36][4][16][NI], a position of a K-block = one contiguous KB = one LDS-DMA instruction, three per wave and K-block), then 12 KB;
 //     U(j) is fetched during K-block j - 2 and waited for at its end, plane(j) during j - 3 and waited for at the end of j - 2 (vmcnt(1)): both are visible to
 //     everyone during K-block j - 1, whose last instructions read the first operands of j in front of the barrier -- the barrier never drains the matrix pipe;
-//   output transform: along nu in-lane (c_xi,b: 4 x NI vectors), then the six waves of a region exchange their c rows through LDS in two rounds of 96 KB
-//     (b = 0, 1 and b = 2, 3); ConvLSTM / ConvP: a lane (q, col) owns the four tiles (q >> 1, 4 (q & 1) + e), i.e. 16 CONTIGUOUS pixels of an image row per
-//     channel and output row a; wave xi < 4 finishes row a = xi of the tiles e = 0, 1, 2, waves 4 and 5 the tile e = 3 of rows 0, 1 / 2, 3 -- twelve waves share the
-//     gate math (12 / 8 LSTM cells per lane; on eight waves it was 10 us of a block), 16-byte accesses per tensor, all four gates in-lane; ConvA: wave xi < 4 finishes the row PAIR xi >> 1 for the N-tiles of parity
-//     xi & 1, so that the 2x2 pooling windows of the 4x4 tile stay in one lane.
+//   output transform: along nu in-lane (c_xi,b: 4 x NI vectors), then the six waves of a region exchange their c rows through LDS, ONE N-tile per round (48 KB = U slot 2
+//     + the 12 KB behind it), and the outputs are finished in image order (see the epilogue).
+// WALK (round 6): a block computes `nwalk` consecutive N-blocks of ITS tile (ConvArgs::nwalk, nparts = n_nblk / nwalk blocks per tile).  Everything per-lane is the same
+// for every N-block of a tile; what changes is scalar (the weight descriptor, the output channel base).  Right behind the last K-block of N-block n the waves issue the
+// prologue DMAs of N-block n + 1 (U slabs of K-blocks 0, 1 -> U slots 0, 1; planes of K-blocks 0, 1, 2) and only then run the finishing phase of n, which lives in U
+// slot 2 + 12 KB: the DMA round trip, the block dispatch and the address set-up of a fresh block are hidden behind the exchange (profiles/r06_b_w4_walk.txt).
 #pragma once
 #include "conv_wino16.h"
 
@@ -47,7 +48,8 @@ constexpr int W4_U_FLOATS = W4_NPOS * W4_UPOS;      // 36 KB
 constexpr int W4_NUS = 3, W4_NPS = 3;
 constexpr int W4_ROW = 40;                          // floats per plane row: aligned chunks x0-4 .. x0+35
 constexpr int W4_PS = 768;                          // floats per channel plane: 18 rows x 40 = 720 -> three DMA instructions of 256
-constexpr int wino4_lds_bytes() { return (W4_NUS * W4_U_FLOATS + W4_NPS * W4_KC * W4_PS) * 4; }   // 147456 (one exchange round: 12 waves x 8 KB = 98304)
+constexpr int W4_X_FLOATS = W4_WAVES * 4 * 64 * 4;   // one exchange round = one N-tile: [12 waves][4 e][64 lanes] 16-byte vectors = 48 KB = U slot 2 + 12 KB
+constexpr int wino4_lds_bytes() { return (W4_NPS * W4_KC * W4_PS + 2 * W4_U_FLOATS + W4_X_FLOATS) * 4; }   // 159744: planes 36 KB, U slots 0 / 1 72 KB, U slot 2 + 12 KB = exchange
 constexpr int wino4_u_floats(int NI) { return W4_NPOS * 4 * 16 * NI; }   // one 4-channel K-block of the packed weights: [36 pos][4 ch][16 cols][NI] (the buffer ends in one K-block of padding: the fetch runs one K-block past the end)
 #ifndef EIG_W4_DIAG
 #define EIG_W4_DIAG 0   // measurement builds only (WRONG RESULTS): 1 no wait for the K loop's DMAs, 2 no barrier in the K loop, 4 no A-operand build, 8 no plane DMA, 16 no U DMA
@@ -94,41 +96,32 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
     static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
     constexpr int U4 = wino4_u_floats(NI);
-    constexpr int NUS = W4_NUS, NPS = W4_NPS, KC = W4_KC, PS = W4_PS;
+    constexpr int NPS = W4_NPS, KC = W4_KC, PS = W4_PS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py with EIG_TL_WAVES=12)
-    float* const Ub = lds;
-    float* const Pb = lds + NUS * W4_U_FLOATS;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py with EIG_TL_WAVES=12)
+    float* const Pb = lds;                          // plane ring
+    float* const Ub = lds + NPS * KC * PS;          // U ring; slot 2 and the 12 KB behind it are the exchange area of the finishing phase
+    float* const xb = Ub + 2 * W4_U_FLOATS;
+    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rg = wv & 1, xi = wv >> 1;
-    const int q = lane >> 4, col = lane & 15;
+    // The lane index, opaque to the compiler: every per-lane quantity of the K loop and of the finishing phase is derived from a FRESH copy at the point of use, so
+    // that nothing per-lane is hoisted out of the walk and carried in registers (or scratch) across the phase that does not need it -- the walking kernel of round 5
+    // spilled 42 registers that way, the first version of this one 9.
+    auto lane_id = [&]() __attribute__((always_inline)) { int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(l)); return l; };
 
     const int tiles = a.tilesX * a.tilesY;
     const int ntile = a.B * tiles;
     const int xcd = blockIdx.x & 7, xi_ = blockIdx.x >> 3;
-    // (divisions by launch constants through their host-side reciprocals, ConvArgs::mg: a run-time integer division is ~25 dependent scalar instructions, and the ten of
-    // them here were most of the 1.4 - 1.8 us a block spent before its first fetch: profiles/r05_f_w4_timeline.txt)
+    // (divisions by launch constants through their host-side reciprocals, ConvArgs::mg: a run-time integer division is ~25 dependent scalar instructions:
+    // profiles/r05_f_w4_timeline.txt)
     auto dv = [&](int x, int d, unsigned m) __attribute__((always_inline)) { return m ? (int)__umulhi((unsigned)x, m) : x / d; };
-    const int q0 = dv(xi_, a.n_nblk, a.mg[0]);
-    int nblk = xi_ - q0 * a.n_nblk;
-    int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + q0 : q0 * 8 + xcd;
-    if (a.tile_map >= 2 && a.mg[5]) {   // (mg[5] != 0: tile_map divides n_nblk, set by the host)
-        // b = tile_map N-blocks x a = 32 / b tiles in flight on an XCD's 32 CUs instead of all n_nblk N-blocks of 32 / n_nblk tiles: the a blocks of an N-block stream ONE
-        // U slab through the L2 in step, the b blocks of a tile ONE set of planes.  Measured at the headline shape (profiles/r05_e_tile_map.txt): b = 2 380.5 -> 385.7
-        // evals/s (layers 2, 3: 6 / 12 N-blocks), b = 3, 4, 6: +0.5 %, b = 1 (planes re-read per N-block): +0.2 %; the window a (32 .. 128 tiles) does not matter
-        const int b = a.tile_map, at = b == 2 ? 16 : 32 / b;
-        const int tx = (ntile + 7) >> 3;                   // tiles of this XCD
-        const int chunk = dv(xi_, at * a.n_nblk, a.mg[3]), base = chunk * at;
-        const int ae = min(at, tx - base);
-        const int r = xi_ - chunk * at * a.n_nblk;
-        const int g = ae == at ? dv(r, at * b, a.mg[4]) : r / (ae * b), r2 = r - g * ae * b;
-        const int r2b = dv(r2, b, a.mg[5]);
-        nblk = g * b + (r2 - r2b * b);
-        tlin = xcd * tx + base + r2b;
-    }
+    // Block -> (tile, part): workgroup b runs on XCD b % 8; an XCD owns a contiguous range of tiles (tile_map = 0: tiles interleaved over the XCDs, A/B only) and the
+    // nparts blocks of a tile are consecutive on it, so they stream ONE set of planes through that XCD's L2 while the 32 / nparts tiles in flight per N-block share its U slab.
+    const int q0 = dv(xi_, a.nparts, a.mg[0]);
+    const int part = xi_ - q0 * a.nparts;
+    const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + q0 : q0 * 8 + xcd;
     if (tlin >= ntile) return;
+    const int nwalk = a.nwalk, nb0 = part * nwalk;   // this block computes N-blocks nb0 .. nb0 + nwalk - 1 of its tile
     const int eb = dv(tlin, tiles, a.mg[1]);
     const int t_ = tlin - eb * tiles;
     const int tyi = dv(t_, a.tilesX, a.mg[2]), txi = t_ - tyi * a.tilesX;
@@ -143,8 +136,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int up_lo = nkb0, up_hi = nkb0 + nkbu;
 #define EIG4_WAITCNT(imm) do { __builtin_amdgcn_s_waitcnt(imm); asm volatile("" ::: "memory"); } while (0)
 #define EIG4_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
+#define EIG4_LDS_BARRIER() do { EIG4_WAITCNT(0xC07F); EIG4_BARRIER(); } while (0)   /* lgkmcnt(0) only: global loads / LDS-DMAs in flight are NOT waited for (__syncthreads would) */
 #define EIG4_IS_UP(kb) ((kb) >= up_lo && (kb) < up_hi)
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
 
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // ---- plane fetch (every wave: channel wv / 3 of the K-block, part wv % 3 of its plane): lane = 16-byte chunk of the 18 x 10-chunk haloed plane (unpooled source:
@@ -156,6 +149,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
     const int pch = wv / 3, ppart = wv - pch * 3;
+    constexpr unsigned W4_POSB = 4 * 16 * NI * 4;   // bytes per position of a packed K-block
+    for (int it = 0; it < nwalk; ++it) {
+    const int nblk = nb0 + it;
+    const int lane = lane_id();
+    const int q = lane >> 4, col = lane & 15;
     int roff, uoff;
     {
         const int c = lane + 64 * ppart;
@@ -184,8 +182,36 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     // The scalar offset runs along the packed K-blocks (no index arithmetic in the K loop; the last two fetches read the next N-block's first K-blocks or the
     // buffer's padding into slots nobody reads).
     const int uvo = (NI == 4 || lane < 48) ? lane * 16 : -1;
-    constexpr unsigned W4_POSB = 4 * 16 * NI * 4;   // bytes per position
-    unsigned u_so = (unsigned)(3 * wv) * W4_POSB;
+    // The prologue of N-block nb: the U slabs of K-blocks 0, 1 -> U slots 0, 1 and the planes of K-blocks 0, 1, 2 -> plane slots 0, 1, 2.  Issued at the start of a block,
+    // and -- WALK -- for N-block nb + 1 right behind the last K-block of nb, ahead of nb's finishing phase (which only touches U slot 2 and the 12 KB behind it).
+    auto prologue_dmas = [&](int nb) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nb * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + (3 * wv + i) * W4_UPOS), 16, uvo, (int)((unsigned)(3 * wv + i) * W4_POSB), 0, 0);
+        dma_plane_at(0, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + W4_U_FLOATS + (3 * wv + i) * W4_UPOS), 16, uvo,
+                                                     (int)((unsigned)U4 * 4 + (unsigned)(3 * wv + i) * W4_POSB), 0, 0);
+        dma_plane_at(1, 1);
+        dma_plane_at(2, 2);
+    };
+
+    // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) = (col >> 3, col & 7) of region rg (rows 8 rg .. 8 rg + 7 of the block; MFMA row r = 8 ty + tx)
+    const int t_ty = col >> 3, t_tx = col & 7;
+    const float* const pbase_n = Pb + q * PS + (8 * rg + 4 * t_ty) * W4_ROW + 4 * t_tx;        // patch row 0, the aligned chunk that holds patch column 0 in its last float: columns 0 .. 5 = floats 3 .. 8
+    const float* const pbase_u = Pb + q * PS + (4 * rg + 2 * t_ty) * W4_ROW + 2 * t_tx + 3;    // source row s, column s of an unpooled patch (half-resolution plane)
+    const int b_off = xi * 6 * W4_UPOS + (q * 16 + col) * NI;   // U[pos = 6 xi + nu][ch = q][col][0 .. NI)
+
+    unsigned long long tq_setup = tq_entry;
+    if (it == 0) {
+        if (EIG_TIMING) tq_setup = __builtin_readcyclecounter();
+        prologue_dmas(nb0);
+        EIG4_WAITCNT(0x0F71);   // all but the plane of K-block 2
+    }
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
+    unsigned u_so = (unsigned)(3 * wv) * W4_POSB + 2u * (unsigned)U4 * 4u;   // (K-blocks 0, 1 came with the prologue)
     auto dma_u = [&](int slot_off) __attribute__((always_inline)) {   // -> the U slot at float offset slot_off
 #pragma unroll
         for (int i = 0; i < 3; ++i)
@@ -193,40 +219,27 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                                                      (int)(u_so + (unsigned)i * W4_POSB), 0, 0);
         u_so += (unsigned)U4 * 4;
     };
-
-    // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) = (col >> 3, col & 7) of region rg (rows 8 rg .. 8 rg + 7 of the block; MFMA row r = 8 ty + tx)
-    const int t_ty = col >> 3, t_tx = col & 7;
-    const float* const pbase_n = Pb + q * PS + (8 * rg + 4 * t_ty) * W4_ROW + 4 * t_tx;        // patch row 0, the aligned chunk that holds patch column 0 in its last float: columns 0 .. 5 = floats 3 .. 8
-    const float* const pbase_u = Pb + q * PS + (4 * rg + 2 * t_ty) * W4_ROW + 2 * t_tx + 3;    // source row s, column s of an unpooled patch (half-resolution plane)
-
     // accumulators: position (xi, nu), N-tile ni
     f32x4 acc[6][NI];
 #pragma unroll
     for (int p = 0; p < 6; ++p)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int b_off = xi * 6 * W4_UPOS + (q * 16 + col) * NI;   // U[pos = 6 xi + nu][ch = q][col][0 .. NI)
-
-    // ---- prologue: the U slabs of K-blocks 0, 1 and the planes of K-blocks 0, 1, 2
-    const unsigned long long tq_setup = EIG_TIMING ? __builtin_readcyclecounter() : 0;
-    dma_u(0);
-    dma_plane_at(0, 0);
-    dma_u(W4_U_FLOATS);
-    dma_plane_at(1, 1);
-    dma_plane_at(2, 2);
-    EIG4_WAITCNT(0x0F71);   // all but the plane of K-block 2
+    // (a fresh block waited for its prologue above; a walking block's waves each waited for theirs -- vmcnt(0) -- in front of the previous finishing phase's gate loads)
     EIG4_BARRIER();
     const unsigned long long tq_k0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     unsigned long long tq_k1 = 0, tq_x = 0, tq_y = 0;
-    // [entry, set-up done, K loop start, K loop end, first exchange barrier passed, y ready (gates start), exit, HW_ID | XCC_ID << 32]
+    // [entry, set-up done, K loop start, K loop end, first exchange barrier passed, y ready (gates start), exit, HW_ID | XCC_ID << 32] per (block, N-block of the walk, wave)
     auto timeline = [&]() __attribute__((always_inline)) {
-        if (EIG_TIMING && a.dbg && lane == 0) {
+        if (EIG_TIMING && a.dbg && lane_id() == 0) {
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* dd = a.dbg + ((size_t)blockIdx.x * W4_WAVES + wv) * 8;
-            dd[0] = tq_entry; dd[1] = tq_setup; dd[2] = tq_k0; dd[3] = tq_k1; dd[4] = tq_x; dd[5] = tq_y; dd[6] = __builtin_readcyclecounter();
+            unsigned long long* dd = a.dbg + (((size_t)blockIdx.x * nwalk + it) * W4_WAVES + wv) * 8;
+            const unsigned long long tq_end = __builtin_readcyclecounter();
+            dd[0] = tq_entry; dd[1] = tq_setup; dd[2] = tq_k0; dd[3] = tq_k1; dd[4] = tq_x; dd[5] = tq_y; dd[6] = tq_end;
             dd[7] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
+            tq_entry = tq_end;
         }
     };
 
@@ -336,8 +349,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         };
         // One K-block.  kind_tag: 0 full, 1 unpooled source, 2 run time; nk_tag: kind of K-block kb + 1 (whose patch rows are read now), same codes; last_tag: the last
         // K-block (nothing to stage).  On entry v and bq hold the A operands and the first B operand of this K-block: the first instruction behind the barrier is an MFMA,
-        // and the staging work sits in slices BETWEEN the chunks -- patch rows of K-block kb + 1 behind chunk 0, the U fetch behind chunk 1, the plane fetch behind
-        // chunk 2, the A operands of kb + 1 behind the last chunks (see slice below).
+        // and the staging work sits in slices BETWEEN the chunks -- the U fetch behind chunk 0, the plane fetch behind chunk 1, the patch rows of K-block kb + 1 and
+        // the A operands of kb + 1 behind the last chunks (see slice below).
         auto kiter = [&](const int kb, auto kind_tag, auto nk_tag, auto last_tag) __attribute__((always_inline)) {
             constexpr int KIND = decltype(kind_tag)::value;
             constexpr int NK = decltype(nk_tag)::value;
@@ -384,7 +397,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             { const int t0 = po0; po0 = po1; po1 = po2; po2 = t0; }
             // the U fetch of this K-block has landed (its plane fetch may stay in flight: it is read two K-blocks from now); after the last K-block: everything
             if (LAST || (EIG_W4_DIAG & (8 | 16))) EIG4_WAITCNT(0x0F70);
-            else if (!(EIG_W4_DIAG & 1)) EIG4_WAITCNT(0x0F71);
+            else if (!(EIG_W4_DIAG & 2)) { if (!(EIG_W4_DIAG & 1)) EIG4_WAITCNT(0x0F71); }
             if (!(EIG_W4_DIAG & 2) || LAST) EIG4_BARRIER();
         };
         const std::false_type nl{};
@@ -414,6 +427,10 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         default: kloops(std::integral_constant<int, 5>{}); break;
     }
     if (EIG_TIMING) tq_k1 = __builtin_readcyclecounter();
+    // WALK: every wave is past the last barrier of the K loop, every DMA of this N-block has landed -- the next N-block's prologue goes out now and lands behind the
+    // finishing phase below (U slots 0, 1 and the plane ring; the exchange lives in U slot 2 + 12 KB)
+    const bool more = it + 1 < nwalk;
+    if (more) prologue_dmas(nblk + 1);
 
     // ---- output transform.  Along nu in-lane: c_xi,b (b = 0..3) of every N-tile.
     f32x4 cc[4][NI];
@@ -424,32 +441,41 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) cc[b][ni] = Y[b];
     }
-    // Along xi: the six waves of a region publish their c rows in two rounds (N-tiles 0, 1 then 2, 3: [12 waves][2 N-tiles][4 e][64 lanes] 16-byte vectors over b = 96 KB
-    // each; U / planes are dead -- every wave is past the last barrier, every DMA has landed); the finishing lanes read what their output rows need:
-    // y0 = (c0 + s) + u, y1 = fma(2, w, d), y2 = fma(4, u, s), y3 = fma(8, w, d) + c5 with s = c1 + c2, d = c1 - c2, u = c3 + c4, w = c3 - c4.
-    float* const xb = lds;
+    // Along xi: the six waves of a region publish their c rows, ONE N-tile per round ([12 waves][4 e][64 lanes] 16-byte vectors over b = 48 KB); the finishing lanes
+    // read what their output rows need: y0 = (c0 + s) + u, y1 = fma(2, w, d), y2 = fma(4, u, s), y3 = fma(8, w, d) + c5 with s = c1 + c2, d = c1 - c2, u = c3 + c4, w = c3 - c4.
+    // (per-lane quantities from a fresh lane_id(): see the top of the kernel)
+    const int ln = lane_id();
+    const int fq = ln >> 4, fcol = ln & 15;
     const size_t cHW = (size_t)HW;
-    const int j = lane & 7, chl = lane >> 3, e_r = j & 3, ql = j >> 2;   // finishing lane: chunk j of the block row, channel 8 chh + chl (see below)
-    int woff[4];                                                           // publishing lane (q, col): its slot in plane e
+    const int j = ln & 7, chl = ln >> 3, e_r = j & 3, ql = j >> 2;   // finishing lane: chunk j of the block row, channel 8 chh + chl (see below)
+    int woff[4];                                                       // publishing lane (q, col): its slot in plane e
 #pragma unroll
-    for (int e = 0; e < 4; ++e) woff[e] = ((wv * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + 8 * (q & 1)) & 15)) * 4;
+    for (int e = 0; e < 4; ++e) woff[e] = ((wv * 4 + e) * 64 + fq * 16 + ((fcol + 4 * e + 8 * (fq & 1)) & 15)) * 4;
+    auto publish = [&](int ni) __attribute__((always_inline)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            f32x4 t;
+            t[0] = cc[0][ni][e]; t[1] = cc[1][ni][e]; t[2] = cc[2][ni][e]; t[3] = cc[3][ni][e];
+            *reinterpret_cast<f32x4*>(xb + woff[e]) = t;
+        }
+    };
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
         // All twelve waves finish outputs, and they finish them in IMAGE order: the exchange is laid out so that a finishing lane reads the four pixels b = 0..3 of ONE tile
         // as a 16-byte vector, and finishing lane L takes the 16-byte chunk j = L & 7 of a 32-pixel block row (tile tx = j, writer lane q = 2 ty + (j >> 2), register e =
         // j & 3) of channel 8 chh + (L >> 3): the eight lanes j = 0..7 of a channel read / write ONE 128-byte line of c, the peepholes, h or P (lane = (tile group, channel)
         // as the accumulators lie touched 64 lines per instruction, and the 7-9 us that cost per block were half of the time between two K loops:
         // profiles/r05_f_w4_timeline.txt).  Units of 64 chunks: wave xi < 4 takes output row a = xi of (tile row ty, channel half chh) = (0,0), (0,1), (1,0); waves 4 / 5
-        // take (1,1) of rows 0, 1 / 2, 3 -- 12 or 8 cells per lane.  Rounds: N-tiles (gates) 0, 1 then 2, 3: [12 waves][2][4 e][64 lanes] 16-byte vectors = 96 KB each; the
-        // slot of writer lane (q, col) in plane e is q 16 + ((col + 4 e + 8 (q & 1)) & 15), which spreads every 16-lane service group of the b128 reads over all 16 slots.
+        // take (1,1) of rows 0, 1 / 2, 3 -- 12 or 8 cells per lane.  The slot of writer lane (q, col) in plane e is q 16 + ((col + 4 e + 8 (q & 1)) & 15), which spreads
+        // every 16-lane service group of the b128 reads over all 16 slots.
         const int nun = xi < 4 ? 3 : 2;
-        int roff[3];
+        int xoff[3];
 #pragma unroll
         for (int un = 0; un < 3; ++un) {
             const int ty = xi < 4 ? (un >> 1) : 1, chh = xi < 4 ? (un & 1) : 1;
-            roff[un] = (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
+            xoff[un] = rg * 1024 + (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
         }
-        auto finish = [&](int arow, int nr, int off) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3
-            auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + ((x * 2 + rg) * 2 + nr) * 1024 + off); };
+        auto finish = [&](int arow, int off) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3
+            auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + x * 2048 + off); };
             const f32x4 c1 = C(1), c2 = C(2), c3 = C(3), c4 = C(4);
             const f32x4 s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
             f32x4 y;
@@ -461,40 +487,27 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         };
         f32x4 ys[NI][3];   // [N-tile][unit]: the four pixels of the lane's chunk
 #pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            if (2 * rnd >= NI) break;
-            if (rnd) __syncthreads();   // (everyone has read round 0)
+        for (int ni = 0; ni < NI; ++ni) {
+            if (ni) EIG4_LDS_BARRIER();   // (everyone has read the previous round)
+            publish(ni);
+            EIG4_LDS_BARRIER();
+            if (EIG_TIMING && ni == 0) tq_x = __builtin_readcyclecounter();
 #pragma unroll
-            for (int nr = 0; nr < 2; ++nr) {
-                const int ni = 2 * rnd + nr;
-                if (ni >= NI) break;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f32x4 t;
-                    t[0] = cc[0][ni][e]; t[1] = cc[1][ni][e]; t[2] = cc[2][ni][e]; t[3] = cc[3][ni][e];
-                    *reinterpret_cast<f32x4*>(xb + woff[e] + nr * 1024) = t;
-                }
-            }
-            __syncthreads();
-            if (EIG_TIMING && rnd == 0) tq_x = __builtin_readcyclecounter();
-#pragma unroll
-            for (int nr = 0; nr < 2; ++nr) {
-                const int ni = 2 * rnd + nr;
-                if (ni >= NI) break;
-#pragma unroll
-                for (int un = 0; un < 3; ++un) {
-                    if (un >= nun) break;
-                    switch (xi) {
-                        case 0: ys[ni][un] = finish(0, nr, roff[un]); break;
-                        case 1: ys[ni][un] = finish(1, nr, roff[un]); break;
-                        case 2: ys[ni][un] = finish(2, nr, roff[un]); break;
-                        case 3: ys[ni][un] = finish(3, nr, roff[un]); break;
-                        case 4: ys[ni][un] = un ? finish(1, nr, roff[un]) : finish(0, nr, roff[un]); break;
-                        default: ys[ni][un] = un ? finish(3, nr, roff[un]) : finish(2, nr, roff[un]); break;
-                    }
+            for (int un = 0; un < 3; ++un) {
+                if (un >= nun) break;
+                switch (xi) {
+                    case 0: ys[ni][un] = finish(0, xoff[un]); break;
+                    case 1: ys[ni][un] = finish(1, xoff[un]); break;
+                    case 2: ys[ni][un] = finish(2, xoff[un]); break;
+                    case 3: ys[ni][un] = finish(3, xoff[un]); break;
+                    case 4: ys[ni][un] = un ? finish(1, xoff[un]) : finish(0, xoff[un]); break;
+                    default: ys[ni][un] = un ? finish(3, xoff[un]) : finish(2, xoff[un]); break;
                 }
             }
         }
+        // WALK: this wave's share of the next N-block's prologue has landed (issued ~3 us ago) -- waited for HERE, ahead of the gate loads and the stores, so that
+        // the barrier at the top of the next K loop needs no vmcnt wait of its own (which would wait for the stores below as well)
+        if (more) EIG4_WAITCNT(0x0F70);
         if (EIG_TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq_y = __builtin_readcyclecounter(); }
 #pragma unroll
         for (int un = 0; un < 3; ++un) {
@@ -535,41 +548,33 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                 }
             }
         }
-        timeline();
     } else {
         // ConvA, in image order as well: a finishing lane takes the chunk j of the output-row PAIR ap (rows 2 ap, 2 ap + 1) of tile row ty for one channel -- the two 2x2
         // pooling windows of its four pixels -- i.e. two pooled pixels (8 bytes); the eight lanes of a channel cover 16 pooled pixels = 64 contiguous bytes of P and of both
-        // halves of E.  Units of 64 such lanes per round (N-tiles 2 rnd, 2 rnd + 1): g = (nr, ty, ap, chh), 16 of them (8 when the round holds one N-tile) over the six waves
-        // of the region as 3,3,3,3,2,2 (2,2,1,1,1,1).  (Before: lane = (tile group, channel), 8-byte accesses to 64 different lines per instruction, and only xi < 4 worked.)
+        // halves of E.  Units of 64 such lanes per round (= N-tile): g = (ty, ap, chh), eight of them over the six waves of the region: wave xi takes unit xi, and units 6, 7
+        // go to the waves 2 rnd % 6, 2 rnd % 6 + 1 (rotating: over three rounds every wave finishes four units).
         const int Ho = a.H >> 1, Wo = a.W >> 1;
         const size_t plane = (size_t)Ho * Wo;
         const int ox = (x0 >> 1) + 2 * j;
 #pragma unroll
-        for (int rnd = 0; rnd < 2; ++rnd) {
-            if (2 * rnd >= NI) break;
-            const int nval = NI - 2 * rnd >= 2 ? 2 : 1;
-            if (rnd) __syncthreads();
+        for (int rnd = 0; rnd < NI; ++rnd) {
+            if (rnd) EIG4_LDS_BARRIER();
+            publish(rnd);
+            EIG4_LDS_BARRIER();
+            if (EIG_TIMING && rnd == 0) tq_x = __builtin_readcyclecounter();
+            if (rnd == NI - 1) { if (more) EIG4_WAITCNT(0x0F70); }   // (see the ConvLSTM / ConvP branch)
+            const int ex0 = (2 * rnd) % 6;
 #pragma unroll
-            for (int nr = 0; nr < 2; ++nr) {
-                if (nr >= nval) break;
-                const int ni = 2 * rnd + nr;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    f32x4 t;
-                    t[0] = cc[0][ni][e]; t[1] = cc[1][ni][e]; t[2] = cc[2][ni][e]; t[3] = cc[3][ni][e];
-                    *reinterpret_cast<f32x4*>(xb + woff[e] + nr * 1024) = t;
+            for (int un = 0; un < 2; ++un) {
+                int g = xi;
+                if (un == 1) {
+                    if (xi == ex0) g = 6;
+                    else if (xi == ex0 + 1) g = 7;
+                    else break;
                 }
-            }
-            __syncthreads();
-            const int g0 = nval == 2 ? (xi < 4 ? 3 * xi : 12 + 2 * (xi - 4)) : (xi < 2 ? 2 * xi : xi + 2);
-            const int cnt = nval == 2 ? (xi < 4 ? 3 : 2) : (xi < 2 ? 2 : 1);
-#pragma unroll
-            for (int un = 0; un < 3; ++un) {
-                if (un >= cnt) break;
-                const int g = g0 + un;
-                const int nr = g >> 3, ty = (g >> 2) & 1, ap = (g >> 1) & 1, chh = g & 1;
-                const int off = ((nr + 2 * rg) * 256 + e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
-                auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + x * 4096 + off); };
+                const int ty = (g >> 2) & 1, ap = (g >> 1) & 1, chh = g & 1;
+                const int off = rg * 1024 + (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
+                auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + x * 2048 + off); };
                 const f32x4 c1 = C(1), c2 = C(2), c3 = C(3), c4 = C(4);
                 const f32x4 s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
                 f32x4 ya, yb;   // output rows 2 ap, 2 ap + 1
@@ -581,7 +586,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                     const f32x4 c5 = C(5);
                     for (int b = 0; b < 4; ++b) { ya[b] = fmaf(4.0f, u_[b], s_[b]); yb[b] = fmaf(8.0f, w_[b], d_[b]) + c5[b]; }
                 }
-                const int ch = (nblk * NI + 2 * rnd + nr) * 16 + 8 * chh + chl;
+                const int ch = (nblk * NI + rnd) * 16 + 8 * chh + chl;
                 const int oy = (y0 >> 1) + 4 * rg + 2 * ty + ap;
                 if (oy >= Ho || ox >= Wo || ch >= a.Cout) continue;
                 const float bb_ = a.bias[ch];
@@ -602,8 +607,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             }
         }
     }
+    timeline();
+    }   // walk
 #undef EIG4_WAITCNT
 #undef EIG4_BARRIER
+#undef EIG4_LDS_BARRIER
 #undef EIG4_IS_UP
 }
 

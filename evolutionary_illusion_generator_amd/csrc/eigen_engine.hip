@@ -380,6 +380,16 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
 #ifndef EIGEN_WINO_DEFAULT
 #define EIGEN_WINO_DEFAULT 0x0FFFFFFE   // every eligible operator in Winograd form, the unpooled source inside the ConvLSTM chains (bit 24), F(4x4, 3x3) tiles (bits 25-27)
 #endif
+// the effective mask of this process: EIGEN_WINOGRAD (default EIGEN_WINO_DEFAULT), bit 24 cleared by EIGEN_WINO_FUSEUP=0 (eigen_winograd_mask; oracle.wino_mask_default)
+static int wino_mask_env()
+{
+    static const int mask = [] {
+        int m = getenv("EIGEN_WINOGRAD") && *getenv("EIGEN_WINOGRAD") ? (int)strtol(getenv("EIGEN_WINOGRAD"), nullptr, 0) : EIGEN_WINO_DEFAULT;
+        if (getenv("EIGEN_WINO_FUSEUP") && !atoi(getenv("EIGEN_WINO_FUSEUP"))) m &= ~(1 << 24);
+        return m;
+    }();
+    return mask;
+}
 static bool wino_op(int mask, int kind, int l, int Cin, int Cout, int H, int W, bool top)
 {
     if (!((mask >> (8 * kind + l)) & 1) || l < 1) return false;
@@ -534,9 +544,9 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     }
 #endif
     {
-        // 0 only for A/B measurements; F(4x4) kernel: value = N-blocks of a tile in flight on an XCD (conv_wino4.h; 2 measured best: profiles/r05_e_tile_map.txt)
-        static const int tile_map = getenv("EIGEN_TILE_MAP") ? atoi(getenv("EIGEN_TILE_MAP")) : -1;
-        a.tile_map = tile_map >= 0 ? tile_map : (op.wino_tile == 4 ? 2 : 1);
+        // 0 only for A/B measurements: tiles interleaved over the XCDs instead of a contiguous tile range per XCD
+        static const int tile_map = getenv("EIGEN_TILE_MAP") ? atoi(getenv("EIGEN_TILE_MAP")) : 1;
+        a.tile_map = tile_map != 0;
     }
     // Eight-wave instantiations (conv_mfma.h: W8).  Measured (profiles/r03_b_ab_w8.txt): where a launch fills the chip many times
     // over they change nothing (256 genomes at 256^2: every operator within +-0.5 %), where it does not they gain 4-5 % (160x120,
@@ -573,16 +583,33 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             if (op.epi == EPI_LSTM && a.acc_init != nullptr) return hipErrorInvalidConfiguration;   // (set_weights never pairs F(4x4) with a separate unpooled chain)
             auto go4 = [&](auto kern) {
                 a.tilesX = (op.W + 31) / 32; a.tilesY = (op.H + 15) / 16;
-                const int g4 = op.n_nblk * ((batch * a.tilesX * a.tilesY + 7) / 8) * 8;
+                const int ntile4 = batch * a.tilesX * a.tilesY;
+                // WALK (conv_wino4.h): nparts blocks per tile, each computing nwalk = n_nblk / nparts consecutive N-blocks of it.  Two blocks per tile where n_nblk is even
+                // (they share the tile's planes through the XCD's L2, as two N-blocks in flight per tile did in round 5: profiles/r05_e_tile_map.txt), one otherwise; more
+                // parts while the launch would not give every CU four blocks.  A property of the launch only -- the bits do not depend on it.  EIGEN_W4_PARTS = n forces
+                // min(n, n_nblk) rounded down to a divisor (n >= n_nblk: one N-block per block, no walk), for A/B measurements and the parity tests.
+                static const int parts_env = getenv("EIGEN_W4_PARTS") ? atoi(getenv("EIGEN_W4_PARTS")) : 0;
+                int nparts = (op.n_nblk % 2 == 0) ? 2 : 1;
+                if (parts_env > 0) nparts = std::min(parts_env, op.n_nblk);
+                else while (nparts < op.n_nblk && (long long)nparts * ntile4 < 4ll * e->n_cu) ++nparts;
+                while (op.n_nblk % nparts) parts_env > 0 ? --nparts : ++nparts;
+                a.nparts = nparts; a.nwalk = op.n_nblk / nparts;
+                const int g4 = nparts * ((ntile4 + 7) / 8) * 8;
                 {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
                     auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };
-                    const int b = a.tile_map >= 2 && op.n_nblk % a.tile_map == 0 ? a.tile_map : 0, at = b ? 32 / b : 0;
-                    a.mg[0] = magic(op.n_nblk); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
-                    a.mg[3] = b ? magic((long long)at * op.n_nblk) : 0u; a.mg[4] = b ? magic((long long)at * b) : 0u; a.mg[5] = b ? magic(b) : 0u;
+                    a.mg[0] = magic(nparts); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
                 }
                 static std::unordered_set<const void*> attr_done;   // (the handle is not thread-safe anyway: one rank, one host thread)
                 if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, wino4_lds_bytes());
-                op.last_grid = g4; op.last_waves = W4_WAVES;
+                op.last_grid = g4 * a.nwalk; op.last_waves = W4_WAVES;   // (timeline records: one per block and N-block of its walk)
+#if EIG_TIMING
+                if (tl_dbg) {   // sized from THIS launch's records (the buffer above was sized for the four-wave grid)
+                    (void)hipFree(tl_dbg);
+                    (void)hipMalloc((void**)&tl_dbg, (size_t)op.last_grid * W4_WAVES * 64);
+                    (void)hipMemset(tl_dbg, 0, (size_t)op.last_grid * W4_WAVES * 64);
+                    a.dbg = tl_dbg;
+                }
+#endif
                 hipLaunchKernelGGL(kern, dim3(g4), dim3(W4_THREADS), wino4_lds_bytes(), st, a);
             };
             if (op.epi == EPI_LSTM) go4(wino4_kernel<4, EPI_LSTM>);
@@ -688,6 +715,7 @@ extern "C" {
 
 int eigen_abi_version(void) { return EIGEN_ABI_VERSION; }
 int eigen_gate_order(void) { return EIG_GATE_ORDER; }
+int eigen_winograd_mask(void) { return wino_mask_env(); }
 const char* eigen_last_error(void) { return g_err.c_str(); }
 
 void eigen_config_defaults(eigen_config* c)
@@ -816,7 +844,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
     for (int l = 0; l < L; ++l) expect += (l > 0 ? 2 : 0) + 2 + 4 * (l < L - 1 ? 4 : 3) + 3;
     if (n_tensors != expect) return fail(EIGEN_ERR_INVALID, "expected %d weight tensors for %d layers, got %d", expect, L, n_tensors);
     int k = 0;
-    static const int wino_env = getenv("EIGEN_WINOGRAD") && *getenv("EIGEN_WINOGRAD") ? (int)strtol(getenv("EIGEN_WINOGRAD"), nullptr, 0) : EIGEN_WINO_DEFAULT;
+    const int wino_env = wino_mask_env();
     auto upload = [&](float** dst, const float* src, size_t n) -> int {
         if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
         if (hipMalloc((void**)dst, n * sizeof(float)) != hipSuccess) return -1;
@@ -928,7 +956,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             if (wino) {
                 // the unpooled source R_{l+1} inside the same chains, between E_l and h_l (conv_wino.h: up_fused; oracle/eig_oracle.c: eig_wino_fuse_up):
                 // bit 24 of the switch (EIGEN_WINO_FUSEUP=0 clears it), 16-byte rows at the source resolution, 8-channel K-blocks
-                static const bool fuse_bit = ((wino_env >> 24) & 1) && !(getenv("EIGEN_WINO_FUSEUP") && !atoi(getenv("EIGEN_WINO_FUSEUP")));
+                const bool fuse_bit = (wino_env >> 24) & 1;
                 wino_fuse = fuse_bit && l < L - 1 && (y.W % 8) == 0 && (e->layer[l + 1].C % 8) == 0;
                 const int Cu = wino_fuse ? e->layer[l + 1].C : 0;
                 const float* w3[3][4];

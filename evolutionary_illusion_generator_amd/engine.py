@@ -11,12 +11,12 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EIGEN_HIP_LIB") or os.path.join(_HERE, "libeigen_hip.so")  # EIGEN_HIP_LIB: A/B builds (scripts/)
-ABI_VERSION = 3  # include/eigen_engine.h: EIGEN_ABI_VERSION
+ABI_VERSION = 4  # include/eigen_engine.h: EIGEN_ABI_VERSION
 MAX_LAYERS = 8
 
 PAIR_POPULATION, PAIR_SINGLE = 0, 1
 
-EXPORTS = ["eigen_abi_version", "eigen_gate_order", "eigen_last_error", "eigen_config_defaults", "eigen_create", "eigen_destroy",
+EXPORTS = ["eigen_abi_version", "eigen_gate_order", "eigen_winograd_mask", "eigen_last_error", "eigen_config_defaults", "eigen_create", "eigen_destroy",
            "eigen_set_prednet_weights", "eigen_set_grid", "eigen_render_cppn", "eigen_eval_cppn_nodes", "eigen_prednet_rollout", "eigen_flow",
            "eigen_score", "eigen_eval_population", "eigen_eval_images", "eigen_test_conv", "eigen_time_conv", "eigen_test_det_math",
            "eigen_get_timings", "eigen_conv_profile", "eigen_debug_corners", "eigen_debug_dense_flow", "eigen_prednet_flops_per_step", "eigen_flatten_genomes"]

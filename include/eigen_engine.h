@@ -27,7 +27,7 @@ extern "C" {
 #endif
 
 #define EIGEN_MAX_LAYERS 8
-#define EIGEN_ABI_VERSION 3 /* 2: eigen_config grew (flow_method, fb_*), eigen_debug_dense_flow, gradient = 2; 3: eigen_gate_order */
+#define EIGEN_ABI_VERSION 4 /* 2: eigen_config grew (flow_method, fb_*), eigen_debug_dense_flow, gradient = 2; 3: eigen_gate_order; 4: eigen_winograd_mask */
 
 typedef enum {
     EIGEN_OK = 0,
@@ -220,6 +220,11 @@ int eigen_flatten_genomes(int32_t n_genomes, int32_t n_inputs, const int32_t* in
  * 1 = chainer_prednet's ConvLSTM.__call__ where it is knowable (rounded peephole products, sigmoid = tanh(x/2)/2 + 1/2, un-fused
  * cell update), 0 = rounds 1-3.  The CPU oracle (oracle/eig_oracle.c: eig_oracle_gate_order) must report the same value. */
 int eigen_gate_order(void);
+
+/* The EFFECTIVE operator-form mask of this process (csrc/eigen_engine.hip: EIGEN_WINOGRAD with EIGEN_WINO_FUSEUP=0 folded in as a cleared bit 24): which 3x3
+ * convolutions run in which canonical summation order.  Every rank of a multi-GPU run must report the same value -- a population scored
+ * under two orders still looks valid (bench.py gathers it).  The CPU oracle's oracle.wino_mask_default() states the same rule. */
+int eigen_winograd_mask(void);
 
 /* Deterministic fp32 exp / sigmoid / tanh used by the gate epilogue. */
 int eigen_test_det_math(eigen_engine* e, const float* d_x, int32_t n, float* d_exp, float* d_sig, float* d_tanh,
