@@ -48,8 +48,14 @@ constexpr int W4_U_FLOATS = W4_NPOS * W4_UPOS;      // 36 KB
 constexpr int W4_NUS = 3, W4_NPS = 3;
 constexpr int W4_ROW = 40;                          // floats per plane row: aligned chunks x0-4 .. x0+35
 constexpr int W4_PS = 768;                          // floats per channel plane: 18 rows x 40 = 720 -> three DMA instructions of 256
-constexpr int W4_X_FLOATS = W4_WAVES * 4 * 64 * 4;   // one exchange round = one N-tile: [12 waves][4 e][64 lanes] 16-byte vectors = 48 KB = U slot 2 + 12 KB
-constexpr int wino4_lds_bytes() { return (W4_NPS * W4_KC * W4_PS + 2 * W4_U_FLOATS + W4_X_FLOATS) * 4; }   // 159744: planes 36 KB, U slots 0 / 1 72 KB, U slot 2 + 12 KB = exchange
+// LDS map (floats): plane slots 0, 1 | U slot 0 | X = U slot 1, U slot 2, plane slot 2, 12 KB.  X (96 KB) is the exchange area of the finishing phase: what a walking
+// block prefetches for its next N-block behind the last K-block (U slab of K-block 0, planes of K-blocks 0, 1: 60 KB) lies outside it.
+constexpr int W4_PSLOT = W4_KC * W4_PS;                         // 3072 floats = 12 KB
+constexpr int W4_P0 = 0, W4_P1 = W4_PSLOT, W4_U0 = 2 * W4_PSLOT;
+constexpr int W4_X = W4_U0 + W4_U_FLOATS;                       // 15360
+constexpr int W4_U1 = W4_X, W4_U2 = W4_X + W4_U_FLOATS, W4_P2 = W4_X + 2 * W4_U_FLOATS;
+constexpr int W4_X_FLOATS = W4_WAVES * 2 * 4 * 64 * 4;          // one exchange round = two N-tiles: [12 waves][2][4 e][64 lanes] 16-byte vectors = 96 KB
+constexpr int wino4_lds_bytes() { return (W4_X + W4_X_FLOATS) * 4; }   // 159744
 constexpr int wino4_u_floats(int NI) { return W4_NPOS * 4 * 16 * NI; }   // one 4-channel K-block of the packed weights: [36 pos][4 ch][16 cols][NI] (the buffer ends in one K-block of padding: the fetch runs one K-block past the end)
 #ifndef EIG_W4_DIAG
 #define EIG_W4_DIAG 0   // measurement builds only (WRONG RESULTS): 1 no wait for the K loop's DMAs, 2 no barrier in the K loop, 4 no A-operand build, 8 no plane DMA, 16 no U DMA
@@ -96,14 +102,14 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
     static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
     constexpr int U4 = wino4_u_floats(NI);
-    constexpr int NPS = W4_NPS, KC = W4_KC, PS = W4_PS;
+    constexpr int KC = W4_KC, PS = W4_PS;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py with EIG_TL_WAVES=12)
-    float* const Pb = lds;                          // plane ring
-    float* const Ub = lds + NPS * KC * PS;          // U ring; slot 2 and the 12 KB behind it are the exchange area of the finishing phase
-    float* const xb = Ub + 2 * W4_U_FLOATS;
-    const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int rg = wv & 1, xi = wv >> 1;
+    float* const Pb = lds;                          // (slot offsets W4_P0 / W4_P1 / W4_P2, W4_U0 / W4_U1 / W4_U2 are absolute)
+    float* const Ub = lds;
+    float* const xb = lds + W4_X;
+    const int wv_o = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int rg_o = wv_o & 1, xi_o = wv_o >> 1;
     // The lane index, opaque to the compiler: every per-lane quantity of the K loop and of the finishing phase is derived from a FRESH copy at the point of use, so
     // that nothing per-lane is hoisted out of the walk and carried in registers (or scratch) across the phase that does not need it -- the walking kernel of round 5
     // spilled 42 registers that way, the first version of this one 9.
@@ -132,8 +138,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int nkb0 = a.src[0].C / KC;
     const int nkbu = up_fused ? (a.up_C / KC) : 0;
     const bool has1 = a.nsrc > 1;
-    const int nkb = nkb0 + nkbu + (has1 ? (a.src[1].C / KC) : 0);
-    const int up_lo = nkb0, up_hi = nkb0 + nkbu;
+    const int nkb_o = nkb0 + nkbu + (has1 ? (a.src[1].C / KC) : 0);
+    const int up_lo_o = nkb0, up_hi_o = nkb0 + nkbu;
 #define EIG4_WAITCNT(imm) do { __builtin_amdgcn_s_waitcnt(imm); asm volatile("" ::: "memory"); } while (0)
 #define EIG4_BARRIER() do { asm volatile("" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); } while (0)
 #define EIG4_LDS_BARRIER() do { EIG4_WAITCNT(0xC07F); EIG4_BARRIER(); } while (0)   /* lgkmcnt(0) only: global loads / LDS-DMAs in flight are NOT waited for (__syncthreads would) */
@@ -142,28 +148,36 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     // ---- plane fetch (every wave: channel wv / 3 of the K-block, part wv % 3 of its plane): lane = 16-byte chunk of the 18 x 10-chunk haloed plane (unpooled source:
     // 10 rows x 6 chunks at half resolution, row stride 10 chunks); rows / chunks outside the image are out of the descriptor's range through a saturating add = zeros
-    const unsigned long long sb0 = (unsigned long long)(a.src[0].ptr + (size_t)eb * a.src[0].Ct * HW);
-    const unsigned long long sb1 = has1 ? (unsigned long long)(a.src[1].ptr + (size_t)eb * a.src[1].Ct * HW) : sb0;
-    const int sz0 = a.src[0].C * HW * 4, sz1 = has1 ? a.src[1].C * HW * 4 : sz0;
-    const int Hh = a.H >> 1, Wh = a.W >> 1, HWh = Hh * Wh;
-    const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
-    const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
-    const int pch = wv / 3, ppart = wv - pch * 3;
     constexpr unsigned W4_POSB = 4 * 16 * NI * 4;   // bytes per position of a packed K-block
     for (int it = 0; it < nwalk; ++it) {
     const int nblk = nb0 + it;
+    // An opaque zero: the scalars of a phase are derived from the wave index, the K-block counts and the tile coordinates offset by it INSIDE the walk, so that the
+    // compiler does not hoist the LDS addresses of every DMA instruction, the source selection of the prologue and of the K loops' six role variants and the address
+    // arithmetic of the finishing phase out of the walk and keep them live in SGPRs throughout (first walking build: 106 SGPRs + 88 spilled to VGPR lanes, 10 VGPRs in
+    // scratch, reloads inside the K loop; the non-walking kernel: 88 / 0 / 0).
+    int zs = 0;
+    asm volatile("" : "+s"(zs));
+    const int wv = wv_o + zs, rg = rg_o + zs, xi = xi_o + zs, nkb = nkb_o + zs, up_lo = up_lo_o + zs, up_hi = up_hi_o + zs;
+    const int pch = wv / 3, ppart = wv - pch * 3;
+    const int eb_i = eb + zs, y0_i = y0 + zs, x0_i = x0 + zs;
+    const unsigned long long sb0 = (unsigned long long)(a.src[0].ptr + (size_t)eb_i * a.src[0].Ct * HW);
+    const unsigned long long sb1 = has1 ? (unsigned long long)(a.src[1].ptr + (size_t)eb_i * a.src[1].Ct * HW) : sb0;
+    const int sz0 = a.src[0].C * HW * 4, sz1 = has1 ? a.src[1].C * HW * 4 : sz0;
+    const int Hh = a.H >> 1, Wh = a.W >> 1, HWh = Hh * Wh;
+    const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb_i * a.up_C * HWh) : sb0;
+    const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
     const int lane = lane_id();
     const int q = lane >> 4, col = lane & 15;
     int roff, uoff;
     {
         const int c = lane + 64 * ppart;
         const int row = c / 10, cx = c - row * 10;
-        const int gy = y0 - 1 + row, gx = x0 - 4 + 4 * cx;
+        const int gy = y0_i - 1 + row, gx = x0_i - 4 + 4 * cx;
         roff = (c < 180 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : -1;
-        const int hy = (y0 >> 1) - 1 + row, hx = (x0 >> 1) - 4 + 4 * cx;
+        const int hy = (y0_i >> 1) - 1 + row, hx = (x0_i >> 1) - 4 + 4 * cx;
         uoff = (row < 10 && cx < 6 && hy >= 0 && hy < Hh && hx >= 0 && hx < Wh) ? (hy * Wh + hx) * 4 : -1;
     }
-    auto dma_plane_at = [&](int jj, int slot) __attribute__((always_inline)) {   // (prologue) this wave's plane DMA of K-block min(jj, nkb - 1) -> slot
+    auto dma_plane_at = [&](int jj, int slot_off) __attribute__((always_inline)) {   // (prologue) this wave's plane DMA of K-block min(jj, nkb - 1) -> the plane slot at float offset slot_off
         const int j = jj < nkb ? jj : nkb - 1;
         const bool up = EIG4_IS_UP(j);
         const bool s1 = j >= up_hi;
@@ -175,27 +189,31 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(sz), 0x00020000);
         const int base = (up_lo & (int)mu) + (up_hi & (int)m1), hw = HW + ((HWh - HW) & (int)mu);
         const unsigned coff = (unsigned)((j - base) * KC + pch) * (unsigned)(hw * 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + (slot * KC + pch) * PS + ppart * 256), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + pch * PS + ppart * 256), 16,
                                                  (int)__builtin_elementwise_add_sat((unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (unsigned)mu), coff), 0, 0, 0);
     };
     // ---- U fetch (every wave: positions 3 wv .. 3 wv + 2 of the next K-block in line): one position of a packed 4-channel K-block = one contiguous KB (NI = 3: 768 B).
     // The scalar offset runs along the packed K-blocks (no index arithmetic in the K loop; the last two fetches read the next N-block's first K-blocks or the
     // buffer's padding into slots nobody reads).
     const int uvo = (NI == 4 || lane < 48) ? lane * 16 : -1;
-    // The prologue of N-block nb: the U slabs of K-blocks 0, 1 -> U slots 0, 1 and the planes of K-blocks 0, 1, 2 -> plane slots 0, 1, 2.  Issued at the start of a block,
-    // and -- WALK -- for N-block nb + 1 right behind the last K-block of nb, ahead of nb's finishing phase (which only touches U slot 2 and the 12 KB behind it).
-    auto prologue_dmas = [&](int nb) __attribute__((always_inline)) {
+    // The prologue of N-block nb in two parts.  A: the U slab of K-block 0 and the planes of K-blocks 0, 1 -- what the first operand build and K-block 0 read; a walking
+    // block issues it for N-block nb + 1 right behind the last K-block of nb, ahead of nb's finishing phase (whose exchange area X it lies outside of).  B: the U slab of
+    // K-block 1 and the plane of K-block 2, into X -- behind the barrier at the top of the next N-block (they are waited for at the end of K-block 0).
+    auto prologue_a = [&](int nb) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nb * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + (3 * wv + i) * W4_UPOS), 16, uvo, (int)((unsigned)(3 * wv + i) * W4_POSB), 0, 0);
-        dma_plane_at(0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + W4_U0 + (3 * wv + i) * W4_UPOS), 16, uvo, (int)((unsigned)(3 * wv + i) * W4_POSB), 0, 0);
+        dma_plane_at(0, W4_P0);
+        dma_plane_at(1, W4_P1);
+    };
+    auto prologue_b = [&](int nb) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nb * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + W4_U_FLOATS + (3 * wv + i) * W4_UPOS), 16, uvo,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + W4_U1 + (3 * wv + i) * W4_UPOS), 16, uvo,
                                                      (int)((unsigned)U4 * 4 + (unsigned)(3 * wv + i) * W4_POSB), 0, 0);
-        dma_plane_at(1, 1);
-        dma_plane_at(2, 2);
+        dma_plane_at(2, W4_P2);
     };
 
     // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) = (col >> 3, col & 7) of region rg (rows 8 rg .. 8 rg + 7 of the block; MFMA row r = 8 ty + tx)
@@ -207,8 +225,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     unsigned long long tq_setup = tq_entry;
     if (it == 0) {
         if (EIG_TIMING) tq_setup = __builtin_readcyclecounter();
-        prologue_dmas(nb0);
-        EIG4_WAITCNT(0x0F71);   // all but the plane of K-block 2
+        prologue_a(nb0);
+        EIG4_WAITCNT(0x0F70);
     }
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
     unsigned u_so = (unsigned)(3 * wv) * W4_POSB + 2u * (unsigned)U4 * 4u;   // (K-blocks 0, 1 came with the prologue)
@@ -225,8 +243,10 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     for (int p = 0; p < 6; ++p)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // (a fresh block waited for its prologue above; a walking block's waves each waited for theirs -- vmcnt(0) -- in front of the previous finishing phase's gate loads)
+    // (a fresh block waited for part A of its prologue above; a walking block's waves each waited for theirs -- vmcnt(0) -- in front of the previous finishing phase's
+    // gate loads.)  Behind this barrier nobody reads the exchange area any more: part B goes into it.
     EIG4_BARRIER();
+    prologue_b(nblk);
     const unsigned long long tq_k0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     unsigned long long tq_k1 = 0, tq_x = 0, tq_y = 0;
     // [entry, set-up done, K loop start, K loop end, first exchange barrier passed, y ready (gates start), exit, HW_ID | XCC_ID << 32] per (block, N-block of the walk, wave)
@@ -252,8 +272,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         // Rings of three, all in the phase kb % 3, as ROTATING float offsets (one set of moves per K-block; slot counters cost an add, a compare, a select and a multiply
         // each, in every K-block's instruction stream): U slots of K-blocks kb, kb + 1 and of the fetch (kb + 2); plane slots of the fetch (kb + 3 -> slot kb % 3), of the
         // patch rows read next (kb + 1) and the third
-        int uo0 = 0, uo1 = W4_U_FLOATS, uo2 = 2 * W4_U_FLOATS;
-        int po0 = 0, po1 = KC * PS, po2 = 2 * KC * PS;
+        int uo0 = W4_U0, uo1 = W4_U1, uo2 = W4_U2;
+        int po0 = W4_P0, po1 = W4_P1, po2 = W4_P2;
         // fetch cursor of the planes (K-block pj = kb + 3, clamped to the last one): the descriptor of its source as scalars (a mutable descriptor OBJECT ends in
         // scratch memory), the byte offset of this wave's channel, the slot
         int pj = 0, psz = 0, pbound = 0;
@@ -351,10 +371,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         // K-block (nothing to stage).  On entry v and bq hold the A operands and the first B operand of this K-block: the first instruction behind the barrier is an MFMA,
         // and the staging work sits in slices BETWEEN the chunks -- the U fetch behind chunk 0, the plane fetch behind chunk 1, the patch rows of K-block kb + 1 and
         // the A operands of kb + 1 behind the last chunks (see slice below).
-        auto kiter = [&](const int kb, auto kind_tag, auto nk_tag, auto last_tag) __attribute__((always_inline)) {
+        auto kiter = [&](const int kb, auto kind_tag, auto nk_tag, auto last_tag, auto first_tag) __attribute__((always_inline)) {
             constexpr int KIND = decltype(kind_tag)::value;
             constexpr int NK = decltype(nk_tag)::value;
             constexpr bool LAST = decltype(last_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;   // K-block 0: the U slab of K-block 1 (prologue part B) is only known to have landed at this K-block's END -- its first operand is read behind the barrier
             constexpr bool UP = KIND == 1;   // (run-time kind = the last K-block of all: an unpooled-source one there runs the full body on its exact-zero operands -- fma(0, u, M) = M)
             constexpr bool IDLE = UP && XI == 2;   // nothing to multiply
             constexpr int NCH = IDLE ? 0 : (UP ? 5 : 6);   // chunks: nu = 0, 1, (2,) 3, 4, 5
@@ -376,7 +397,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                     if (!(EIG_W4_DIAG & 16)) dma_u(uo2);
                     if (!(EIG_W4_DIAG & 8)) dma_plane();
                     rows_begin(po1, NK == 2 ? EIG4_IS_UP(kb + 1) : NK == 1); rows_mid(); rows_end();
-                    read_b(uo1, 0, bq); build_cols();
+                    if constexpr (!FIRST) read_b(uo1, 0, bq);
+                    build_cols();
                 }
             } else {
 #pragma unroll
@@ -385,7 +407,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                     if (i + 1 < NCH) {
                         const int nu1 = (UP && i + 1 >= 2) ? i + 2 : i + 1;
                         read_b(uo0, nu1, bv[(i + 1) & 1]);
-                    } else if constexpr (!LAST) read_b(uo1, 0, bq);
+                    } else if constexpr (!LAST && !FIRST) read_b(uo1, 0, bq);
                     const float* const b = i == 0 ? bq : bv[i & 1];
 #pragma unroll
                     for (int ni = 0; ni < NI; ++ni) acc[nu][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], b[ni], acc[nu][ni], 0, 0, 0);
@@ -399,24 +421,27 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             if (LAST || (EIG_W4_DIAG & (8 | 16))) EIG4_WAITCNT(0x0F70);
             else if (!(EIG_W4_DIAG & 2)) { if (!(EIG_W4_DIAG & 1)) EIG4_WAITCNT(0x0F71); }
             if (!(EIG_W4_DIAG & 2) || LAST) EIG4_BARRIER();
+            if constexpr (FIRST) read_b(uo0, 0, bq);
         };
         const std::false_type nl{};
         const std::integral_constant<int, 2> rt{};
         int kb = 0;
-        rows_begin(0, EIG4_IS_UP(0)); rows_mid(); rows_end();
-        read_b(0, 0, bq);
+        rows_begin(W4_P0, EIG4_IS_UP(0)); rows_mid(); rows_end();
+        read_b(W4_U0, 0, bq);
         build_cols();
         EIG4_WAITCNT(0xC07F);
         EIG4_BARRIER();   // (every wave has read plane 0 out of its slot before anyone's K-block 0 fetches into it)
         // K-blocks [kb, end) of one kind; the LAST K-block of all is left out.  A K-block reads the patch rows of the next one: same kind except at the end of a run.
         auto run = [&](const int end, auto kind_tag) __attribute__((always_inline)) {
-            for (; kb + 1 < end; ++kb) kiter(kb, kind_tag, kind_tag, nl);
-            if (kb + 1 == end && end < nkb) { kiter(kb, kind_tag, rt, nl); ++kb; }
+            for (; kb + 1 < end; ++kb) kiter(kb, kind_tag, kind_tag, nl, nl);
+            if (kb + 1 == end && end < nkb) { kiter(kb, kind_tag, rt, nl, nl); ++kb; }
         };
+        kiter(0, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, nl, std::true_type{});   // (source 0 has at least two K-blocks: Cin % 8 == 0)
+        kb = 1;
         run(up_lo, std::integral_constant<int, 0>{});
         run(up_hi, std::integral_constant<int, 1>{});
         run(nkb, std::integral_constant<int, 0>{});
-        kiter(nkb - 1, rt, rt, std::true_type{});
+        kiter(nkb - 1, rt, rt, std::true_type{}, nl);
     };
     switch (xi) {
         case 0: kloops(std::integral_constant<int, 0>{}); break;
@@ -427,10 +452,10 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         default: kloops(std::integral_constant<int, 5>{}); break;
     }
     if (EIG_TIMING) tq_k1 = __builtin_readcyclecounter();
-    // WALK: every wave is past the last barrier of the K loop, every DMA of this N-block has landed -- the next N-block's prologue goes out now and lands behind the
-    // finishing phase below (U slots 0, 1 and the plane ring; the exchange lives in U slot 2 + 12 KB)
+    // WALK: every wave is past the last barrier of the K loop, every DMA of this N-block has landed -- part A of the next N-block's prologue goes out now and lands
+    // behind the finishing phase below (U slot 0, plane slots 0, 1; the exchange lives in X)
     const bool more = it + 1 < nwalk;
-    if (more) prologue_dmas(nblk + 1);
+    if (more) prologue_a(nblk + 1);
 
     // ---- output transform.  Along nu in-lane: c_xi,b (b = 0..3) of every N-tile.
     f32x4 cc[4][NI];
@@ -441,41 +466,37 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) cc[b][ni] = Y[b];
     }
-    // Along xi: the six waves of a region publish their c rows, ONE N-tile per round ([12 waves][4 e][64 lanes] 16-byte vectors over b = 48 KB); the finishing lanes
-    // read what their output rows need: y0 = (c0 + s) + u, y1 = fma(2, w, d), y2 = fma(4, u, s), y3 = fma(8, w, d) + c5 with s = c1 + c2, d = c1 - c2, u = c3 + c4, w = c3 - c4.
-    // (per-lane quantities from a fresh lane_id(): see the top of the kernel)
-    const int ln = lane_id();
-    const int fq = ln >> 4, fcol = ln & 15;
-    const size_t cHW = (size_t)HW;
-    const int j = ln & 7, chl = ln >> 3, e_r = j & 3, ql = j >> 2;   // finishing lane: chunk j of the block row, channel 8 chh + chl (see below)
-    int woff[4];                                                       // publishing lane (q, col): its slot in plane e
+    // Along xi: the six waves of a region publish their c rows in two rounds (N-tiles 0, 1 then 2, 3: [12 waves][2 N-tiles][4 e][64 lanes] 16-byte vectors over b = 96 KB
+    // each; U / planes are dead -- every wave is past the last barrier, every DMA has landed); the finishing lanes read what their output rows need:
+    // y0 = (c0 + s) + u, y1 = fma(2, w, d), y2 = fma(4, u, s), y3 = fma(8, w, d) + c5 with s = c1 + c2, d = c1 - c2, u = c3 + c4, w = c3 - c4.
+    {   // (own scope: per-lane quantities from a FRESH lane_id(), scalars from coordinates offset by a fresh opaque zero: see the top of the kernel / of the walk)
+    int zf = 0;
+    asm volatile("" : "+s"(zf));
+    const int eb = eb_i + zf, y0 = y0_i + zf, x0 = x0_i + zf, wv = wv_o + zf, rg = rg_o + zf, xi = xi_o + zf, HWf = HW + zf, Cout = a.Cout + zf;
+    const int lane = lane_id();
+    const int q = lane >> 4, col = lane & 15;
+    const size_t cHW = (size_t)HWf;
+    const int j = lane & 7, chl = lane >> 3, e_r = j & 3, ql = j >> 2;   // finishing lane: chunk j of the block row, channel 8 chh + chl (see below)
+    int woff[4];                                                           // publishing lane (q, col): its slot in plane e
 #pragma unroll
-    for (int e = 0; e < 4; ++e) woff[e] = ((wv * 4 + e) * 64 + fq * 16 + ((fcol + 4 * e + 8 * (fq & 1)) & 15)) * 4;
-    auto publish = [&](int ni) __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            f32x4 t;
-            t[0] = cc[0][ni][e]; t[1] = cc[1][ni][e]; t[2] = cc[2][ni][e]; t[3] = cc[3][ni][e];
-            *reinterpret_cast<f32x4*>(xb + woff[e]) = t;
-        }
-    };
+    for (int e = 0; e < 4; ++e) woff[e] = ((wv * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + 8 * (q & 1)) & 15)) * 4;
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
         // All twelve waves finish outputs, and they finish them in IMAGE order: the exchange is laid out so that a finishing lane reads the four pixels b = 0..3 of ONE tile
         // as a 16-byte vector, and finishing lane L takes the 16-byte chunk j = L & 7 of a 32-pixel block row (tile tx = j, writer lane q = 2 ty + (j >> 2), register e =
         // j & 3) of channel 8 chh + (L >> 3): the eight lanes j = 0..7 of a channel read / write ONE 128-byte line of c, the peepholes, h or P (lane = (tile group, channel)
         // as the accumulators lie touched 64 lines per instruction, and the 7-9 us that cost per block were half of the time between two K loops:
         // profiles/r05_f_w4_timeline.txt).  Units of 64 chunks: wave xi < 4 takes output row a = xi of (tile row ty, channel half chh) = (0,0), (0,1), (1,0); waves 4 / 5
-        // take (1,1) of rows 0, 1 / 2, 3 -- 12 or 8 cells per lane.  The slot of writer lane (q, col) in plane e is q 16 + ((col + 4 e + 8 (q & 1)) & 15), which spreads
-        // every 16-lane service group of the b128 reads over all 16 slots.
+        // take (1,1) of rows 0, 1 / 2, 3 -- 12 or 8 cells per lane.  Rounds: N-tiles (gates) 0, 1 then 2, 3: [12 waves][2][4 e][64 lanes] 16-byte vectors = 96 KB each; the
+        // slot of writer lane (q, col) in plane e is q 16 + ((col + 4 e + 8 (q & 1)) & 15), which spreads every 16-lane service group of the b128 reads over all 16 slots.
         const int nun = xi < 4 ? 3 : 2;
         int xoff[3];
 #pragma unroll
         for (int un = 0; un < 3; ++un) {
             const int ty = xi < 4 ? (un >> 1) : 1, chh = xi < 4 ? (un & 1) : 1;
-            xoff[un] = rg * 1024 + (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
+            xoff[un] = (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
         }
-        auto finish = [&](int arow, int off) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3
-            auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + x * 2048 + off); };
+        auto finish = [&](int arow, int nr, int off) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3
+            auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + ((x * 2 + rg) * 2 + nr) * 1024 + off); };
             const f32x4 c1 = C(1), c2 = C(2), c3 = C(3), c4 = C(4);
             const f32x4 s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
             f32x4 y;
@@ -487,26 +508,42 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         };
         f32x4 ys[NI][3];   // [N-tile][unit]: the four pixels of the lane's chunk
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            if (ni) EIG4_LDS_BARRIER();   // (everyone has read the previous round)
-            publish(ni);
-            EIG4_LDS_BARRIER();
-            if (EIG_TIMING && ni == 0) tq_x = __builtin_readcyclecounter();
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (2 * rnd >= NI) break;
+            if (rnd) EIG4_LDS_BARRIER();   // (everyone has read round 0; lgkmcnt only -- the prefetches of the next N-block stay in flight)
 #pragma unroll
-            for (int un = 0; un < 3; ++un) {
-                if (un >= nun) break;
-                switch (xi) {
-                    case 0: ys[ni][un] = finish(0, xoff[un]); break;
-                    case 1: ys[ni][un] = finish(1, xoff[un]); break;
-                    case 2: ys[ni][un] = finish(2, xoff[un]); break;
-                    case 3: ys[ni][un] = finish(3, xoff[un]); break;
-                    case 4: ys[ni][un] = un ? finish(1, xoff[un]) : finish(0, xoff[un]); break;
-                    default: ys[ni][un] = un ? finish(3, xoff[un]) : finish(2, xoff[un]); break;
+            for (int nr = 0; nr < 2; ++nr) {
+                const int ni = 2 * rnd + nr;
+                if (ni >= NI) break;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x4 t;
+                    t[0] = cc[0][ni][e]; t[1] = cc[1][ni][e]; t[2] = cc[2][ni][e]; t[3] = cc[3][ni][e];
+                    *reinterpret_cast<f32x4*>(xb + woff[e] + nr * 1024) = t;
+                }
+            }
+            EIG4_LDS_BARRIER();
+            if (EIG_TIMING && rnd == 0) tq_x = __builtin_readcyclecounter();
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr) {
+                const int ni = 2 * rnd + nr;
+                if (ni >= NI) break;
+#pragma unroll
+                for (int un = 0; un < 3; ++un) {
+                    if (un >= nun) break;
+                    switch (xi) {
+                        case 0: ys[ni][un] = finish(0, nr, xoff[un]); break;
+                        case 1: ys[ni][un] = finish(1, nr, xoff[un]); break;
+                        case 2: ys[ni][un] = finish(2, nr, xoff[un]); break;
+                        case 3: ys[ni][un] = finish(3, nr, xoff[un]); break;
+                        case 4: ys[ni][un] = un ? finish(1, nr, xoff[un]) : finish(0, nr, xoff[un]); break;
+                        default: ys[ni][un] = un ? finish(3, nr, xoff[un]) : finish(2, nr, xoff[un]); break;
+                    }
                 }
             }
         }
-        // WALK: this wave's share of the next N-block's prologue has landed (issued ~3 us ago) -- waited for HERE, ahead of the gate loads and the stores, so that
-        // the barrier at the top of the next K loop needs no vmcnt wait of its own (which would wait for the stores below as well)
+        // WALK: this wave's share of part A has landed (issued ~3 us ago) -- waited for HERE, ahead of the gate loads and the stores, so that the barrier at the top
+        // of the next N-block needs no vmcnt wait of its own (which would wait for the stores below as well)
         if (more) EIG4_WAITCNT(0x0F70);
         if (EIG_TIMING) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tq_y = __builtin_readcyclecounter(); }
 #pragma unroll
@@ -519,9 +556,9 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             const size_t pix = (size_t)gy * a.W + gx;
             if constexpr (EPI == EPI_LSTM) {
                 const int ch = nblk * 16 + 8 * chh + chl;
-                if (ch >= a.Cout) continue;
-                const float bi = a.bias[ch], bf = a.bias[a.Cout + ch], bc = a.bias[2 * a.Cout + ch], bo = a.bias[3 * a.Cout + ch];
-                const size_t cbase = ((size_t)eb * a.Cout + ch) * cHW, ps = (size_t)a.Cout * cHW, pbase = (size_t)ch * cHW;
+                if (ch >= Cout) continue;
+                const float bi = a.bias[ch], bf = a.bias[Cout + ch], bc = a.bias[2 * Cout + ch], bo = a.bias[3 * Cout + ch];
+                const size_t cbase = ((size_t)eb * Cout + ch) * cHW, ps = (size_t)Cout * cHW, pbase = (size_t)ch * cHW;
                 const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
                 const f32x4 pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
                 const f32x4 pf4 = *reinterpret_cast<const f32x4*>(a.peep + ps + pbase + pix);
@@ -539,42 +576,50 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
                     const int ch = (nblk * NI + ni) * 16 + 8 * chh + chl;
-                    if (ch >= a.Cout) continue;
+                    if (ch >= Cout) continue;
                     const float bb_ = a.bias[ch];
                     f32x4 v4;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) v4[b] = relu_f(ys[ni][un][b] + bb_);
-                    *reinterpret_cast<f32x4*>(a.Pout + ((size_t)eb * a.Cout + ch) * cHW + pix) = v4;
+                    *reinterpret_cast<f32x4*>(a.Pout + ((size_t)eb * Cout + ch) * cHW + pix) = v4;
                 }
             }
         }
     } else {
         // ConvA, in image order as well: a finishing lane takes the chunk j of the output-row PAIR ap (rows 2 ap, 2 ap + 1) of tile row ty for one channel -- the two 2x2
         // pooling windows of its four pixels -- i.e. two pooled pixels (8 bytes); the eight lanes of a channel cover 16 pooled pixels = 64 contiguous bytes of P and of both
-        // halves of E.  Units of 64 such lanes per round (= N-tile): g = (ty, ap, chh), eight of them over the six waves of the region: wave xi takes unit xi, and units 6, 7
-        // go to the waves 2 rnd % 6, 2 rnd % 6 + 1 (rotating: over three rounds every wave finishes four units).
+        // halves of E.  Units of 64 such lanes per round (N-tiles 2 rnd, 2 rnd + 1): g = (nr, ty, ap, chh), 16 of them (8 when the round holds one N-tile) over the six waves
+        // of the region as 3,3,3,3,2,2 (2,2,1,1,1,1).  (Before: lane = (tile group, channel), 8-byte accesses to 64 different lines per instruction, and only xi < 4 worked.)
         const int Ho = a.H >> 1, Wo = a.W >> 1;
         const size_t plane = (size_t)Ho * Wo;
         const int ox = (x0 >> 1) + 2 * j;
 #pragma unroll
-        for (int rnd = 0; rnd < NI; ++rnd) {
+        for (int rnd = 0; rnd < 2; ++rnd) {
+            if (2 * rnd >= NI) break;
+            const int nval = NI - 2 * rnd >= 2 ? 2 : 1;
             if (rnd) EIG4_LDS_BARRIER();
-            publish(rnd);
-            EIG4_LDS_BARRIER();
-            if (EIG_TIMING && rnd == 0) tq_x = __builtin_readcyclecounter();
-            if (rnd == NI - 1) { if (more) EIG4_WAITCNT(0x0F70); }   // (see the ConvLSTM / ConvP branch)
-            const int ex0 = (2 * rnd) % 6;
 #pragma unroll
-            for (int un = 0; un < 2; ++un) {
-                int g = xi;
-                if (un == 1) {
-                    if (xi == ex0) g = 6;
-                    else if (xi == ex0 + 1) g = 7;
-                    else break;
+            for (int nr = 0; nr < 2; ++nr) {
+                if (nr >= nval) break;
+                const int ni = 2 * rnd + nr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x4 t;
+                    t[0] = cc[0][ni][e]; t[1] = cc[1][ni][e]; t[2] = cc[2][ni][e]; t[3] = cc[3][ni][e];
+                    *reinterpret_cast<f32x4*>(xb + woff[e] + nr * 1024) = t;
                 }
-                const int ty = (g >> 2) & 1, ap = (g >> 1) & 1, chh = g & 1;
-                const int off = rg * 1024 + (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
-                auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + x * 2048 + off); };
+            }
+            EIG4_LDS_BARRIER();
+            if (rnd == (NI - 1) / 2) { if (more) EIG4_WAITCNT(0x0F70); }   // (see the ConvLSTM / ConvP branch)
+            const int g0 = nval == 2 ? (xi < 4 ? 3 * xi : 12 + 2 * (xi - 4)) : (xi < 2 ? 2 * xi : xi + 2);
+            const int cnt = nval == 2 ? (xi < 4 ? 3 : 2) : (xi < 2 ? 2 : 1);
+#pragma unroll
+            for (int un = 0; un < 3; ++un) {
+                if (un >= cnt) break;
+                const int g = g0 + un;
+                const int nr = g >> 3, ty = (g >> 2) & 1, ap = (g >> 1) & 1, chh = g & 1;
+                const int off = ((nr + 2 * rg) * 256 + e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
+                auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + x * 4096 + off); };
                 const f32x4 c1 = C(1), c2 = C(2), c3 = C(3), c4 = C(4);
                 const f32x4 s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
                 f32x4 ya, yb;   // output rows 2 ap, 2 ap + 1
@@ -586,12 +631,12 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                     const f32x4 c5 = C(5);
                     for (int b = 0; b < 4; ++b) { ya[b] = fmaf(4.0f, u_[b], s_[b]); yb[b] = fmaf(8.0f, w_[b], d_[b]) + c5[b]; }
                 }
-                const int ch = (nblk * NI + rnd) * 16 + 8 * chh + chl;
+                const int ch = (nblk * NI + 2 * rnd + nr) * 16 + 8 * chh + chl;
                 const int oy = (y0 >> 1) + 4 * rg + 2 * ty + ap;
-                if (oy >= Ho || ox >= Wo || ch >= a.Cout) continue;
+                if (oy >= Ho || ox >= Wo || ch >= Cout) continue;
                 const float bb_ = a.bias[ch];
-                const size_t pb = ((size_t)eb * a.Cout + ch) * plane + (size_t)oy * Wo + ox;
-                const size_t e0 = ((size_t)eb * 2 * a.Cout + ch) * plane + (size_t)oy * Wo + ox, e1 = e0 + (size_t)a.Cout * plane;
+                const size_t pb = ((size_t)eb * Cout + ch) * plane + (size_t)oy * Wo + ox;
+                const size_t e0 = ((size_t)eb * 2 * Cout + ch) * plane + (size_t)oy * Wo + ox, e1 = e0 + (size_t)Cout * plane;
                 const f32x2 p2 = *reinterpret_cast<const f32x2*>(a.P + pb);
                 f32x2 ea, eb2;
 #pragma unroll
@@ -606,6 +651,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                 *reinterpret_cast<f32x2*>(a.E + e1) = eb2;
             }
         }
+    }
     }
     timeline();
     }   // walk
