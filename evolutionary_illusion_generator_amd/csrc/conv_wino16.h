@@ -1,11 +1,11 @@
-// conv_wino16.h -- the Winograd ConvLSTM of conv_wino.h on SIXTEEN waves per block (four per SIMD).  DESIGN.md section 3.1d.
+// conv_wino16.h -- the Winograd F(2x2, 3x3) operators on SIXTEEN waves per block (four per SIMD).  DESIGN.md section 3.1d.
 //
 // Why: the model of conv_wino.h's K-block (scripts/wino_loop_model.hip, profiles/r04_w_wino_loop_model.txt) shows every piece of the staging work
 // costing the matrix pipe several times its instruction count when only ONE partner wave per SIMD can fill in, and the barrier 9 points once
 // the waves drift; the same K-block on sixteen waves of half the accumulators each loses 4 points to all of it instead of 17.
 //
 // Same block (16 x 16 output pixels of one image x 64 columns = 16 channels x 4 gates), same K-blocks, same LDS image (V, U double-buffered,
-// eight planes), same arithmetic in the same order as wino_kernel<4, EPI_LSTM, 8> -- the results are identical bit for bit.  What changes:
+// eight planes), same arithmetic in the same order as the eight-wave kernel of round 4 -- the results are identical bit for bit.  What changes:
 //   wave w COMPUTES region rg = w & 3 for the FOUR positions (xi, nu = 0..3) with xi = w >> 2: 4 x 4 accumulator tiles (64 VGPRs), 32 MFMAs per
 //     K-block in 8 chunks of 4, each with the operand reads of the next chunk;
 //   waves 0-7 TRANSFORM channel w of the K-block (plane DMA, patch reads before the barrier, column pass in chunk 0, one row in each of the chunks 1-4),
@@ -15,7 +15,14 @@
 //     parity a of segment s (tile rows 4 rg + a + 2 s: window row s) from c_0..c_2 or c_1..c_3 -- the pixel ownership of the eight-wave
 //     kernel's gate epilogue split in two, whose code (lstm_cell, 16-byte accesses) is reused.
 #pragma once
-#include "conv_wino.h"
+#include "conv_mfma.h"
+
+namespace eig {
+// (the eight-wave F(2x2) kernel of rounds 4-5, conv_wino.h, is gone: round 6 -- docs/HISTORY.md section 3.1d keeps its description)
+constexpr int wino_u_floats(int NI) { return 16 * KC * 16 * NI; }   // one packed K-block of F(2x2) weights: [16 pos][8 ch][16 cols][NI]: 8192 floats for NI = 4
+constexpr int WINO_RAW_FLOATS = 18 * 24;                            // one channel's haloed rows y0-1 .. y0+16, aligned chunks x0-4 .. x0+19
+static_assert(KC == 8, "conv_wino16.h: 8-channel K-blocks");
+}  // namespace eig
 
 namespace eig {
 
@@ -63,7 +70,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     const int y0 = tyi * 16, x0 = txi * 16;
     const int HW = a.H * a.W;
 
-    // transform side (conv_wino.h): tile `lane` of the block
+    // transform side: tile `lane` of the block
     const int t_rg = lane >> 4, t_r = lane & 15;
     const int t_ty = 2 * t_rg + ((t_r & 3) >> 1), t_tx = 2 * (t_r >> 2) + (t_r & 1);
     const bool up_fused = EPI == EPI_LSTM && a.up_src != nullptr;
@@ -100,7 +107,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     }
     const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb * a.up_C * HWh) : sb0;
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
-    auto dma_raw = [&](int kb, int par) __attribute__((always_inline)) {   // (conv_wino.h: dma_raw) -> the plane of K-block kb's parity (par = kb & 1)
+    auto dma_raw = [&](int kb, int par) __attribute__((always_inline)) {   // (round 4: dma_raw) -> the plane of K-block kb's parity (par = kb & 1)
         float* const rawp = planes + par * PLANE_PAR;
         const bool up = EIG16_IS_UP(kb);
         const bool s1 = kb >= nkb0 + nkbu;
@@ -121,7 +128,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
     const int rd_off_u = t_ty * 24 + t_tx + 3;
     const float* const pbase_n = planes + rd_off;
     const float* const pbase_u = planes + rd_off_u;
-    auto read_patch = [&](int kb, int par) __attribute__((always_inline)) {   // (conv_wino.h: read_patch) <- the plane of K-block kb's parity (par = kb & 1)
+    auto read_patch = [&](int kb, int par) __attribute__((always_inline)) {   // (round 4: read_patch) <- the plane of K-block kb's parity (par = kb & 1)
         const bool up = EIG16_IS_UP(kb);
         const float* const p00 = (up ? pbase_u : pbase_n) + par * PLANE_PAR;
         const float* const p10 = p00 - (up ? 24 : 0);
@@ -144,7 +151,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
 #pragma unroll
         for (int j = 0; j < 4; ++j) d[2][j] = d[1][j];
     };
-    auto transform = [&](float* vbuf) __attribute__((always_inline)) {   // (conv_wino.h: transform)
+    auto transform = [&](float* vbuf) __attribute__((always_inline)) {   // (round 4: transform)
         float t[4][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {

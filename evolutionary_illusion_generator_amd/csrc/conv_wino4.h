@@ -611,6 +611,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             }
             EIG4_LDS_BARRIER();
             if (rnd == (NI - 1) / 2) { if (more) EIG4_WAITCNT(0x0F70); }   // (see the ConvLSTM / ConvP branch)
+            if (EIG_TIMING && rnd == 0) { tq_x = __builtin_readcyclecounter(); tq_y = tq_x; }
             const int g0 = nval == 2 ? (xi < 4 ? 3 * xi : 12 + 2 * (xi - 4)) : (xi < 2 ? 2 * xi : xi + 2);
             const int cnt = nval == 2 ? (xi < 4 ? 3 : 2) : (xi < 2 ? 2 : 1);
 #pragma unroll

@@ -15,12 +15,8 @@
 
 #include "../../include/eigen_engine.h"
 #include "conv_mfma.h"
-#include "conv_wino.h"
 #include "conv_wino16.h"
 #include "conv_wino4.h"
-#ifndef EIGEN_WINO16_DEFAULT
-#define EIGEN_WINO16_DEFAULT 7
-#endif
 #include "cppn_kernel.h"
 #include "farneback_kernels.h"
 #include "flow_kernels.h"
@@ -60,10 +56,10 @@ struct ConvOp {
     double macs = 0;  // algorithmic multiply-accumulates per image (real channels only)
     double ms = 0;    // profiling accumulator
     int launches = 0;
-    // ConvLSTM with the chain of its unpooled source computed in-kernel (conv_mfma.h: FUSE); the weights live in Layer::d_upw
+    // Winograd ConvLSTM below the top layer: its unpooled source R_{l+1} rides inside the same chains (conv_wino16.h / conv_wino4.h: up_fused)
     bool fused = false;
     int up_C = 0, up_kb = 0;
-    bool wino = false;  // Winograd form (conv_wino.h / conv_wino4.h); epi stays the operator's epilogue
+    bool wino = false;  // Winograd form (conv_wino16.h / conv_wino4.h); epi stays the operator's epilogue
     int wino_tile = 2;  // ... F(2x2, 3x3) or F(4x4, 3x3) (bits 25-27 of EIGEN_WINOGRAD; conv_wino4.h)
 };
 
@@ -80,7 +76,6 @@ struct Layer {
     // The unpooled source R_{l+1} of the ConvLSTM in its 2x2 form (conv_mfma.h: EPI_UP4), launched at the resolution of
     // layer l+1 ahead of the ConvLSTM launch, which adds the result to its own chain (eigen_engine::d_raw4).
     ConvOp up4;
-    float* d_upw = nullptr;  // FUSE: 2x2-form weights of R_{l+1}, [n_nblk][up_kb][KC*4][4 classes][16][4 gates]
 };
 
 template <typename T> struct DevBuf {
@@ -234,10 +229,8 @@ static void choose_ni(int Cout, bool lstm, int* NI, int* n_nblk)
     *NI = best; *n_nblk = (Cout + 16 * best - 1) / (16 * best);
 }
 
-// Tile shape of an operator: 16 x 16, 8 x 8 or -- allow4: operators that have the half-block instantiations, on maps whose width takes
-// 16-byte staging -- strips of 4 columns x 16 rows, when they cover the map at least 15 % better than the best square tile (20 x 15:
-// 94 % against 78 %; their 12-float LDS rows and the half blocks they come as cost about a tenth, conv_mfma.h).  EIGEN_NO_TW4=1: A/B.
-static int choose_tw(int H, int W, bool allow4 = false)
+// Tile shape of an operator: 16 x 16, or 8 x 8 where that covers the map at least 15 % better.
+static int choose_tw(int H, int W)
 {
     auto util = [&](int tw) {
         const int th = (tw == 8) ? 8 : 16;
@@ -249,8 +242,6 @@ static int choose_tw(int H, int W, bool allow4 = false)
     // 8 x 8 tiles at 100 % cover ran at 0.78 of peak, 16 x 16 tiles at 93.75 % cover at 0.86.  EIGEN_TW8_FACTOR for A/Bs.
     static const double tw8_factor = getenv("EIGEN_TW8_FACTOR") ? atof(getenv("EIGEN_TW8_FACTOR")) : 1.15;
     const int sq = (util(16) * tw8_factor + 1e-9 >= util(8)) ? 16 : 8;
-    static const bool no4 = getenv("EIGEN_NO_TW4") && atoi(getenv("EIGEN_NO_TW4"));
-    if (allow4 && !no4 && (W % 4) == 0 && util(4) >= 1.15 * util(sq)) return 4;
     return sq;
 }
 
@@ -330,26 +321,6 @@ static std::vector<float> pack_weights_up4(const ConvOp& op, const float* const 
     return out;
 }
 
-// FUSE (conv_mfma.h): the 2x2-form weights of the unpooled source as the ConvLSTM kernel stages them, K-block by K-block:
-// [n_nblk][up_kb][row = (channel in K-block, a, b)][4 classes][16 columns][4 gates]; channels past Cin are zero rows.
-static std::vector<float> pack_weights_upfuse(int Cout, int n_nblk, int Cin, const float* const srcw[4])
-{
-    const int up_kb = (Cin + KC - 1) / KC;
-    std::vector<float> out((size_t)n_nblk * up_kb * UP_WFLOATS, 0.0f);
-    for (int nb = 0; nb < n_nblk; ++nb)
-        for (int c = 0; c < Cin; ++c)
-            for (int tap = 0; tap < 4; ++tap)
-                for (int cls = 0; cls < 4; ++cls) {
-                    float* dst = &out[(((size_t)nb * up_kb + c / KC) * (KC * 4) + (size_t)(c % KC) * 4 + tap) * UP_WROW + (size_t)cls * 64];
-                    for (int n = 0; n < 64; ++n) {
-                        const int g = n / 16, o = nb * 16 + (n % 16);
-                        if (o >= Cout) continue;
-                        dst[(n % 16) * 4 + g] = presum_up_weight(srcw[g] + ((size_t)o * Cin + c) * 9, cls >> 1, cls & 1, tap >> 1, tap & 1);
-                    }
-                }
-    return out;
-}
-
 // EPI_UP4C (conv_mfma.h): the four classes are the four N-tiles of ONE block: [n_nblk][krows][16 columns][4 classes]
 static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const srcw[4], int lstm)
 {
@@ -370,7 +341,7 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
     return out;
 }
 
-// ---- Winograd F(2x2, 3x3) form of the ConvLSTM's E_l / h_l chain (conv_wino.h; oracle/eig_oracle.c: wino_weights states the same rule)
+// ---- Winograd F(2x2, 3x3) form of the ConvLSTM's E_l / h_l chain (conv_wino16.h; oracle/eig_oracle.c: wino_weights states the same rule)
 // EIGEN_WINOGRAD: bit l = ConvLSTM_l, bit 8 + l = ConvA_l, bit 16 + l = ConvP_l may take the Winograd form (if eligible).  Default: all
 // of them -- measured faster at every shape tried, 256^2 / 512^2 / 640x480 / 160x120, colour and gray, incl. 40 x 30 maps that 16 x 16
 // tiles cover to 78 % (profiles/r04_h_wino_shapes.txt).  Eligibility (the same rule in oracle/eig_oracle.c: eig_wino_op) is a property
@@ -462,33 +433,27 @@ static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm
     return out;
 }
 
-template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false, int SPLIT = 0> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
+template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, int SPLIT = 0> static hipError_t launch_inst2(const ConvArgs& a, int grid, hipStream_t st)
 {
     constexpr int NT = SPLIT == 1 ? 512 : CONV_THREADS;
-    constexpr int lds = FUSE ? 2 * conv_fuse_buf_floats<NI, TW, VEC>() * 4 : conv_lds_bytes<NI, TW, VEC, epi_taps(EPI), ONEKB, NT, SPLIT == 2>();
+    constexpr int lds = conv_lds_bytes<NI, TW, VEC, epi_taps(EPI), ONEKB, NT, false>();
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, false, SPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         attr_done = true;
     }
-    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, FUSE, SPLIT>), dim3(grid), dim3(NT), lds, st, a);
+    hipLaunchKernelGGL((conv3x3_mfma<NI, TW, EPI, VEC, ONEKB, false, SPLIT>), dim3(grid), dim3(NT), lds, st, a);
     return hipGetLastError();
 }
 
-// split: 0 four waves x four classes; 1 the eight-wave instantiation (conv_mfma.h: W8); 2 four-wave half blocks of two images (H4,
-// 8-wide tiles) -- 16-byte staging only, chosen per launch in launch_conv
-template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec, int split = 0)
+// w8: the eight-wave instantiation (conv_mfma.h: W8) -- ConvA only (the image layer's ConvA at small launches; every other direct operator class lost its
+// eight-wave / half-block / strip instantiations in round 6: with the Winograd forms as the default nothing at any BASELINE shape ran them)
+template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec, int w8 = 0)
 {
-    if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP || EPI == EPI_CONVA || EPI == EPI_UP4 || EPI == EPI_RAW) {
-        if constexpr (TW == 8 || TW == 4) {
-            if (split == 2 && vec) return launch_inst2<NI, TW, EPI, true, false, false, 2>(a, grid, st);
-        }
-        if constexpr (TW != 4) {
-            if (split && vec) return launch_inst2<NI, TW, EPI, true, false, false, 1>(a, grid, st);
-        }
+    if constexpr (EPI == EPI_CONVA) {
+        if (w8 && vec) return launch_inst2<NI, TW, EPI, true, false, 1>(a, grid, st);
     }
-    if constexpr (TW == 4) return hipErrorInvalidConfiguration;  // 4-wide strips: half blocks with 16-byte staging only (choose_tw)
-    else return vec ? launch_inst2<NI, TW, EPI, true>(a, grid, st) : launch_inst2<NI, TW, EPI, false>(a, grid, st);
+    return vec ? launch_inst2<NI, TW, EPI, true>(a, grid, st) : launch_inst2<NI, TW, EPI, false>(a, grid, st);
 }
 
 template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& a, int grid, hipStream_t st, bool vec, int w8 = 0)
@@ -501,17 +466,6 @@ template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& 
             default: return launch_inst<4, 16, EPI>(a, grid, st, vec, w8);
         }
     }
-    if (TW == 4) {
-        if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP || EPI == EPI_CONVA || EPI == EPI_UP4 || EPI == EPI_RAW) {
-            switch (NI) {
-                case 1: return launch_inst<1, 4, EPI>(a, grid, st, vec, w8);
-                case 2: return launch_inst<2, 4, EPI>(a, grid, st, vec, w8);
-                case 3: return launch_inst<3, 4, EPI>(a, grid, st, vec, w8);
-                default: return launch_inst<4, 4, EPI>(a, grid, st, vec, w8);
-            }
-        }
-        return hipErrorInvalidConfiguration;
-    }
     switch (NI) {
         case 1: return launch_inst<1, 8, EPI>(a, grid, st, vec, w8);
         case 2: return launch_inst<2, 8, EPI>(a, grid, st, vec, w8);
@@ -523,7 +477,7 @@ template <int EPI> static hipError_t launch_epi(int NI, int TW, const ConvArgs& 
 static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batch, hipStream_t st)
 {
     const int TH = (op.TW == 8) ? 8 : 16;
-    const int NIMG = op.TW == 4 ? 2 : 256 / (TH * op.TW);  // 4-wide strips exist as half blocks (two images) only
+    const int NIMG = 256 / (TH * op.TW);
     a.H = op.H; a.W = op.W; a.B = batch;
     a.tilesX = (op.W + op.TW - 1) / op.TW;
     a.tilesY = (op.H + TH - 1) / TH;
@@ -548,37 +502,14 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         static const int tile_map = getenv("EIGEN_TILE_MAP") ? atoi(getenv("EIGEN_TILE_MAP")) : 1;
         a.tile_map = tile_map != 0;
     }
-    // Eight-wave instantiations (conv_mfma.h: W8).  Measured (profiles/r03_b_ab_w8.txt): where a launch fills the chip many times
-    // over they change nothing (256 genomes at 256^2: every operator within +-0.5 %), where it does not they gain 4-5 % (160x120,
-    // 50 genomes: twice as many waves out of the same few blocks).  Hence: launches of at most EIGEN_W8_GRID blocks (four rounds of
-    // the 512 block slots).  EIGEN_W8 = bit mask forces it for operator classes whatever the grid (1 ConvLSTM, 2 ConvA, 4 ConvP,
-    // 8 the 2x2-form pass, 16 raw test convolutions), EIGEN_W8=0 switches it off: A/B measurements and the parity tests.
+    // Eight-wave instantiation of the direct ConvA (conv_mfma.h: W8): launches of at most four rounds of the device's block slots gain 4-5 % from twice as many waves out
+    // of the same few blocks (profiles/r03_b_ab_w8.txt); EIGEN_W8 = 0 / 1 forces it off / on (A/B measurements and the parity tests).
     static const int w8_env = getenv("EIGEN_W8") ? atoi(getenv("EIGEN_W8")) : -1;
-#ifdef EIGEN_W8_GRID
-    const int w8_grid = EIGEN_W8_GRID;  // measurement builds
-#else
-    const int w8_grid = 8 * e->n_cu;    // four rounds of the device's block slots (two blocks per CU): 2048 on MI355X
-#endif
-    const int w8_mask = w8_env >= 0 ? w8_env : (grid <= w8_grid ? 15 : 0);
-    const int cls_bit = op.epi == EPI_LSTM ? 1 : (op.epi == EPI_CONVA ? 2 : (op.epi == EPI_CONVP ? 4 : (op.epi == EPI_UP4 ? 8 : (op.epi == EPI_RAW ? 16 : 0))));
-    int w8 = (vec && (w8_mask & cls_bit)) ? 1 : 0;  // 0: four waves x four classes, 1: eight waves, 2: half blocks (below)
-    // Half blocks (conv_mfma.h: SPLIT 2, 8-wide tiles): two images per block instead of four.  A launch of fewer than ~2 blocks per CU
-    // takes as long as the CU that received ceil(blocks / 256) of them; twice as many blocks of (a little more than) half the work
-    // are chosen when that model says so -- 300 blocks: 2 block times against 3 x 0.55.  EIGEN_H4 = 1 / 0 forces it on / off (A/B).
-    if (op.TW == 4) w8 = 2;  // (choose_tw only hands out 4-wide strips where 16-byte staging and the half-block instantiations exist)
-    else if (w8 && op.TW == 8) {
-        static const int h4_env = getenv("EIGEN_H4") ? atoi(getenv("EIGEN_H4")) : -1;
-        const int ntile2 = ((batch + 1) / 2) * a.tilesX * a.tilesY;
-        const long b1 = (long)per_tile * ntile, b2 = (long)per_tile * ntile2;
-        static const double h4_factor = getenv("EIGEN_H4_FACTOR") ? atof(getenv("EIGEN_H4_FACTOR")) : 0.55;  // cost of a half block in block times (A/B)
-        const long ncu = e->n_cu;
-        const bool pays = ((b2 + ncu - 1) / ncu) * h4_factor < (double)((b1 + ncu - 1) / ncu);
-        if (h4_env >= 0 ? h4_env != 0 : pays) { w8 = 2; ntile = ntile2; grid = per_tile * ((ntile + 7) / 8) * 8; }
-    }
+    const int w8 = (vec && op.epi == EPI_CONVA && (w8_env >= 0 ? w8_env != 0 : grid <= 8 * e->n_cu)) ? 1 : 0;
     op.last_grid = grid; op.last_waves = (w8 == 1) ? 8 : 4;
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
-    if (op.wino) {  // Winograd form: F(4x4, 3x3) conv_wino4.h; F(2x2, 3x3) conv_wino16.h (sixteen waves), or conv_wino.h (eight waves) for a ConvLSTM whose unpooled source is a chain of its own
+    if (op.wino) {  // Winograd form: F(4x4, 3x3) conv_wino4.h (twelve waves), F(2x2, 3x3) conv_wino16.h (sixteen waves)
         if (op.wino_tile == 4) {   // 16 x 32-pixel blocks, twelve waves
             if (op.epi == EPI_LSTM && a.acc_init != nullptr) return hipErrorInvalidConfiguration;   // (set_weights never pairs F(4x4) with a separate unpooled chain)
             auto go4 = [&](auto kern) {
@@ -619,30 +550,17 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
             const int nt = batch * a.tilesX * a.tilesY;
             const int g = op.n_nblk * ((nt + 7) / 8) * 8;
-            op.last_grid = g; op.last_waves = 8;
-            auto go = [&](auto kern, int ni) {
-                const int lds = wino_lds_bytes(ni, true);
-                static std::unordered_set<const void*> attr_done;
-                if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL(kern, dim3(g), dim3(WINO_THREADS), lds, st, a);
-            };
-            // EIGEN_WINO16: bit mask of the F(2x2) operators on sixteen waves per block (conv_wino16.h; same results): 1 ConvLSTM, 2 ConvA, 4 ConvP
-            static const int wino16 = getenv("EIGEN_WINO16") ? atoi(getenv("EIGEN_WINO16")) : EIGEN_WINO16_DEFAULT;
+            op.last_grid = g; op.last_waves = 16;
             auto go16 = [&](auto kern, int ni) {
                 const int lds = wino16_lds_bytes(ni);
                 static std::unordered_set<const void*> attr_done;
                 if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                op.last_waves = 16;
                 hipLaunchKernelGGL(kern, dim3(g), dim3(WINO16_THREADS), lds, st, a);
             };
-            if ((wino16 & 1) && op.epi == EPI_LSTM && a.acc_init == nullptr) go16(wino16_kernel<4, EPI_LSTM>, 4);
-            else if ((wino16 & 2) && op.epi == EPI_CONVA) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVA>, 4); else go16(wino16_kernel<3, EPI_CONVA>, 3); }
-            else if ((wino16 & 4) && op.epi == EPI_CONVP) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVP>, 4); else go16(wino16_kernel<3, EPI_CONVP>, 3); }
-            else if (op.epi == EPI_LSTM) go(wino_kernel<4, EPI_LSTM, 8>, 4);
-            else if (op.epi == EPI_CONVA && op.NI == 4) go(wino_kernel<4, EPI_CONVA, 8>, 4);
-            else if (op.epi == EPI_CONVA) go(wino_kernel<3, EPI_CONVA, 8>, 3);
-            else if (op.NI == 4) go(wino_kernel<4, EPI_CONVP, 8>, 4);
-            else go(wino_kernel<3, EPI_CONVP, 8>, 3);
+            if (op.epi == EPI_LSTM && a.acc_init != nullptr) return hipErrorInvalidConfiguration;   // (set_weights never pairs a Winograd ConvLSTM with a separate unpooled chain)
+            if (op.epi == EPI_LSTM) go16(wino16_kernel<4, EPI_LSTM>, 4);
+            else if (op.epi == EPI_CONVA) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVA>, 4); else go16(wino16_kernel<3, EPI_CONVA>, 3); }
+            else { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVP>, 4); else go16(wino16_kernel<3, EPI_CONVP>, 3); }
         }
         r = hipGetLastError();
     } else {
@@ -668,11 +586,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         r = hipGetLastError();
     } else
     switch (op.epi) {
-        case EPI_LSTM:
-            if (op.fused && a.up_src) r = launch_inst2<4, 16, EPI_LSTM, true, false, true>(a, grid, st);  // chain of the unpooled source in-kernel
-            else r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec, w8)
-                                   : (op.TW == 4 ? launch_inst<4, 4, EPI_LSTM>(a, grid, st, vec, w8) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec, w8));
-            break;
+        case EPI_LSTM: r = (op.TW == 16) ? launch_inst<4, 16, EPI_LSTM>(a, grid, st, vec) : launch_inst<4, 8, EPI_LSTM>(a, grid, st, vec); break;
         case EPI_LSTM_PACKED: r = (op.TW == 16) ? launch_inst<1, 16, EPI_LSTM_PACKED>(a, grid, st, vec) : launch_inst<1, 8, EPI_LSTM_PACKED>(a, grid, st, vec); break;
         case EPI_CONVA: {
             // the image layer's ConvA (K = 9 x 6 channels): one K-block, its own instantiation (conv_mfma.h: ONEKB)
@@ -733,7 +647,7 @@ int eigen_destroy(eigen_engine* e)
     (void)hipSetDevice(e->cfg.device);
     for (int l = 0; l < e->L; ++l) {
         Layer& y = e->layer[l];
-        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw, y.lstm.d_wraw, y.convA_t0.d_wpk, y.lstm_t0.d_wpk, y.up4.d_wpk, y.d_upw};
+        float* ptrs[] = {y.h[0], y.h[1], y.c, y.P, y.E, y.bias_lstm, y.peep, y.biasA, y.biasP, y.convA.d_wpk, y.lstm.d_wpk, y.convP.d_wpk, y.convP.d_wraw, y.lstm.d_wraw, y.convA_t0.d_wpk, y.lstm_t0.d_wpk, y.up4.d_wpk};
         for (float* p : ptrs) if (p) (void)hipFree(p);
     }
     if (e->d_planes) (void)hipFree(e->d_planes);
@@ -875,7 +789,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             op.epi = EPI_CONVA; op.layer = l; op.nsrc = 1; op.src_C[0] = 2 * e->layer[l - 1].C;
             op.H = e->layer[l - 1].H; op.W = e->layer[l - 1].W; op.Cout = C;
             choose_ni(C, false, &op.NI, &op.n_nblk);
-            op.TW = choose_tw(op.H, op.W, true);
+            op.TW = choose_tw(op.H, op.W);
             op.krows = pad4(op.src_C[0]) * 9;
             op.macs = (double)op.H * op.W * C * op.src_C[0] * 9;
             const float* sw[3][4] = {{convA_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
@@ -911,7 +825,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             choose_ni(C, true, &op.NI, &op.n_nblk);
             if (C <= 4) { op.epi = EPI_LSTM_PACKED; op.NI = 1; op.n_nblk = 1; }  // 4 gates x <=4 channels in one MFMA tile
             const int lstm_mode = (op.epi == EPI_LSTM_PACKED) ? 2 : 1;
-            op.TW = choose_tw(op.H, op.W, op.epi == EPI_LSTM);
+            op.TW = choose_tw(op.H, op.W);
             op.krows = 0; op.macs = 0;
             for (int s = 0; s < op.nsrc; ++s) { op.krows += pad4(op.src_C[s]) * 9; op.macs += (double)y.H * y.W * 4 * C * op.src_C[s] * 9; }
             const float* sw[3][4];
@@ -939,32 +853,22 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             t0.krows = pad4(C) * 9; t0.macs = (double)y.H * y.W * 4 * C * C * 9;
             std::vector<float> pk0 = pack_weights(t0, sw, lstm_mode);
             if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, step 0)", l);
-            // The chain of the unpooled source R_{l+1}: a pass of its own at the source resolution (EPI_UP4), or inside the ConvLSTM
-            // kernel where its wide instantiation runs (conv_mfma.h: FUSE; 16-wide tiles, 16-byte staging of the half-resolution
-            // rows: W % 8 == 0).  Same chain, bit for bit.  Measured (scripts/ab_bench.sh, profiles/r02_b_ab_fuseup.txt): at 256^2
-            // colour the own pass wins by 0.3-0.4 % at every device batch 32..256 (in-kernel K-blocks stage the weights of all four
-            // parity classes: 10 LDS-DMA instructions and four ds_read_b128 per step against 9 per 18 steps and one, which costs what
-            // the pass's prologue / epilogue and its round trip save); where the pass is a SHORT kernel its fixed costs dominate and
-            // the in-kernel form wins: 160x120 colour pop 50 +2.3 %, 160x120 gray +5 %.  Hence: in-kernel iff the pass would
-            // execute < 2.5e10 multiply-adds per launch at this engine's device batch (~0.35 ms); EIGEN_FUSEUP=0 / 1 force it.
-            // EIGEN_WINOGRAD = bit mask of the operators that run in Winograd form (bit l ConvLSTM_l, 8 + l ConvA_l, 16 + l ConvP_l; bit 24: the unpooled source inside the
-            // ConvLSTM's chains; bits 25-27: F(4x4, 3x3) tiles) -- ANOTHER canonical summation order per setting, which the oracle follows through the same variable.
-            // DEFAULT ON for every eligible operator (EIGEN_WINO_DEFAULT); EIGEN_WINOGRAD=0 restores the direct chains of rounds 1-3.  Every rank of a multi-GPU
-            // run must use the same value (bench.py gathers it beside ranks_seen).
-            const bool wino = op.epi == EPI_LSTM && wino_op(wino_env, 0, l, 3 * C, C, y.H, y.W, l == L - 1);
-            bool wino_fuse = false;
+            // The chain of the unpooled source R_{l+1}.  Direct ConvLSTM (the image layer, ineligible shapes, EIGEN_WINOGRAD=0): a pass of its own at the source resolution
+            // in 2x2 form (EPI_UP4 / EPI_UP4C), added to the ConvLSTM's chain with one fp32 addition.  Winograd ConvLSTM: INSIDE the same chains, between E_l and h_l
+            // (conv_wino16.h / conv_wino4.h: up_fused; oracle/eig_oracle.c: eig_wino_lstm) -- below the top layer the Winograd form exists only that way (16-byte rows at the
+            // source resolution: W % 8 == 0, 8-channel K-blocks: C_{l+1} % 8 == 0, bit 24 of the mask); an operator that cannot is a direct one.
+            // EIGEN_WINOGRAD = bit mask of the operators that run in Winograd form (bit l ConvLSTM_l, 8 + l ConvA_l, 16 + l ConvP_l; bit 24: see above; bits 25-27: F(4x4, 3x3)
+            // tiles) -- ANOTHER canonical summation order per setting, which the oracle follows through the same variable.  DEFAULT ON for every eligible operator
+            // (EIGEN_WINO_DEFAULT); EIGEN_WINOGRAD=0 = the direct chains of rounds 1-3.  Every rank of a multi-GPU run must use the same value (eigen_winograd_mask).
+            const bool wino_fuse = ((wino_env >> 24) & 1) && l < L - 1 && (y.W % 8) == 0 && (e->layer[l + 1].C % 8) == 0;
+            const bool wino = op.epi == EPI_LSTM && wino_op(wino_env, 0, l, 3 * C, C, y.H, y.W, l == L - 1) && (l == L - 1 || wino_fuse);
             if (wino) {
-                // the unpooled source R_{l+1} inside the same chains, between E_l and h_l (conv_wino.h: up_fused; oracle/eig_oracle.c: eig_wino_fuse_up):
-                // bit 24 of the switch (EIGEN_WINO_FUSEUP=0 clears it), 16-byte rows at the source resolution, 8-channel K-blocks
-                const bool fuse_bit = (wino_env >> 24) & 1;
-                wino_fuse = fuse_bit && l < L - 1 && (y.W % 8) == 0 && (e->layer[l + 1].C % 8) == 0;
                 const int Cu = wino_fuse ? e->layer[l + 1].C : 0;
                 const float* w3[3][4];
                 for (int g = 0; g < 4; ++g) { w3[0][g] = wx0[g]; w3[1][g] = wino_fuse ? wx1[g] : wh[g]; w3[2][g] = wino_fuse ? wh[g] : nullptr; }
                 const int sc[3] = {2 * C, wino_fuse ? Cu : C, C}, sw[3] = {2 * C, wino_fuse ? Cu : C, C};
                 const int sc0[2] = {C, Cu}, sw0[2] = {2 * C, Cu};
-                // F(4x4, 3x3) (conv_wino4.h; oracle: eig_wino_tile): bit 25, and only where the unpooled source rides in the chains (or there is none)
-                const int wt = (((wino_env >> 25) & 1) && (wino_fuse || l == L - 1)) ? 4 : 2;
+                const int wt = ((wino_env >> 25) & 1) ? 4 : 2;   // F(4x4, 3x3) (conv_wino4.h; oracle: eig_wino_tile)
                 std::vector<float> pw = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 3 : 2, sc, sw, w3, wt);
                 std::vector<float> pw0 = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 2 : 1, sc0, sw0, w3, wt);
                 if (upload(&op.d_wpk, pw.data(), pw.size()) || upload(&t0.d_wpk, pw0.data(), pw0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, Winograd form)", l);
@@ -976,24 +880,12 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
                 if (wino_fuse)
                     for (ConvOp* f : {&op, &t0}) { f->fused = true; f->up_C = Cu; f->up_kb = Cu / KC; }
             }
-            static const int fuse_env = getenv("EIGEN_FUSEUP") ? atoi(getenv("EIGEN_FUSEUP")) : -1;
-            static const int fuse_mask = getenv("EIGEN_FUSEUP_MASK") ? atoi(getenv("EIGEN_FUSEUP_MASK")) : -1;  // bit l: layer l in-kernel (A/B)
-            const double pass_macs = l < L - 1 ? (double)e->B * y.H * y.W * 4 * C * e->layer[l + 1].C * 4 : 0;
-            const bool fuse_up = fuse_mask >= 0 ? ((fuse_mask >> l) & 1) != 0 : (fuse_env >= 0 ? fuse_env != 0 : pass_macs < 2.5e10);
-            const bool fused = fuse_up && !wino && l < L - 1 && op.epi == EPI_LSTM && op.TW == 16 && (op.W % 8) == 0 && KC == 8;
-            if (fused) {
-                const int Cup = e->layer[l + 1].C;
-                std::vector<float> pf = pack_weights_upfuse(C, op.n_nblk, Cup, wx1);
-                if (upload(&y.d_upw, pf.data(), pf.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, fused unpooled source)", l);
-                const double up_macs = (double)y.H * y.W * 4 * C * Cup * 4;  // 4 taps per output pixel and channel instead of 9
-                for (ConvOp* f : {&op, &t0}) { f->fused = true; f->up_C = Cup; f->up_kb = (Cup + KC - 1) / KC; f->macs += up_macs; }
-            }
             ConvOp& u = y.up4;
             { float* k0 = u.d_wpk; u = ConvOp(); u.d_wpk = k0; }
-            if (l < L - 1 && !fused && !wino_fuse) {  // R_{l+1}, at ITS resolution; columns = the ConvLSTM's
+            if (l < L - 1 && !wino) {  // R_{l+1}, at ITS resolution; columns = the ConvLSTM's
                 const Layer& yu = e->layer[l + 1];
                 u.epi = EPI_UP4; u.layer = l; u.nsrc = 1; u.src_C[0] = e->layer[l + 1].C; u.H = yu.H; u.W = yu.W; u.Cout = C;
-                u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W, lstm_mode == 1);
+                u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W);
                 u.krows = pad4(u.src_C[0]) * 4;
                 u.macs = (double)y.H * y.W * 4 * C * u.src_C[0] * 4;  // 4 taps per output pixel and channel instead of 9
                 const size_t need = (size_t)e->B * 4 * u.n_nblk * u.NI * 16 * u.H * u.W;
@@ -1019,7 +911,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             op.epi = EPI_CONVP; op.layer = l; op.nsrc = 1; op.src_C[0] = C;
             op.H = y.H; op.W = y.W; op.Cout = C;
             choose_ni(C, false, &op.NI, &op.n_nblk);
-            op.TW = choose_tw(op.H, op.W, l > 0);
+            op.TW = choose_tw(op.H, op.W);
             op.krows = pad4(C) * 9;
             op.macs = (double)y.H * y.W * C * C * 9;
             const float* sw[3][4] = {{convP_w, nullptr, nullptr, nullptr}, {nullptr}, {nullptr}};
@@ -1197,7 +1089,7 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
                 int k = 0;
                 if (l < L - 1 && y.lstm.fused) {  // R_{l+1} of THIS step: its chain runs inside the ConvLSTM launch
                     a.up_src = off(e->layer[l + 1].h[cur ^ 1], e->layer[l + 1]);
-                    a.up_C = y.lstm.up_C; a.up_kb = y.lstm.up_kb; a.up_wpk = y.d_upw;
+                    a.up_C = y.lstm.up_C; a.up_kb = y.lstm.up_kb;
                 } else if (l < L - 1) {  // R_{l+1} of THIS step, 2x2 form -> partial chains
                     ConvArgs u;
                     memset(&u, 0, sizeof(u));
@@ -1463,7 +1355,7 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
     ConvOp op;
     op.epi = EPI_RAW; op.nsrc = 0; op.H = H; op.W = W; op.Cout = cout;
     choose_ni(cout, false, &op.NI, &op.n_nblk);
-    op.TW = choose_tw(H, W, true);
+    op.TW = choose_tw(H, W);
     op.krows = 0;
     const float* sw[3][4] = {{nullptr}, {nullptr}, {nullptr}};
     ConvArgs a;
@@ -1483,7 +1375,7 @@ static int test_conv_impl(eigen_engine* e, int32_t n_src, const float* const* d_
     float* d_raw4 = nullptr;
     if (n_up) {
         u.epi = EPI_UP4; u.nsrc = 1; u.src_C[0] = cin[i_up]; u.H = H / 2; u.W = W / 2; u.Cout = cout;
-        u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W, true);
+        u.NI = op.NI; u.n_nblk = op.n_nblk; u.TW = choose_tw(u.H, u.W);
         u.krows = pad4(cin[i_up]) * 4;
         const float* uw[4] = {h_w[i_up], nullptr, nullptr, nullptr};
         std::vector<float> pku = pack_weights_up4(u, uw, 0);

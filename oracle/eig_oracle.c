@@ -303,7 +303,7 @@ static void conv_up2x2_chain(float* acc, const float* src, const float* w, int C
     free(w4);
 }
 
-/* ---- Winograd F(2x2, 3x3) form of a 3x3 'same' convolution, fp32, ONE fixed order of operations (the HIP kernel conv_wino.h runs
+/* ---- Winograd F(2x2, 3x3) form of a 3x3 'same' convolution, fp32, ONE fixed order of operations (the HIP kernel conv_wino16.h runs
  * exactly these; eligibility and switch: see eig_wino_op).  Per 2x2 output tile T = (ty, tx), input patch d[4][4] =
  * in[c][2ty-1+i][2tx-1+j] (zeros outside the image):
  *   input transform   t_ij = rows:  t0j = d0j - d2j, t1j = d1j + d2j, t2j = d2j - d1j, t3j = d1j - d3j   (B^T d)
@@ -508,6 +508,13 @@ static int eig_wino_op(int wino_mask, int kind, int l, int Cin, int Cout, int H,
  * Needs 16-byte rows at the source resolution (W % 8 == 0) and a multiple of 8 source channels; same rule in eigen_engine.hip. */
 static int eig_wino_fuse_up(int wino_mask, int l, int L, int W, int Cup) { return ((wino_mask >> 24) & 1) && l < L - 1 && (W % 8) == 0 && (Cup % 8) == 0; }
 
+/* A ConvLSTM takes the Winograd form when its operator shape is eligible AND -- below the top layer -- its unpooled source can ride in the same chains (round 6: the
+ * form "Winograd chains + a separate 2x2-form chain" and the eight-wave kernel that ran it are gone; such an operator is a direct one, in the engine and here). */
+static int eig_wino_lstm(int wino_mask, int l, int L, int C, int H, int W, int Cup)
+{
+    return eig_wino_op(wino_mask, 0, l, C, C, H, W, l == L - 1) && (l == L - 1 || eig_wino_fuse_up(wino_mask, l, L, W, Cup));
+}
+
 /* exported for kernel-level tests: out[Cout][H][W] = Winograd chain over the listed full-resolution sources (canonical order) */
 int eig_oracle_wino_chain_m(int ns, const float* const* src, const int* cin, const float* const* w, int Cout, int H, int W, float* out, int m)
 {
@@ -683,9 +690,9 @@ static void prednet_step(prednet_t* n, const float* x)
         if (n->order == 1) { lstm_reference_order(n, l); goto predict; }
         memset(n->gate, 0, sizeof(float) * 4 * C * hw);
         /* one chain over the full-resolution sources E_l, h_l (ConvLSTM.__call__: x_*0, h_*) ... */
-        if (eig_wino_op(n->wino_mask, 0, l, C, C, H, W, l == L - 1)) {  /* ... in its Winograd form: 16 chains per 2x2 tile */
-            const int fuse = l < L - 1 && eig_wino_fuse_up(n->wino_mask, l, L, W, n->ch[l + 1]);
-            const int wm = (fuse || l == L - 1) ? eig_wino_tile(n->wino_mask, 0) : 2;   /* (F(4x4) only where the unpooled source rides in the chains, or there is none) */
+        if (eig_wino_lstm(n->wino_mask, l, L, C, H, W, l < L - 1 ? n->ch[l + 1] : 0)) {  /* ... in its Winograd form: (m + 2)^2 chains per m x m tile */
+            const int fuse = l < L - 1;   /* (below the top layer the Winograd form exists only with the unpooled source inside the chains: eig_wino_lstm) */
+            const int wm = eig_wino_tile(n->wino_mask, 0);
             const size_t mf = wino_m_floats(C, H, W, wm);
             float* M = (float*)calloc(4 * mf, sizeof(float));   /* the chains of each of the four gates */
             float* V;
@@ -712,7 +719,7 @@ static void prednet_step(prednet_t* n, const float* x)
         for (int g = 0; g < 4; g++) conv3x3_chain(n->gate + (size_t)g * C * hw, n->pad, n->wh[l][g], C, C, H, W);
         }
         /* ... plus the chain of the unpooled R_{l+1} (x_*1; 2x2 form, see the header): one fp32 addition */
-        if (l < L - 1 && !(eig_wino_op(n->wino_mask, 0, l, C, C, H, W, 0) && eig_wino_fuse_up(n->wino_mask, l, L, W, n->ch[l + 1]))) { /* h[l+1] already holds R_{l+1} of this step */
+        if (l < L - 1 && !eig_wino_lstm(n->wino_mask, l, L, C, H, W, n->ch[l + 1])) { /* (direct form only) h[l+1] already holds R_{l+1} of this step */
             memset(n->up, 0, sizeof(float) * 4 * C * hw);
             for (int g = 0; g < 4; g++) conv_up2x2_chain(n->up + (size_t)g * C * hw, n->h[l + 1], n->wx1[l][g], C, n->ch[l + 1], H, W);
             for (size_t i = 0; i < 4 * C * hw; i++) n->gate[i] = n->gate[i] + n->up[i];

@@ -222,8 +222,9 @@ print("FRAMES", *out)
 
 
 def test_specialised_operators_equal_the_general_mfma_path(cuda):
-    """Every A/B switch of the engine (step-0 operators, single-K-block ConvA, one-block 2x2 pass, the two direct image-layer
-    kernels, the in-kernel chain of the unpooled source) turned off one at a time in a fresh process: all six PredNet frames of three small roll-outs are byte-identical."""
+    """Every A/B switch of the engine that must NOT change a bit (step-0 operators, single-K-block ConvA, one-block 2x2 pass, the two direct image-layer
+    kernels, the eight-wave direct ConvA, the tile order, how many N-blocks of a tile a block of the F(4x4) kernel walks) set one at a time in a fresh process: all
+    six PredNet frames of three small roll-outs are byte-identical."""
     import subprocess
     script = _FRAMES_SCRIPT % {"root": ROOT}
 
@@ -237,17 +238,12 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
         return line[0]
 
     base = run({})
-    # round 3: the eight-wave instantiations (chosen by launch size: these small roll-outs take them by default) forced off / on
-    # for every operator class, with and without the separate 2x2 pass
-    # (round 5: the side stream, the two-streams-per-population pipeline and the schedule variants of the eight-wave Winograd kernel lost their A/Bs and are gone;
-    #  EIGEN_TILE_MAP: the block order of the kernels, 0 / 1 and the F(4x4) kernel's N-blocks-in-flight values)
-    envs = [{sw: "1"} for sw in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA", "EIGEN_FUSEUP")]
-    envs += [{"EIGEN_W8": "0"}, {"EIGEN_W8": "31", "EIGEN_FUSEUP": "0"},
-             {"EIGEN_H4": "1", "EIGEN_W8": "31", "EIGEN_FUSEUP": "0"}, {"EIGEN_H4": "0", "EIGEN_W8": "31"},  # half blocks forced on / off
-             {"EIGEN_NO_TW4": "1"},                                                                          # 4-column strips off: 8 x 8 tiles on the 20 x 16 maps
-             {"EIGEN_TILE_MAP": "0"}, {"EIGEN_TILE_MAP": "1"}, {"EIGEN_TILE_MAP": "3"}]
+    # (round 5: the side stream, the two-streams-per-population pipeline and the schedule variants of the eight-wave Winograd kernel lost their A/Bs; round 6: the
+    #  half-block / 4-column-strip / in-kernel-2x2-chain instantiations of the direct kernel and the eight-wave Winograd kernel went the same way.)
+    envs = [{sw: "1"} for sw in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA")]
+    envs += [{"EIGEN_W8": "0"}, {"EIGEN_W8": "1"}, {"EIGEN_TILE_MAP": "0"}, {"EIGEN_TILE_MAP": "1"},
+             {"EIGEN_W4_PARTS": "1"}, {"EIGEN_W4_PARTS": "2"}, {"EIGEN_W4_PARTS": "99"}]   # the walk of the F(4x4) kernel: all N-blocks of a tile in one block ... one block per N-block
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=4) as pool:   # (fresh processes sharing the one GPU: the runs are tiny)
         for env, got in zip(envs, pool.map(run, envs)):
             assert got == base, env
-    assert run({"EIGEN_FUSEUP": "0"}) == base  # these small roll-outs take the in-kernel chain by default: the separate pass

@@ -144,23 +144,13 @@ def test_cppn_render_saturating_bands_byte_exact(cuda, oracle_lib, w, h, structu
 @pytest.mark.parametrize("w,h,ch,requant", [(64, 64, [1, 16, 32, 64], False), (48, 32, [3, 8, 16, 32], False),
                                               (80, 40, [3, 12, 20], True), (160, 120, [1, 16, 32, 64], False),
                                               (20, 12, [1, 4, 8], False),   # widths 20 / 10 / 5: mixed VEC and 4-byte DMA layers
-                                              # the unpooled source's chain INSIDE the ConvLSTM kernel (FUSE): partial last K-block
-                                              # (12 channels) with ragged tile rows (layer 1: 80 x 60 = 3.75 tiles), one-K-block source (8)
+                                              # direct ConvLSTMs with a 12-channel unpooled source (partial last K-block of the 2x2-form pass), ragged tile rows
+                                              # (layer 1: 80 x 60 = 3.75 tiles), one-K-block source (8)
                                               (160, 120, [1, 8, 12, 8], False), (64, 96, [1, 8, 12, 8], True),
-                                              # five layers, 20 x 16 maps at layer 3: ConvA_4 / ConvLSTM_3 / ConvP_3 / the 2x2 pass of layer 2 on 4-wide strips
+                                              # five layers, 20 x 16 maps at layer 3 (8 x 8 tiles)
                                               (160, 128, [1, 4, 8, 8, 8], False)])
 def test_prednet_rollout_frames_bit_exact(cuda, oracle_lib, w, h, ch, requant, monkeypatch):
     import torch
-    if ch == [1, 8, 12, 8]:
-        # the in-kernel form of the unpooled source's chain (conv_mfma.h: FUSE) is chosen automatically for short passes; force it
-        # here (the switch is read once per process, when the first weights are set -> a child process)
-        import os, subprocess, sys
-        if os.environ.get("EIGEN_FUSEUP") != "1":
-            env = dict(os.environ, EIGEN_FUSEUP="1")
-            r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", __file__, "-k",
-                                "test_prednet_rollout_frames_bit_exact and %d-%d-ch" % (w, h)], env=env, capture_output=True, text=True, timeout=1200)
-            assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-            return
     from oracle import cppn
     c_dim = ch[0]
     cfg, pop, grid = _render_setup(w, h, c_dim, 3, seed=11)
@@ -454,24 +444,23 @@ print("WINO_OK" if ok else "WINO_FAIL")
 """
 
 
-@pytest.mark.parametrize("switch", ["14", None, "0x0E0E00", "0x0100000E", "0x01FFFFFE", "wino16=0", "0x03FFFFFE", "0x0DFEFEFE"])
+@pytest.mark.parametrize("switch", [None, "parts=1", "parts=99", "0x03FFFFFE", "0x0DFEFEFE", "0x01FFFFFE", "14", "0x0E0E00", "0x0100000E"])
 def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
-    """The Winograd F(2x2, 3x3) form of the 3x3 convolutions (csrc/conv_wino.h) against the oracle's statement of exactly that arithmetic
-    (eig_oracle.c: wino_*; the oracle follows the same environment switch): all frames of four small roll-outs, bit for bit -- incl.
-    step-0 operators (one source), ragged tiles, a top layer without an unpooled source, the 20 x 15 top layer of 160 x 120 (odd
-    height), N-blocks of 48 and 64 columns.  EIGEN_WINOGRAD=14: the ConvLSTMs of layers 1-3 only; unset: the default = every eligible
-    ConvLSTM / ConvA / ConvP with the unpooled source inside the ConvLSTM's chains; 0x0E0E00: ConvA and ConvP only; 0x0100000E: the ConvLSTMs
-    with their unpooled source fused, everything else direct.  The ConvLSTMs run on the sixteen-wave kernel (csrc/conv_wino16.h) wherever it
-    applies; "wino16=0": the default operators with the eight-wave ConvLSTM kernel (EIGEN_WINO16=0) -- same arithmetic, same bits;
-    unset (the default, 0x0FFFFFFE): every eligible operator as Winograd F(4x4, 3x3) (csrc/conv_wino4.h; bits 25 / 26 / 27 = ConvLSTM / ConvA /
-    ConvP) -- ANOTHER canonical order, which the oracle states and follows through the same mask; 0x03FFFFFE: the ConvLSTMs only; 0x0DFEFEFE: ConvA and ConvP in
-    F(4x4), the ConvLSTMs in F(2x2) without the fused unpooled source."""
+    """The Winograd forms of the 3x3 convolutions against the oracle's statement of exactly that arithmetic (eig_oracle.c: wino_*, wino4_*; the oracle follows the
+    same environment switch): all frames of four small roll-outs, bit for bit -- incl. step-0 operators (one source), ragged tiles, a top layer without an unpooled
+    source, the 20 x 15 top layer of 160 x 120 (odd height), N-blocks of 48 and 64 columns.
+    None = THE DEFAULT (0x0FFFFFFE): every eligible ConvLSTM / ConvA / ConvP as Winograd F(4x4, 3x3) on the twelve-wave kernel (csrc/conv_wino4.h), the unpooled source
+    inside the ConvLSTM's chains; "parts=1" / "parts=99": the same with a block of that kernel walking ALL N-blocks of its tile / exactly one (EIGEN_W4_PARTS: the
+    launch geometry must not show in a single bit); 0x03FFFFFE: only the ConvLSTMs in F(4x4), ConvA / ConvP in F(2x2); 0x0DFEFEFE: ConvA and ConvP in F(4x4), the
+    ConvLSTMs direct except the top one (bit 24 clear: below the top layer a ConvLSTM is a Winograd operator only with its unpooled source inside the chains) in F(2x2).
+    0x01FFFFFE: everything in F(2x2, 3x3) on the sixteen-wave kernel (csrc/conv_wino16.h; the round-4 default); 14: the ConvLSTM bits of layers 1-3 alone (top layer
+    only, see above); 0x0E0E00: ConvA and ConvP only; 0x0100000E: the ConvLSTMs with their unpooled source fused, everything else direct."""
     import subprocess
     env = dict(os.environ)
     env.pop("EIGEN_WINOGRAD", None)
-    env.pop("EIGEN_WINO16", None)
-    if switch == "wino16=0":
-        env["EIGEN_WINO16"] = "0"
+    env.pop("EIGEN_W4_PARTS", None)
+    if switch is not None and switch.startswith("parts="):
+        env["EIGEN_W4_PARTS"] = switch.split("=")[1]
         switch = None
     if switch is not None:
         env["EIGEN_WINOGRAD"] = switch

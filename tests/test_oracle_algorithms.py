@@ -119,7 +119,7 @@ def test_oracle_threads_do_not_change_a_bit(oracle_lib):
 
 
 def test_winograd_statement_is_the_same_convolution(oracle_lib):
-    """oracle/eig_oracle.c: wino_* (the canonical arithmetic of the operators csrc/conv_wino.h takes) IS the 3x3 'same' convolution: against a
+    """oracle/eig_oracle.c: wino_* (the canonical arithmetic of the operators csrc/conv_wino16.h / conv_wino4.h take) IS the 3x3 'same' convolution: against a
     float64 reference it is as accurate as the direct fma chain (F(2x2, 3x3) in fp32: ~1e-6 relative), on even and on odd heights (a
     20 x 15 top-layer map), with several chained sources; and a roll-out under any switch setting stays within fp32 round-off of the
     direct one -- the switch selects a summation order, never a different function."""
