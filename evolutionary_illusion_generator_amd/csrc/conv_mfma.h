@@ -866,7 +866,10 @@ conv3x3_mfma(const ConvArgs a)
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             float* dst;
-            if (EPI == EPI_UP4C) dst = a.raw + (((size_t)eb * 4 + ni) * a.n_nblk * 16 + nblk * 16 + col) * HW;  // N-tile ni is class ni of the 16 output columns
+            if (EPI == EPI_UP4C) {   // N-tile ni is class ni of the 16 output columns; column = gate * 4 + channel of the packed ConvLSTM: channels >= Cout are never read
+                if ((col & 3) >= a.Cout) continue;
+                dst = a.raw + (((size_t)eb * 4 + ni) * a.n_nblk * 16 + nblk * 16 + col) * HW;
+            }
             else if (EPI == EPI_UP4) dst = a.raw + (((size_t)eb * 4 + cls) * a.n_nblk * NB + nblk * NB + ni * 16 + col) * HW;
             else {
                 const int o = nblk * NB + ni * 16 + col;
@@ -1105,7 +1108,7 @@ conv3x3_mfma(const ConvArgs a)
 // pixel and channel).  One thread per pixel, all C outputs; the haloed tile goes through LDS.  Arithmetic = the same fp32
 // fma chain in (channel, ky, kx) order as the MFMA path (out-of-image taps multiply a staged 0, as there), then the
 // epilogue of EPI_CONVP verbatim, so the results are bit-identical.
-constexpr int P0_TX = 64, P0_TY = 4;
+constexpr int P0_TX = 64, P0_TY = 8;
 template <int C>
 __global__ void __launch_bounds__(P0_TX * P0_TY) convp0_direct_kernel(const float* __restrict__ src, const float* __restrict__ wgt /*[C][C][3][3]*/,
                                                                      const ConvArgs a)
@@ -1158,13 +1161,18 @@ __global__ void __launch_bounds__(P0_TX * P0_TY) convp0_direct_kernel(const floa
 // out-of-image taps multiply a staged 0 -- adds the chain of the unpooled source (one fp32 addition, ConvArgs::acc_init: class
 // (y & 1, x & 1) of source pixel (y / 2, x / 2), column = gate * 4 + channel as the packed MFMA layout has it) and runs the gate
 // epilogue of EPI_LSTM_PACKED verbatim: bit-identical results.  T0: the step-0 operator (first half of E_0 only, no h_0).
-// wgt: [4 gates][C][2C][9] for E_0 followed by [4][C][C][9] for h_0 (OIHW per gate, as the weight table holds them).
-constexpr int L0_TX = 64, L0_TY = 4;
+// The FOUR GATE chains of an output channel run side by side (round 6): a staged value is read from LDS once per output channel and multiplied into four
+// accumulators by the four gate weights of its tap, which lie together in the packed weight table wgt: [C outputs][K taps = (channel, ky, kx) over E_0 then h_0][4 gates]
+// (T0: the table of the step-0 operator behind it) -- 243 LDS reads per pixel instead of 972 (the kernel was LDS-bound: 972 reads x 2 clocks per wave at 1024 waves per
+// CU = 0.83 ms of its 1.02), one s_load_dwordx4 per tap.  (Measured before: all 12 chains from each staged value 1.21 ms, one chain at a time 1.07 ms, the 81 staged
+// values held in registers 1.44 ms: profiles/r05_f_w4_timeline.txt.)
+constexpr int L0_TX = 64, L0_TY = 8;   // (64 x 8 pixels per block: the haloed tile is 1.29 x the pixels it serves; 64 x 4: 1.55 x)
 template <int C, bool T0>
 __global__ void __launch_bounds__(L0_TX * L0_TY) lstm0_direct_kernel(const float* __restrict__ srcE, const float* __restrict__ srcH,
                                                                     const float* __restrict__ wgt, const ConvArgs a)
 {
     constexpr int CE = T0 ? C : 2 * C, CH = T0 ? 0 : C;
+    constexpr int K = (CE + CH) * 9;
     __shared__ float tile[CE + (CH ? CH : 1)][L0_TY + 2][L0_TX + 2];
     const int tx = threadIdx.x & (L0_TX - 1), ty = threadIdx.x / L0_TX;
     const int x0 = blockIdx.x * L0_TX, y0 = blockIdx.y * L0_TY, b = blockIdx.z;
@@ -1184,34 +1192,27 @@ __global__ void __launch_bounds__(L0_TX * L0_TY) lstm0_direct_kernel(const float
     const int gy = y0 + ty, gx = x0 + tx;
     if (gy >= a.H || gx >= a.W) return;
     const int pix = gy * a.W + gx;
-    const float* wE = wgt;
-    const float* wH = wgt + 4 * C * 2 * C * 9;
+    const f32x4* const w4 = reinterpret_cast<const f32x4*>(wgt) + (T0 ? C * (3 * C * 9) : 0);   // (the step-0 table lies behind the full one)
     const int Hs = a.H >> 1, Ws = a.W >> 1;
     const size_t up_hw = (size_t)Hs * Ws;
     const float* up = a.acc_init ? a.acc_init + (((size_t)b * 4 + ((gy & 1) * 2 + (gx & 1))) * 16) * up_hw + (size_t)(gy >> 1) * Ws + (gx >> 1) : nullptr;
-    // one chain at a time (measured: feeding all 4 x C chains from each staged value is slower -- 972 scalar weight operands
-    // in flight instead of a stream of them: 1.21 vs 1.07 ms per launch; round 5: the 81 staged values of a pixel held in registers across the chains, 81 LDS reads
-    // instead of 972 but 110 VGPRs instead of 56: 1.44 vs 1.08 ms -- half the waves to hide the scalar weight loads behind)
 #pragma unroll
     for (int o = 0; o < C; ++o) {
-        float z[4];
+        float z[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float acc = 0.0f;
+        for (int c = 0; c < CE + CH; ++c)
 #pragma unroll
-            for (int c = 0; c < CE; ++c)
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float v = tile[c][ty + ky][tx + kx];
+                    const f32x4 w = w4[o * K + (c * 3 + ky) * 3 + kx];   // (wave-uniform address: a scalar load)
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) acc = fmaf(tile[c][ty + ky][tx + kx], wE[(((g * C + o) * 2 * C + c) * 3 + ky) * 3 + kx], acc);
+                    for (int g = 0; g < 4; ++g) z[g] = fmaf(v, w[g], z[g]);
+                }
+        if (up) {
 #pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) acc = fmaf(tile[CE + c][ty + ky][tx + kx], wH[(((g * C + o) * C + c) * 3 + ky) * 3 + kx], acc);
-            if (up) acc = acc + up[(size_t)(g * 4 + o) * up_hw];
-            z[g] = acc;
+            for (int g = 0; g < 4; ++g) z[g] = z[g] + up[(size_t)(g * 4 + o) * up_hw];
         }
         const float bi = a.bias[o], bf = a.bias[C + o], bc = a.bias[2 * C + o], bo = a.bias[3 * C + o];
         const size_t cbase = ((size_t)b * C + o) * HW;

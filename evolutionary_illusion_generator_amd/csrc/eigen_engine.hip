@@ -838,12 +838,20 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             for (int g = 0; g < 3; ++g) memcpy(&pp[g * chw], peep[g], sizeof(float) * chw);
             if (upload(&op.d_wpk, pk.data(), pk.size()) || upload(&y.bias_lstm, bias.data(), bias.size()) || upload(&y.peep, pp.data(), pp.size()))
                 return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d)", l);
-            if (op.epi == EPI_LSTM_PACKED && (C == 1 || C == 3)) {  // image layer: raw OIHW weights for lstm0_direct_kernel
-                std::vector<float> raw((size_t)4 * C * 3 * C * 9);
-                for (int g = 0; g < 4; ++g) {
-                    memcpy(&raw[(size_t)g * C * 2 * C * 9], wx0[g], sizeof(float) * C * 2 * C * 9);
-                    memcpy(&raw[(size_t)4 * C * 2 * C * 9 + (size_t)g * C * C * 9], wh[g], sizeof(float) * C * C * 9);
-                }
+            if (op.epi == EPI_LSTM_PACKED && (C == 1 || C == 3)) {  // image layer, lstm0_direct_kernel: [C outputs][K taps = (channel, ky, kx) over E_0 then h_0][4 gates], then the step-0 table (first half of E_0 only)
+                const int K = 3 * C * 9, K0 = C * 9;
+                std::vector<float> raw((size_t)C * K * 4 + (size_t)C * K0 * 4);
+                for (int o = 0; o < C; ++o)
+                    for (int g = 0; g < 4; ++g) {
+                        for (int c = 0; c < 2 * C; ++c)
+                            for (int t9 = 0; t9 < 9; ++t9) {
+                                const float wv = wx0[g][((size_t)o * 2 * C + c) * 9 + t9];
+                                raw[((size_t)o * K + c * 9 + t9) * 4 + g] = wv;
+                                if (c < C) raw[(size_t)C * K * 4 + ((size_t)o * K0 + c * 9 + t9) * 4 + g] = wv;
+                            }
+                        for (int c = 0; c < C; ++c)
+                            for (int t9 = 0; t9 < 9; ++t9) raw[((size_t)o * K + (2 * C + c) * 9 + t9) * 4 + g] = wh[g][((size_t)o * C + c) * 9 + t9];
+                    }
                 if (upload(&op.d_wraw, raw.data(), raw.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d direct)", l);
             }
             ConvOp& t0 = y.lstm_t0;  // step 0: first half of E_l only; h_l = 0 is not read (Layer::lstm_t0)
