@@ -46,16 +46,24 @@ constexpr int W4_NPOS = 36;
 constexpr int W4_UPOS = 256;                        // floats per position of a U slot: 4 ch x 16 cols x NI (NI = 3: 192 used)
 constexpr int W4_U_FLOATS = W4_NPOS * W4_UPOS;      // 36 KB
 constexpr int W4_NUS = 3, W4_NPS = 3;
-constexpr int W4_ROW = 40;                          // floats per plane row: aligned chunks x0-4 .. x0+35
-constexpr int W4_PS = 768;                          // floats per channel plane: 18 rows x 40 = 720 -> three DMA instructions of 256
-// LDS map (floats): plane slots 0, 1 | U slot 0 | X = U slot 1, U slot 2, plane slot 2, 12 KB.  X (96 KB) is the exchange area of the finishing phase: what a walking
-// block prefetches for its next N-block behind the last K-block (U slab of K-block 0, planes of K-blocks 0, 1: 60 KB) lies outside it.
-constexpr int W4_PSLOT = W4_KC * W4_PS;                         // 3072 floats = 12 KB
-constexpr int W4_P0 = 0, W4_P1 = W4_PSLOT, W4_U0 = 2 * W4_PSLOT;
-constexpr int W4_X = W4_U0 + W4_U_FLOATS;                       // 15360
-constexpr int W4_U1 = W4_X, W4_U2 = W4_X + W4_U_FLOATS, W4_P2 = W4_X + 2 * W4_U_FLOATS;
+// Two block shapes (template parameter TALL), chosen per operator by the MAP SIZE alone (eigen_engine.hip: the one that covers the map with fewer blocks, ties -> wide):
+//   wide  16 rows x 32 columns: regions 8 x 32 (2 x 8 tiles, MFMA row r = 8 ty + tx), plane = 18 rows x 10 chunks (row stride 40 floats), 3 DMA parts per channel;
+//   tall  32 rows x 16 columns: regions 16 x 16 (4 x 4 tiles, r = 4 ty + tx), plane = 34 rows x 6 chunks at a row stride of 7 chunks (28 floats: the sixteen 16-byte patch
+//         reads of a lane group -- tiles (ty, tx) at chunk 28 ty + tx -- fall on sixteen different bank slots), 4 DMA parts per channel (waves 0-3 issue a second
+//         instruction), no walk (its plane slots are 16 KB).  Same chains, same order: the shape of the block does not show in a single bit.  What it is for: the reference's
+//         own 160 x 120 -- maps of 80 x 60 / 40 x 30 take 10 / 3 tall blocks where they take 12 / 4 wide ones.
+constexpr int w4_row(bool tall) { return tall ? 28 : 40; }              // floats per plane row
+constexpr int w4_ps(bool tall) { return tall ? 1024 : 768; }            // floats per channel plane (whole DMA parts of 256)
+constexpr int w4_pslot(bool tall) { return W4_KC * w4_ps(tall); }       // 12 KB / 16 KB
+// LDS map (floats).  wide: plane slots 0, 1 | U slot 0 | X = U slot 1, U slot 2, plane slot 2, 12 KB -- X (96 KB) is the exchange area of the finishing phase: what a
+// walking block prefetches for its next N-block behind the last K-block (U slab of K-block 0, planes of K-blocks 0, 1: 60 KB) lies outside it.  tall (no walk): plane
+// slots 0, 1, 2 | U slots 0, 1, 2, the exchange area over the U ring.
+constexpr int w4_p(bool tall, int k) { return tall ? k * w4_pslot(true) : (k < 2 ? k * w4_pslot(false) : 2 * w4_pslot(false) + 3 * W4_U_FLOATS); }
+constexpr int w4_u(bool tall, int k) { return tall ? 3 * w4_pslot(true) + k * W4_U_FLOATS : 2 * w4_pslot(false) + k * W4_U_FLOATS; }
+constexpr int w4_x(bool tall) { return tall ? w4_u(true, 0) : w4_u(false, 1); }
 constexpr int W4_X_FLOATS = W4_WAVES * 2 * 4 * 64 * 4;          // one exchange round = two N-tiles: [12 waves][2][4 e][64 lanes] 16-byte vectors = 96 KB
-constexpr int wino4_lds_bytes() { return (W4_X + W4_X_FLOATS) * 4; }   // 159744
+constexpr int wino4_lds_bytes() { return (w4_x(false) + W4_X_FLOATS) * 4; }   // 159744, both shapes (tall: 3 x 16 KB + 3 x 36 KB)
+static_assert((w4_u(true, 2) + W4_U_FLOATS) * 4 == wino4_lds_bytes() && (w4_p(false, 2) + w4_pslot(false)) * 4 <= wino4_lds_bytes(), "LDS maps");
 constexpr int wino4_u_floats(int NI) { return W4_NPOS * 4 * 16 * NI; }   // one 4-channel K-block of the packed weights: [36 pos][4 ch][16 cols][NI] (the buffer ends in one K-block of padding: the fetch runs one K-block past the end)
 #ifndef EIG_W4_DIAG
 #define EIG_W4_DIAG 0   // measurement builds only (WRONG RESULTS): 1 no wait for the K loop's DMAs, 2 no barrier in the K loop, 4 no A-operand build, 8 no plane DMA, 16 no U DMA
@@ -95,19 +103,22 @@ template <typename V4> __device__ __forceinline__ void w4_out1d(const V4& m0, co
     for (int e = 0; e < 4; ++e) { Y[1][e] = fmaf(2.0f, w[e], d[e]); Y[2][e] = fmaf(4.0f, u[e], s[e]); Y[3][e] = fmaf(8.0f, w[e], d[e]) + m5[e]; }
 }
 
-template <int NI, int EPI>
+template <int NI, int EPI, bool TALL = false>
 __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 {
     static_assert(EPI == EPI_LSTM || EPI == EPI_CONVA || EPI == EPI_CONVP, "conv_wino4.h: ConvLSTM, ConvA, ConvP");
     static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
     static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
     constexpr int U4 = wino4_u_floats(NI);
-    constexpr int KC = W4_KC, PS = W4_PS;
+    constexpr int KC = W4_KC, PS = w4_ps(TALL), W4_ROW = w4_row(TALL);
+    constexpr int W4_P0 = w4_p(TALL, 0), W4_P1 = w4_p(TALL, 1), W4_P2 = w4_p(TALL, 2), W4_U0 = w4_u(TALL, 0), W4_U1 = w4_u(TALL, 1), W4_U2 = w4_u(TALL, 2);
+    constexpr bool WALK = !TALL;                     // (tall blocks: one N-block per block -- with 16 KB plane slots the prefetched part of a next N-block does not fit beside the exchange area)
+    constexpr int RGH = TALL ? 16 : 8;               // rows of a region
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py with EIG_TL_WAVES=12)
     float* const Pb = lds;                          // (slot offsets W4_P0 / W4_P1 / W4_P2, W4_U0 / W4_U1 / W4_U2 are absolute)
     float* const Ub = lds;
-    float* const xb = lds + W4_X;
+    float* const xb = lds + w4_x(TALL);
     const int wv_o = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rg_o = wv_o & 1, xi_o = wv_o >> 1;
     // The lane index, opaque to the compiler: every per-lane quantity of the K loop and of the finishing phase is derived from a FRESH copy at the point of use, so
@@ -127,11 +138,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int part = xi_ - q0 * a.nparts;
     const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + q0 : q0 * 8 + xcd;
     if (tlin >= ntile) return;
-    const int nwalk = a.nwalk, nb0 = part * nwalk;   // this block computes N-blocks nb0 .. nb0 + nwalk - 1 of its tile
+    const int nwalk = WALK ? a.nwalk : 1, nb0 = part * nwalk;   // this block computes N-blocks nb0 .. nb0 + nwalk - 1 of its tile
     const int eb = dv(tlin, tiles, a.mg[1]);
     const int t_ = tlin - eb * tiles;
     const int tyi = dv(t_, a.tilesX, a.mg[2]), txi = t_ - tyi * a.tilesX;
-    const int y0 = tyi * 16, x0 = txi * 32;
+    const int y0 = tyi * (TALL ? 32 : 16), x0 = txi * (TALL ? 16 : 32);
     const int HW = a.H * a.W;
 
     const bool up_fused = EPI == EPI_LSTM && a.up_src != nullptr;
@@ -168,15 +179,21 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
     const int lane = lane_id();
     const int q = lane >> 4, col = lane & 15;
-    int roff, uoff;
-    {
-        const int c = lane + 64 * ppart;
-        const int row = c / 10, cx = c - row * 10;
+    // wide: 18 rows x 10 chunks (unpooled source: 10 rows x 6 chunks at half resolution); tall: 34 rows x 6 chunks at a row stride of 7 (18 rows x 4 chunks), four parts
+    // per channel: waves 0-3 fetch part 3 of channel wv with a second instruction (roff2 / uoff2)
+    constexpr int CPR = TALL ? 7 : 10, CREAL = TALL ? 6 : 10, NCHK = TALL ? 34 * 7 : 180, UROWS = TALL ? 18 : 10, UCHK = TALL ? 4 : 6;
+    auto plane_offsets = [&](int part, int& ro, int& uo) __attribute__((always_inline)) {
+        const int c = lane + 64 * part;
+        const int row = c / CPR, cx = c - row * CPR;
         const int gy = y0_i - 1 + row, gx = x0_i - 4 + 4 * cx;
-        roff = (c < 180 && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : -1;
+        ro = (c < NCHK && cx < CREAL && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) ? (gy * a.W + gx) * 4 : -1;
         const int hy = (y0_i >> 1) - 1 + row, hx = (x0_i >> 1) - 4 + 4 * cx;
-        uoff = (row < 10 && cx < 6 && hy >= 0 && hy < Hh && hx >= 0 && hx < Wh) ? (hy * Wh + hx) * 4 : -1;
-    }
+        uo = (row < UROWS && cx < UCHK && hy >= 0 && hy < Hh && hx >= 0 && hx < Wh) ? (hy * Wh + hx) * 4 : -1;
+    };
+    int roff, uoff, roff2 = -1, uoff2 = -1;
+    plane_offsets(ppart, roff, uoff);
+    const bool two_parts = TALL && wv_o < 4;   // (wave-uniform)
+    if (TALL) plane_offsets(3, roff2, uoff2);
     auto dma_plane_at = [&](int jj, int slot_off) __attribute__((always_inline)) {   // (prologue) this wave's plane DMA of K-block min(jj, nkb - 1) -> the plane slot at float offset slot_off
         const int j = jj < nkb ? jj : nkb - 1;
         const bool up = EIG4_IS_UP(j);
@@ -191,7 +208,14 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         const unsigned coff = (unsigned)((j - base) * KC + pch) * (unsigned)(hw * 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + pch * PS + ppart * 256), 16,
                                                  (int)__builtin_elementwise_add_sat((unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (unsigned)mu), coff), 0, 0, 0);
+        if (two_parts) {
+            const unsigned coff2 = (unsigned)((j - base) * KC + wv) * (unsigned)(hw * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + wv * PS + 3 * 256), 16,
+                                                     (int)__builtin_elementwise_add_sat((unsigned)roff2 + (((unsigned)uoff2 - (unsigned)roff2) & (unsigned)mu), coff2), 0, 0, 0);
+        }
     };
+    // "the U fetch of this K-block has landed, its plane fetch (one instruction, two for waves 0-3 of a tall block) may stay in flight"
+    auto wait_u = [&]() __attribute__((always_inline)) { if (two_parts) EIG4_WAITCNT(0x0F72); else EIG4_WAITCNT(0x0F71); };
     // ---- U fetch (every wave: positions 3 wv .. 3 wv + 2 of the next K-block in line): one position of a packed 4-channel K-block = one contiguous KB (NI = 3: 768 B).
     // The scalar offset runs along the packed K-blocks (no index arithmetic in the K loop; the last two fetches read the next N-block's first K-blocks or the
     // buffer's padding into slots nobody reads).
@@ -216,10 +240,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         dma_plane_at(2, W4_P2);
     };
 
-    // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) = (col >> 3, col & 7) of region rg (rows 8 rg .. 8 rg + 7 of the block; MFMA row r = 8 ty + tx)
-    const int t_ty = col >> 3, t_tx = col & 7;
-    const float* const pbase_n = Pb + q * PS + (8 * rg + 4 * t_ty) * W4_ROW + 4 * t_tx;        // patch row 0, the aligned chunk that holds patch column 0 in its last float: columns 0 .. 5 = floats 3 .. 8
-    const float* const pbase_u = Pb + q * PS + (4 * rg + 2 * t_ty) * W4_ROW + 2 * t_tx + 3;    // source row s, column s of an unpooled patch (half-resolution plane)
+    // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) of region rg (rows RGH rg .. of the block): wide (col >> 3, col & 7), MFMA row r = 8 ty + tx;
+    // tall (col >> 2, col & 3), r = 4 ty + tx
+    const int t_ty = TALL ? col >> 2 : col >> 3, t_tx = TALL ? col & 3 : col & 7;
+    const float* const pbase_n = Pb + q * PS + (RGH * rg + 4 * t_ty) * W4_ROW + 4 * t_tx;        // patch row 0, the aligned chunk that holds patch column 0 in its last float: columns 0 .. 5 = floats 3 .. 8
+    const float* const pbase_u = Pb + q * PS + ((RGH / 2) * rg + 2 * t_ty) * W4_ROW + 2 * t_tx + 3;    // source row s, column s of an unpooled patch (half-resolution plane)
     const int b_off = xi * 6 * W4_UPOS + (q * 16 + col) * NI;   // U[pos = 6 xi + nu][ch = q][col][0 .. NI)
 
     unsigned long long tq_setup = tq_entry;
@@ -297,6 +322,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)phi << 32) | plo), 0, psz, 0x00020000);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + pch * PS + ppart * 256), 16,
                                                      (int)__builtin_elementwise_add_sat(o, pcoff), 0, 0, 0);
+            if (two_parts) {
+                const unsigned o2 = (unsigned)roff2 + (((unsigned)uoff2 - (unsigned)roff2) & (0u - (unsigned)pup));
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + wv * PS + 3 * 256), 16,
+                                                         (int)__builtin_elementwise_add_sat(o2, pcoff + (unsigned)(wv - pch) * phw4), 0, 0, 0);
+            }
             if (__builtin_expect(pj + 1 == pbound, 0)) { if (pbound < nkb) plane_source(pj + 1); }   // (at the end the cursor stays on the last K-block)
             else { ++pj; pcoff += KC * phw4; }
         };
@@ -419,7 +449,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             { const int t0 = po0; po0 = po1; po1 = po2; po2 = t0; }
             // the U fetch of this K-block has landed (its plane fetch may stay in flight: it is read two K-blocks from now); after the last K-block: everything
             if (LAST || (EIG_W4_DIAG & (8 | 16))) EIG4_WAITCNT(0x0F70);
-            else if (!(EIG_W4_DIAG & 2)) { if (!(EIG_W4_DIAG & 1)) EIG4_WAITCNT(0x0F71); }
+            else if (!(EIG_W4_DIAG & 2)) { if (!(EIG_W4_DIAG & 1)) wait_u(); }
             if (!(EIG_W4_DIAG & 2) || LAST) EIG4_BARRIER();
             if constexpr (FIRST) read_b(uo0, 0, bq);
         };
@@ -476,10 +506,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int lane = lane_id();
     const int q = lane >> 4, col = lane & 15;
     const size_t cHW = (size_t)HWf;
-    const int j = lane & 7, chl = lane >> 3, e_r = j & 3, ql = j >> 2;   // finishing lane: chunk j of the block row, channel 8 chh + chl (see below)
+    // finishing lane: chunk j of the block row (= tile column tx = j), channel 8 chh + chl (wide: 8 chunks per row, 8 channels per unit; tall: 4 chunks, all 16 channels)
+    const int j = TALL ? lane & 3 : lane & 7, chl = TALL ? lane >> 2 : lane >> 3, e_r = j & 3, ql = TALL ? 0 : j >> 2;
     int woff[4];                                                           // publishing lane (q, col): its slot in plane e
 #pragma unroll
-    for (int e = 0; e < 4; ++e) woff[e] = ((wv * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + 8 * (q & 1)) & 15)) * 4;
+    for (int e = 0; e < 4; ++e) woff[e] = ((wv * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + (TALL ? 0 : 8 * (q & 1))) & 15)) * 4;
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
         // All twelve waves finish outputs, and they finish them in IMAGE order: the exchange is laid out so that a finishing lane reads the four pixels b = 0..3 of ONE tile
         // as a 16-byte vector, and finishing lane L takes the 16-byte chunk j = L & 7 of a 32-pixel block row (tile tx = j, writer lane q = 2 ty + (j >> 2), register e =
@@ -491,9 +522,9 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         const int nun = xi < 4 ? 3 : 2;
         int xoff[3];
 #pragma unroll
-        for (int un = 0; un < 3; ++un) {
-            const int ty = xi < 4 ? (un >> 1) : 1, chh = xi < 4 ? (un & 1) : 1;
-            xoff[un] = (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
+        for (int un = 0; un < 3; ++un) {   // (tall: MFMA row r = 4 ty + tx -- the writer lane group q IS the tile row, a unit = one of the four tile rows for all 16 channels)
+            const int ty = TALL ? (xi < 4 ? un : 3) : (xi < 4 ? (un >> 1) : 1), chh = TALL ? 0 : (xi < 4 ? (un & 1) : 1);
+            xoff[un] = TALL ? (e_r * 64 + ty * 16 + ((chl + 4 * e_r) & 15)) * 4 : (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
         }
         auto finish = [&](int arow, int nr, int off) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3
             auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + ((x * 2 + rg) * 2 + nr) * 1024 + off); };
@@ -549,9 +580,9 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 #pragma unroll
         for (int un = 0; un < 3; ++un) {
             if (un >= nun) break;
-            const int ty = xi < 4 ? (un >> 1) : 1, chh = xi < 4 ? (un & 1) : 1;
+            const int ty = TALL ? (xi < 4 ? un : 3) : (xi < 4 ? (un >> 1) : 1), chh = TALL ? 0 : (xi < 4 ? (un & 1) : 1);
             const int arow = xi < 4 ? xi : 2 * (xi - 4) + un;
-            const int gy = y0 + 8 * rg + 4 * ty + arow, gx = x0 + 4 * j;
+            const int gy = y0 + RGH * rg + 4 * ty + arow, gx = x0 + 4 * j;
             if (gy >= a.H || gx >= a.W) continue;
             const size_t pix = (size_t)gy * a.W + gx;
             if constexpr (EPI == EPI_LSTM) {
@@ -618,8 +649,9 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             for (int un = 0; un < 3; ++un) {
                 if (un >= cnt) break;
                 const int g = g0 + un;
-                const int nr = g >> 3, ty = (g >> 2) & 1, ap = (g >> 1) & 1, chh = g & 1;
-                const int off = ((nr + 2 * rg) * 256 + e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
+                const int nr = g >> 3, ty = TALL ? (g >> 1) & 3 : (g >> 2) & 1, ap = TALL ? g & 1 : (g >> 1) & 1, chh = TALL ? 0 : g & 1;
+                const int off = TALL ? ((nr + 2 * rg) * 256 + e_r * 64 + ty * 16 + ((chl + 4 * e_r) & 15)) * 4
+                                     : ((nr + 2 * rg) * 256 + e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
                 auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + x * 4096 + off); };
                 const f32x4 c1 = C(1), c2 = C(2), c3 = C(3), c4 = C(4);
                 const f32x4 s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
@@ -633,7 +665,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                     for (int b = 0; b < 4; ++b) { ya[b] = fmaf(4.0f, u_[b], s_[b]); yb[b] = fmaf(8.0f, w_[b], d_[b]) + c5[b]; }
                 }
                 const int ch = (nblk * NI + 2 * rnd + nr) * 16 + 8 * chh + chl;
-                const int oy = (y0 >> 1) + 4 * rg + 2 * ty + ap;
+                const int oy = (y0 >> 1) + (RGH / 2) * rg + 2 * ty + ap;
                 if (oy >= Ho || ox >= Wo || ch >= Cout) continue;
                 const float bb_ = a.bias[ch];
                 const size_t pb = ((size_t)eb * Cout + ch) * plane + (size_t)oy * Wo + ox;

@@ -512,8 +512,12 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     if (op.wino) {  // Winograd form: F(4x4, 3x3) conv_wino4.h (twelve waves), F(2x2, 3x3) conv_wino16.h (sixteen waves)
         if (op.wino_tile == 4) {   // 16 x 32-pixel blocks, twelve waves
             if (op.epi == EPI_LSTM && a.acc_init != nullptr) return hipErrorInvalidConfiguration;   // (set_weights never pairs F(4x4) with a separate unpooled chain)
+            // Block shape (conv_wino4.h): 16 rows x 32 columns, or 32 x 16 ("tall") where that covers the MAP with fewer blocks -- 80 x 60: 10 instead of 12, 40 x 30: 3
+            // instead of 4 (the reference's 160 x 120); a function of the operator's map size alone, and the chains do not depend on it.  EIGEN_W4_TALL = 0 / 1 forces it (A/B, tests).
+            static const int tall_env = getenv("EIGEN_W4_TALL") ? atoi(getenv("EIGEN_W4_TALL")) : -1;
+            const bool tall = tall_env >= 0 ? tall_env != 0 : ((op.W + 15) / 16) * ((op.H + 31) / 32) < ((op.W + 31) / 32) * ((op.H + 15) / 16);
             auto go4 = [&](auto kern) {
-                a.tilesX = (op.W + 31) / 32; a.tilesY = (op.H + 15) / 16;
+                a.tilesX = tall ? (op.W + 15) / 16 : (op.W + 31) / 32; a.tilesY = tall ? (op.H + 31) / 32 : (op.H + 15) / 16;
                 const int ntile4 = batch * a.tilesX * a.tilesY;
                 // WALK (conv_wino4.h): nparts blocks per tile, each computing nwalk = n_nblk / nparts consecutive N-blocks of it.  Two blocks per tile where n_nblk is even
                 // (they share the tile's planes through the XCD's L2, as two N-blocks in flight per tile did in round 5: profiles/r05_e_tile_map.txt), one otherwise; more
@@ -524,6 +528,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
                 if (parts_env > 0) nparts = std::min(parts_env, op.n_nblk);
                 else while (nparts < op.n_nblk && (long long)nparts * ntile4 < 4ll * e->n_cu) ++nparts;
                 while (op.n_nblk % nparts) parts_env > 0 ? --nparts : ++nparts;
+                if (tall) nparts = op.n_nblk;   // (tall blocks do not walk)
                 a.nparts = nparts; a.nwalk = op.n_nblk / nparts;
                 const int g4 = nparts * ((ntile4 + 7) / 8) * 8;
                 {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
@@ -543,9 +548,15 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
 #endif
                 hipLaunchKernelGGL(kern, dim3(g4), dim3(W4_THREADS), wino4_lds_bytes(), st, a);
             };
-            if (op.epi == EPI_LSTM) go4(wino4_kernel<4, EPI_LSTM>);
-            else if (op.epi == EPI_CONVA) { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVA>); else go4(wino4_kernel<3, EPI_CONVA>); }
-            else { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVP>); else go4(wino4_kernel<3, EPI_CONVP>); }
+            if (tall) {
+                if (op.epi == EPI_LSTM) go4(wino4_kernel<4, EPI_LSTM, true>);
+                else if (op.epi == EPI_CONVA) { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVA, true>); else go4(wino4_kernel<3, EPI_CONVA, true>); }
+                else { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVP, true>); else go4(wino4_kernel<3, EPI_CONVP, true>); }
+            } else {
+                if (op.epi == EPI_LSTM) go4(wino4_kernel<4, EPI_LSTM>);
+                else if (op.epi == EPI_CONVA) { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVA>); else go4(wino4_kernel<3, EPI_CONVA>); }
+                else { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVP>); else go4(wino4_kernel<3, EPI_CONVP>); }
+            }
         } else {
             a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
             const int nt = batch * a.tilesX * a.tilesY;
