@@ -217,6 +217,11 @@ for (w, h, ch) in [(64, 64, [3, 12, 24, 48]), (96, 64, [1, 8, 16]), (80, 64, [1,
     e.prednet_rollout(d, B, 6, 0, fr)
     torch.cuda.synchronize()
     out.append(hashlib.sha256(fr.cpu().numpy().tobytes()).hexdigest())
+    for rep in range(2):   # the same buffers again: a roll-out leaves nothing behind that changes the next one (reset_state)
+        fr.zero_()
+        e.prednet_rollout(d, B, 6, 0, fr)
+        torch.cuda.synchronize()
+        assert hashlib.sha256(fr.cpu().numpy().tobytes()).hexdigest() == out[-1], "roll-out %%d of the same buffers differs" %% (rep + 2)
 print("FRAMES", *out)
 """
 
