@@ -160,7 +160,10 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     // ---- plane fetch (every wave: channel wv / 3 of the K-block, part wv % 3 of its plane): lane = 16-byte chunk of the 18 x 10-chunk haloed plane (unpooled source:
     // 10 rows x 6 chunks at half resolution, row stride 10 chunks); rows / chunks outside the image are out of the descriptor's range through a saturating add = zeros
     constexpr unsigned W4_POSB = 4 * 16 * NI * 4;   // bytes per position of a packed K-block
-    for (int it = 0; it < nwalk; ++it) {
+    // One N-block of the walk, as a lambda called from the loop below.  (Written as the loop's body the same code kept 7 VGPRs in scratch -- K-loop lane invariants reloaded
+    // inside the K loop -- and 30 SGPRs in VGPR lanes; as a lambda: 158 VGPRs, nothing in scratch.  Called three times with compile-time indices, i.e. the walk as
+    // straight-line code: 157 VGPRs and 0.6 % SLOWER, profiles/r06_m_walk_clean_ab.txt.)
+    auto walk_body = [&](const int it) __attribute__((always_inline)) {
     const int nblk = nb0 + it;
     // An opaque zero: the scalars of a phase are derived from the wave index, the K-block counts and the tile coordinates offset by it INSIDE the walk, so that the
     // compiler does not hoist the LDS addresses of every DMA instruction, the source selection of the prologue and of the K loops' six role variants and the address
@@ -687,7 +690,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     }
     }
     timeline();
-    }   // walk
+    };   // walk_body
+    for (int it = 0; it < nwalk; ++it) walk_body(it);
 #undef EIG4_WAITCNT
 #undef EIG4_BARRIER
 #undef EIG4_LDS_BARRIER

@@ -516,20 +516,23 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             // instead of 4 (the reference's 160 x 120); a function of the operator's map size alone, and the chains do not depend on it.  EIGEN_W4_TALL = 0 / 1 forces it (A/B, tests).
             static const int tall_env = getenv("EIGEN_W4_TALL") ? atoi(getenv("EIGEN_W4_TALL")) : -1;
             const bool tall = tall_env >= 0 ? tall_env != 0 : ((op.W + 15) / 16) * ((op.H + 31) / 32) < ((op.W + 31) / 32) * ((op.H + 15) / 16);
+            a.tilesX = tall ? (op.W + 15) / 16 : (op.W + 31) / 32; a.tilesY = tall ? (op.H + 31) / 32 : (op.H + 15) / 16;
+            const int ntile4 = batch * a.tilesX * a.tilesY;
+            // WALK (conv_wino4.h): nparts blocks per tile, each computing nwalk = n_nblk / nparts consecutive N-blocks of it: walks of three N-blocks where n_nblk allows, of
+            // two otherwise (the blocks of a tile share its planes through the XCD's L2), no walk while the launch would not give every CU four blocks.  A property of the
+            // launch only -- the bits do not depend on it.  EIGEN_W4_PARTS = n forces min(n, n_nblk) rounded down to a divisor (n >= n_nblk: one N-block per block), for A/B
+            // measurements and the parity tests.
+            static const int parts_env = getenv("EIGEN_W4_PARTS") ? atoi(getenv("EIGEN_W4_PARTS")) : 0;
+            int nparts;
+            if (parts_env > 0) { nparts = std::min(parts_env, op.n_nblk); while (op.n_nblk % nparts) --nparts; }
+            else {   // walks of three N-blocks where n_nblk allows (two otherwise), shorter while the launch would not give every CU four blocks
+                int nwalk = (op.n_nblk % 3 == 0) ? 3 : ((op.n_nblk % 2 == 0) ? 2 : 1);
+                if ((long long)(op.n_nblk / nwalk) * ntile4 < 4ll * e->n_cu) nwalk = 1;
+                nparts = op.n_nblk / nwalk;
+            }
+            if (tall) nparts = op.n_nblk;   // (tall blocks do not walk)
+            a.nparts = nparts; a.nwalk = op.n_nblk / nparts;
             auto go4 = [&](auto kern) {
-                a.tilesX = tall ? (op.W + 15) / 16 : (op.W + 31) / 32; a.tilesY = tall ? (op.H + 31) / 32 : (op.H + 15) / 16;
-                const int ntile4 = batch * a.tilesX * a.tilesY;
-                // WALK (conv_wino4.h): nparts blocks per tile, each computing nwalk = n_nblk / nparts consecutive N-blocks of it.  Two blocks per tile where n_nblk is even
-                // (they share the tile's planes through the XCD's L2, as two N-blocks in flight per tile did in round 5: profiles/r05_e_tile_map.txt), one otherwise; more
-                // parts while the launch would not give every CU four blocks.  A property of the launch only -- the bits do not depend on it.  EIGEN_W4_PARTS = n forces
-                // min(n, n_nblk) rounded down to a divisor (n >= n_nblk: one N-block per block, no walk), for A/B measurements and the parity tests.
-                static const int parts_env = getenv("EIGEN_W4_PARTS") ? atoi(getenv("EIGEN_W4_PARTS")) : 0;
-                int nparts = (op.n_nblk % 2 == 0) ? 2 : 1;
-                if (parts_env > 0) nparts = std::min(parts_env, op.n_nblk);
-                else while (nparts < op.n_nblk && (long long)nparts * ntile4 < 4ll * e->n_cu) ++nparts;
-                while (op.n_nblk % nparts) parts_env > 0 ? --nparts : ++nparts;
-                if (tall) nparts = op.n_nblk;   // (tall blocks do not walk)
-                a.nparts = nparts; a.nwalk = op.n_nblk / nparts;
                 const int g4 = nparts * ((ntile4 + 7) / 8) * 8;
                 {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
                     auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };
