@@ -39,9 +39,8 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
 LSTM_KERNEL_TAG = "conv3x3_mfma<4, 16, 1"  # the dominant kernel's name in rocprofv3 output (EPI_LSTM = 1)
-WINO_KERNEL_TAG = "wino_kernel<4, 1,"       # ... when the ConvLSTM chains run in their Winograd form (EIGEN_WINOGRAD): the eight-wave kernel (EIGEN_WINO16=0)
-WINO16_KERNEL_TAG = "wino16_kernel<4, 1>"    # ... the sixteen-wave F(2x2, 3x3) kernel (csrc/conv_wino16.h; EIGEN_WINOGRAD without bits 25-27)
-WINO4_KERNEL_TAG = "wino4_kernel<4, 1>"      # ... and the F(4x4, 3x3) kernel (csrc/conv_wino4.h, the default)
+WINO16_KERNEL_TAG = "wino16_kernel<4, 1>"    # ... when the ConvLSTM chains run in their Winograd form: the sixteen-wave F(2x2, 3x3) kernel (csrc/conv_wino16.h; EIGEN_WINOGRAD without bits 25-27)
+WINO4_KERNEL_TAG = "wino4_kernel<4, 1,"      # ... and the F(4x4, 3x3) kernel (csrc/conv_wino4.h, the default; third template argument: the block shape -- wide at the headline shape)
 N_STEPS_PREDNET = 21          # steps 1-20 + first extension (the 22nd step is never read on the population path)
 
 SHAPES = {
@@ -607,7 +606,7 @@ def main():
             elif pm.get("pop") != nb:
                 traffic_note = "PMC summary is for a device batch of %s genomes, this run uses %d: not reported" % (pm.get("pop"), nb)
             else:
-                tags = (WINO4_KERNEL_TAG, WINO16_KERNEL_TAG, WINO_KERNEL_TAG) if any(r.get("wino") for r in lstm) else (LSTM_KERNEL_TAG,)
+                tags = (WINO4_KERNEL_TAG, WINO16_KERNEL_TAG) if any(r.get("wino") for r in lstm) else (LSTM_KERNEL_TAG,)
                 for tag in tags:   # (the first tag the summary holds: the kernel that ran the ConvLSTMs of that build)
                     hit = [kv for kname, kv in pm["kernels"].items() if tag in kname]
                     if hit:

@@ -444,18 +444,18 @@ print("WINO_OK" if ok else "WINO_FAIL")
 """
 
 
-@pytest.mark.parametrize("switch", [None, "parts=1", "parts=99", "tall=1", "tall=0", "0x03FFFFFE", "0x0DFEFEFE", "0x01FFFFFE", "14", "0x0E0E00", "0x0100000E"])
+@pytest.mark.parametrize("switch", [None, "parts=1", "tall=1", "0x03FFFFFE", "0x0DFEFEFE", "0x01FFFFFE", "0x0E0E00", "0x0100000E"])
 def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     """The Winograd forms of the 3x3 convolutions against the oracle's statement of exactly that arithmetic (eig_oracle.c: wino_*, wino4_*; the oracle follows the
     same environment switch): all frames of four small roll-outs, bit for bit -- incl. step-0 operators (one source), ragged tiles, a top layer without an unpooled
     source, the 20 x 15 top layer of 160 x 120 (odd height), N-blocks of 48 and 64 columns.
     None = THE DEFAULT (0x0FFFFFFE): every eligible ConvLSTM / ConvA / ConvP as Winograd F(4x4, 3x3) on the twelve-wave kernel (csrc/conv_wino4.h), the unpooled source
-    inside the ConvLSTM's chains; "parts=1" / "parts=99": the same with a block of that kernel walking ALL N-blocks of its tile / exactly one (EIGEN_W4_PARTS: the
-    launch geometry must not show in a single bit); "tall=1" / "tall=0": every F(4x4) operator on 32 x 16-pixel / on 16 x 32-pixel blocks (EIGEN_W4_TALL; the default
-    picks per operator by map size -- these roll-outs include 80 x 60 and 40 x 30 maps, which take the tall shape, and a 20 x 15 one, which does not); 0x03FFFFFE: only the ConvLSTMs in F(4x4), ConvA / ConvP in F(2x2); 0x0DFEFEFE: ConvA and ConvP in F(4x4), the
+    inside the ConvLSTM's chains -- launches this small do not walk, and the block shape is picked per operator by map size (these roll-outs include 80 x 60 and 40 x 30
+    maps, which take the tall shape, and a 20 x 15 one, which does not); "parts=1": the same with a block of that kernel walking ALL N-blocks of its tile (EIGEN_W4_PARTS: the
+    launch geometry must not show in a single bit; test_specialised_operators... covers 2 / 99 and the forced shapes on other roll-outs); "tall=1": every F(4x4) operator on
+    32 x 16-pixel blocks (EIGEN_W4_TALL); 0x03FFFFFE: only the ConvLSTMs in F(4x4), ConvA / ConvP in F(2x2); 0x0DFEFEFE: ConvA and ConvP in F(4x4), the
     ConvLSTMs direct except the top one (bit 24 clear: below the top layer a ConvLSTM is a Winograd operator only with its unpooled source inside the chains) in F(2x2).
-    0x01FFFFFE: everything in F(2x2, 3x3) on the sixteen-wave kernel (csrc/conv_wino16.h; the round-4 default); 14: the ConvLSTM bits of layers 1-3 alone (top layer
-    only, see above); 0x0E0E00: ConvA and ConvP only; 0x0100000E: the ConvLSTMs with their unpooled source fused, everything else direct."""
+    0x01FFFFFE: everything in F(2x2, 3x3) on the sixteen-wave kernel (csrc/conv_wino16.h; the round-4 default); 0x0E0E00: ConvA and ConvP only; 0x0100000E: the ConvLSTMs with their unpooled source fused, everything else direct."""
     import subprocess
     env = dict(os.environ)
     env.pop("EIGEN_WINOGRAD", None)
