@@ -137,10 +137,8 @@ struct ConvArgs {
 };
 
 // ---- deterministic fp32 transcendental kernels: same operations, same order as oracle/eig_oracle.c ----
-__device__ __forceinline__ float det_expf(float x)
+__device__ __forceinline__ float det_expf_core(float x)   // x in [-80, 80] (det_expf clamps; det_tanhf calls it with 2 |x| in [1.25, 20], where the clamps are identities)
 {
-    x = fminf(x, 80.0f);
-    x = fmaxf(x, -80.0f);
     const float n = rintf(x * 1.44269504088896341f);
     float r = fmaf(n, -0.693359375f, x);
     r = fmaf(n, 2.12194440e-4f, r);
@@ -154,6 +152,12 @@ __device__ __forceinline__ float det_expf(float x)
     const float y = fmaf(p, r2, r) + 1.0f;
     const float s = __int_as_float(((int)n + 127) << 23);
     return y * s;
+}
+__device__ __forceinline__ float det_expf(float x)
+{
+    x = fminf(x, 80.0f);
+    x = fmaxf(x, -80.0f);
+    return det_expf_core(x);
 }
 // EIG_GATE_ORDER: element-wise order of the ConvLSTM gate epilogue (oracle/eig_oracle.c: lstm_cell states the
 // same thing).  1 (default, round 4): the order chainer_prednet's ConvLSTM.__call__ evaluates, wherever that order is knowable --
@@ -183,8 +187,14 @@ __device__ __forceinline__ float det_tanhf(float x)
         return fmaf(pz, x, x);
     }
     ax = fminf(ax, 10.0f);
-    const float t = det_expf(2.0f * ax);
-    const float r = 1.0f - 2.0f / (t + 1.0f);
+    const float t = det_expf_core(2.0f * ax);
+    // 2 / (t + 1), t + 1 in [4.49, 4.9e8]: v_rcp_f32 and one fused refinement step instead of the ten-instruction IEEE division sequence -- the SAME fp32 number for every
+    // fp32 divisor in [1, 1e9], and this function the same for ALL 2^32 inputs (exhaustive check on the device: scripts/fastdiv_check.hip, profiles/r06_o_fastdiv_check.txt);
+    // the oracle keeps the plain division.  Five of these per ConvLSTM cell.
+    const float d = t + 1.0f, rc = __builtin_amdgcn_rcpf(d);
+    float q = 2.0f * rc;
+    q = fmaf(fmaf(-d, q, 2.0f), rc, q);
+    const float r = 1.0f - q;
     return x < 0.0f ? -r : r;
 }
 __device__ __forceinline__ float relu_f(float v) { return v > 0.0f ? v : 0.0f; }

@@ -1,6 +1,6 @@
 // conv_wino16.h -- the Winograd F(2x2, 3x3) operators on SIXTEEN waves per block (four per SIMD).  DESIGN.md section 3.1d.
 //
-// Why: the model of conv_wino.h's K-block (scripts/wino_loop_model.hip, profiles/r04_w_wino_loop_model.txt) shows every piece of the staging work
+// Why: the model of the round-4 eight-wave K-block (scripts/wino_loop_model.hip, profiles/r04_w_wino_loop_model.txt) shows every piece of the staging work
 // costing the matrix pipe several times its instruction count when only ONE partner wave per SIMD can fill in, and the barrier 9 points once
 // the waves drift; the same K-block on sixteen waves of half the accumulators each loses 4 points to all of it instead of 17.
 //
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(WINO16_THREADS, 1) wino16_kernel(const ConvArg
         timeline();
     } else {
         // N-TILE split: wave (rg, xi) finishes N-tile xi of its region for both row parities (xi = 3 rests where NI = 3): all four parity classes of
-        // a window in one lane -- ConvA's max_pooling_2d is the max over a lane's four values, ConvP stores whole 4 x 4-pixel patches (conv_wino.h)
+        // a window in one lane -- ConvA's max_pooling_2d is the max over a lane's four values, ConvP stores whole 4 x 4-pixel patches
         const int k = xi;
         if (k >= NI) return;
         f32x4 y[2][2];   // [py][px]

@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 GHZ = float(os.environ.get("EIG_GFX_GHZ", "2.4"))
-NW = int(os.environ.get("EIG_TL_WAVES", "16"))   # waves per block: 16 = conv_wino16.h, 8 = conv_winoh.h (EIGEN_WINOH=7; two blocks per CU)
+NW = int(os.environ.get("EIG_TL_WAVES", "16"))   # waves per block: 16 = conv_wino16.h, 12 = conv_wino4.h (one record per block and N-block of its walk)
 out_dir = os.environ.setdefault("EIGEN_TIMELINE", "gpurun_out/tl")
 os.makedirs(out_dir, exist_ok=True)
 if "--analyze-only" not in sys.argv:
@@ -23,7 +23,7 @@ if "--analyze-only" not in sys.argv:
     cfg = synth.make_config(2, 3)
     genomes = [g for _, g in synth.make_population(pop, cfg, seed=0)]
     wts = weights.synthetic_prednet_weights(ch, W, H, seed=0)
-    fitness.evaluate_population(1, genomes, wts, cfg, W, H, ch, c_dim=3, max_batch=pop)   # (EIGEN_WINOGRAD / EIGEN_WINOH select the kernel: set EIG_TL_WAVES = 16 / 8 / 12 to match)
+    fitness.evaluate_population(1, genomes, wts, cfg, W, H, ch, c_dim=3, max_batch=pop)   # (EIGEN_WINOGRAD selects the kernel: set EIG_TL_WAVES = 16 / 12 to match)
     torch.cuda.synchronize()
 
 
@@ -56,7 +56,7 @@ for path in sorted(glob.glob(os.path.join(out_dir, "timeline_H*.bin"))):
             role, (S - E)[:, sl].mean(), (K0 - S)[:, sl].mean(), (K1 - K0)[:, sl].mean(), (X - K1)[:, sl].mean(), (Y - X)[:, sl].mean(), (END - Y)[:, sl].mean()))
     print("   inside a block: first wave in -> last wave in %.0f cycles; first wave out -> last wave out %.0f; K-loop end spread %.0f" % (
         (E.max(axis=1) - E.min(axis=1)).mean(), (END.max(axis=1) - END.min(axis=1)).mean(), (K1.max(axis=1) - K1.min(axis=1)).mean()))
-    # co-resident blocks (conv_winoh.h: two per CU): share of a CU's busy span during which NO block of it is inside its K loop
+    # co-resident blocks (kernels with two blocks per CU): share of a CU's busy span during which NO block of it is inside its K loop
     cov, spans, conc = 0.0, 0.0, 0.0
     for key in np.unique(cu_key):
         idx = np.nonzero(cu_key == key)[0]
