@@ -132,6 +132,9 @@ struct eigen_engine {
     bool profile_convs = false;
     double ms[6] = {0, 0, 0, 0, 0, 0};
     int hflip = 0;  // which h buffer holds the current R
+    // ConvP_l (l > 0) is read by nobody until ConvA_l of the NEXT step: forked onto a side stream it can fill the CUs the last round of the ConvLSTM below it leaves idle
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join[EIGEN_MAX_LAYERS] = {nullptr};
 };
 
 // ------------------------------------------------------------------------------------------------ helpers
@@ -674,6 +677,9 @@ int eigen_destroy(eigen_engine* e)
     for (int i = 0; i < 2; ++i)
         for (int l = 0; l < FLOW_MAX_LEVELS; ++l) if (e->d_gray[i][l]) (void)hipFree(e->d_gray[i][l]);
     for (int l = 0; l < FLOW_MAX_LEVELS; ++l) if (e->d_deriv[l]) (void)hipFree(e->d_deriv[l]);
+    if (e->side) (void)hipStreamDestroy(e->side);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    for (auto& ev : e->ev_join) if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
     if (e->pev0) (void)hipEventDestroy(e->pev0);
     if (e->pev1) (void)hipEventDestroy(e->pev1);
@@ -757,6 +763,9 @@ int eigen_create(const eigen_config* cfg, eigen_engine** out)
     (void)hipMemset(e->d_zeros, 0, 256);
 #undef ALLOC
     for (auto& ev : e->ev) HIPCHK(hipEventCreate(&ev));
+    HIPCHK(hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    for (int l = 0; l < L; ++l) HIPCHK(hipEventCreateWithFlags(&e->ev_join[l], hipEventDisableTiming));
     HIPCHK(hipEventCreate(&e->pev0));
     HIPCHK(hipEventCreate(&e->pev1));
     *out = e;
@@ -1090,6 +1099,12 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
     static const bool skip_zero_sources = !(getenv("EIGEN_NO_T0") && atoi(getenv("EIGEN_NO_T0")));  // A/B measurements only
     hipLaunchKernelGGL(e0_init_kernel, dim3(1024), dim3(256), 0, st, d_images, e->layer[0].E, e->C0, (int)HW, batch);
     HIPCHK(hipGetLastError());
+    // ConvP_l (l > 0) on a side stream: pays where the launches are a fraction of a round of the chip -- configs[0] (pop 10 at 64 x 64: 10 to 40 blocks per launch) +7.5 %;
+    // neutral at configs[1], -0.7 % at 160 x 120 colour pop 50, -2 % at the headline (profiles/r06_q_side_stream_ab.txt), as in round 3.  Hence: only while the layer-1 maps of
+    // the batch are less than one block per CU.  A scheduling choice of the launch, not of the arithmetic.  EIGEN_SIDE_STREAM = 0 / 1 forces it (A/B, tests).
+    static const int side_env = getenv("EIGEN_SIDE_STREAM") ? atoi(getenv("EIGEN_SIDE_STREAM")) : -1;
+    const bool side_auto = L > 1 && (long long)batch * e->layer[1].H * e->layer[1].W < 512ll * e->n_cu;
+    const bool side_on = (side_env >= 0 ? side_env != 0 : side_auto) && !e->profile_convs;
     // One PredNet step of genomes [b0, b0 + nb) on stream s; raw4: that range's partial-chain scratch.
     auto run_step = [&](int t, int b0, int nb, hipStream_t s, float* raw4) -> int {
         auto off = [&](float* p, const Layer& y, int mult = 1) { return p + (size_t)b0 * mult * y.C * y.H * y.W; };
@@ -1100,6 +1115,7 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
             memset(&a, 0, sizeof(a));
             a.src[0].ptr = off(e->layer[l - 1].E, e->layer[l - 1], 2);
             a.bias = y.biasA; a.P = off(y.P, y); a.E = off(y.E, y, 2);
+            if (side_on && t > 0) HIPCHK(hipStreamWaitEvent(s, e->ev_join[l], 0));   // P_l of the previous step came from the side stream
             HIPCHK(launch_conv(e, (t == 0 && skip_zero_sources) ? y.convA_t0 : y.convA, a, nb, s));
         }
         // top-down: R_l, then P_l
@@ -1143,6 +1159,12 @@ int eigen_prednet_rollout(eigen_engine* e, const uint8_t* d_images, int32_t batc
                         a.frame = d_frames + (size_t)b0 * a.frame_bstride + (size_t)(t - first_out_step) * e->C0 * HW;
                     }
                 }
+                if (side_on && l > 0) {   // fork: behind the ConvLSTM that produced R_l, beside everything that follows on the main stream
+                    HIPCHK(hipEventRecord(e->ev_fork, s));
+                    HIPCHK(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+                    HIPCHK(launch_conv(e, y.convP, a, nb, e->side));
+                    HIPCHK(hipEventRecord(e->ev_join[l], e->side));
+                } else
                 HIPCHK(launch_conv(e, y.convP, a, nb, s));
             }
         }
