@@ -1236,6 +1236,7 @@ __global__ void __launch_bounds__(L0_TX * L0_TY) lstm0_direct_kernel(const float
     }
 }
 
+#ifdef EIG_ENGINE_UNIT   // (non-template kernels: defined in the engine's translation unit only -- this header is included by three)
 // E_0 for the first step: P_0 = 0  ->  E = [relu(x), relu(-x)] = [x, 0]
 __global__ void e0_init_kernel(const uint8_t* img, float* E0, int C, int HW, int B)
 {
@@ -1258,5 +1259,6 @@ __global__ void det_math_kernel(const float* x, int n, float* e, float* s, float
         if (t) t[i] = det_tanhf(x[i]);
     }
 }
+#endif
 
 }  // namespace eig

@@ -15,18 +15,12 @@
 //     parity a of segment s (tile rows 4 rg + a + 2 s: window row s) from c_0..c_2 or c_1..c_3 -- the pixel ownership of the eight-wave
 //     kernel's gate epilogue split in two, whose code (lstm_cell, 16-byte accesses) is reused.
 #pragma once
-#include "conv_mfma.h"
+#include "wino_launch.h"
 
 namespace eig {
 // (the eight-wave F(2x2) kernel of rounds 4-5, conv_wino.h, is gone: round 6 -- docs/HISTORY.md section 3.1d keeps its description)
-constexpr int wino_u_floats(int NI) { return 16 * KC * 16 * NI; }   // one packed K-block of F(2x2) weights: [16 pos][8 ch][16 cols][NI]: 8192 floats for NI = 4
 constexpr int WINO_RAW_FLOATS = 18 * 24;                            // one channel's haloed rows y0-1 .. y0+16, aligned chunks x0-4 .. x0+19
-static_assert(KC == 8, "conv_wino16.h: 8-channel K-blocks");
-}  // namespace eig
 
-namespace eig {
-
-constexpr int WINO16_THREADS = 1024;
 #ifndef EIG_W16_TRIM_UP
 #define EIG_W16_TRIM_UP 1      // (0: every K-block's patch through the full 4 x 4 transform -- A/B builds)
 #endif

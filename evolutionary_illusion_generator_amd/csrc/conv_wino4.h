@@ -35,14 +35,10 @@
 // prologue DMAs of N-block n + 1 (U slabs of K-blocks 0, 1 -> U slots 0, 1; planes of K-blocks 0, 1, 2) and only then run the finishing phase of n, which lives in U
 // slot 2 + 12 KB: the DMA round trip, the block dispatch and the address set-up of a fresh block are hidden behind the exchange (profiles/r06_b_w4_walk.txt).
 #pragma once
-#include "conv_wino16.h"
+#include "wino_launch.h"
 
 namespace eig {
 
-constexpr int W4_WAVES = 12;
-constexpr int W4_THREADS = 64 * W4_WAVES;
-constexpr int W4_KC = 4;
-constexpr int W4_NPOS = 36;
 constexpr int W4_UPOS = 256;                        // floats per position of a U slot: 4 ch x 16 cols x NI (NI = 3: 192 used)
 constexpr int W4_U_FLOATS = W4_NPOS * W4_UPOS;      // 36 KB
 constexpr int W4_NUS = 3, W4_NPS = 3;
@@ -64,7 +60,6 @@ constexpr int w4_x(bool tall) { return tall ? w4_u(true, 0) : w4_u(false, 1); }
 constexpr int W4_X_FLOATS = W4_WAVES * 2 * 4 * 64 * 4;          // one exchange round = two N-tiles: [12 waves][2][4 e][64 lanes] 16-byte vectors = 96 KB
 constexpr int wino4_lds_bytes() { return (w4_x(false) + W4_X_FLOATS) * 4; }   // 159744, both shapes (tall: 3 x 16 KB + 3 x 36 KB)
 static_assert((w4_u(true, 2) + W4_U_FLOATS) * 4 == wino4_lds_bytes() && (w4_p(false, 2) + w4_pslot(false)) * 4 <= wino4_lds_bytes(), "LDS maps");
-constexpr int wino4_u_floats(int NI) { return W4_NPOS * 4 * 16 * NI; }   // one 4-channel K-block of the packed weights: [36 pos][4 ch][16 cols][NI] (the buffer ends in one K-block of padding: the fetch runs one K-block past the end)
 #ifndef EIG_W4_DIAG
 #define EIG_W4_DIAG 0   // measurement builds only (WRONG RESULTS): 1 no wait for the K loop's DMAs, 2 no barrier in the K loop, 4 no A-operand build, 8 no plane DMA, 16 no U DMA
 #endif

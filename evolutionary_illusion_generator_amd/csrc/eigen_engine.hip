@@ -14,9 +14,9 @@
 #include <vector>
 
 #include "../../include/eigen_engine.h"
+#define EIG_ENGINE_UNIT 1   // (conv_mfma.h: the non-template kernels are defined in this unit)
 #include "conv_mfma.h"
-#include "conv_wino16.h"
-#include "conv_wino4.h"
+#include "wino_launch.h"   // the Winograd kernels live in wino4_kernels.hip / wino16_kernels.hip
 #include "cppn_kernel.h"
 #include "farneback_kernels.h"
 #include "flow_kernels.h"
@@ -453,7 +453,7 @@ template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, int SPLIT = 0> 
 // eight-wave / half-block / strip instantiations in round 6: with the Winograd forms as the default nothing at any BASELINE shape ran them)
 template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec, int w8 = 0)
 {
-    if constexpr (EPI == EPI_CONVA) {
+    if constexpr (EPI == EPI_CONVA && TW == 16) {   // (16-wide tiles only: the image layer's ConvA never runs on 8 x 8 tiles at a reference shape)
         if (w8 && vec) return launch_inst2<NI, TW, EPI, true, false, 1>(a, grid, st);
     }
     return vec ? launch_inst2<NI, TW, EPI, true>(a, grid, st) : launch_inst2<NI, TW, EPI, false>(a, grid, st);
@@ -535,51 +535,29 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             }
             if (tall) nparts = op.n_nblk;   // (tall blocks do not walk)
             a.nparts = nparts; a.nwalk = op.n_nblk / nparts;
-            auto go4 = [&](auto kern) {
-                const int g4 = nparts * ((ntile4 + 7) / 8) * 8;
-                {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
-                    auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };
-                    a.mg[0] = magic(nparts); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
-                }
-                static std::unordered_set<const void*> attr_done;   // (the handle is not thread-safe anyway: one rank, one host thread)
-                if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, wino4_lds_bytes());
-                op.last_grid = g4 * a.nwalk; op.last_waves = W4_WAVES;   // (timeline records: one per block and N-block of its walk)
-#if EIG_TIMING
-                if (tl_dbg) {   // sized from THIS launch's records (the buffer above was sized for the four-wave grid)
-                    (void)hipFree(tl_dbg);
-                    (void)hipMalloc((void**)&tl_dbg, (size_t)op.last_grid * W4_WAVES * 64);
-                    (void)hipMemset(tl_dbg, 0, (size_t)op.last_grid * W4_WAVES * 64);
-                    a.dbg = tl_dbg;
-                }
-#endif
-                hipLaunchKernelGGL(kern, dim3(g4), dim3(W4_THREADS), wino4_lds_bytes(), st, a);
-            };
-            if (tall) {
-                if (op.epi == EPI_LSTM) go4(wino4_kernel<4, EPI_LSTM, true>);
-                else if (op.epi == EPI_CONVA) { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVA, true>); else go4(wino4_kernel<3, EPI_CONVA, true>); }
-                else { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVP, true>); else go4(wino4_kernel<3, EPI_CONVP, true>); }
-            } else {
-                if (op.epi == EPI_LSTM) go4(wino4_kernel<4, EPI_LSTM>);
-                else if (op.epi == EPI_CONVA) { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVA>); else go4(wino4_kernel<3, EPI_CONVA>); }
-                else { if (op.NI == 4) go4(wino4_kernel<4, EPI_CONVP>); else go4(wino4_kernel<3, EPI_CONVP>); }
+            const int g4 = nparts * ((ntile4 + 7) / 8) * 8;
+            {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
+                auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };
+                a.mg[0] = magic(nparts); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
             }
+            op.last_grid = g4 * a.nwalk; op.last_waves = W4_WAVES;   // (timeline records: one per block and N-block of its walk)
+#if EIG_TIMING
+            if (tl_dbg) {   // sized from THIS launch's records (the buffer above was sized for the four-wave grid)
+                (void)hipFree(tl_dbg);
+                (void)hipMalloc((void**)&tl_dbg, (size_t)op.last_grid * W4_WAVES * 64);
+                (void)hipMemset(tl_dbg, 0, (size_t)op.last_grid * W4_WAVES * 64);
+                a.dbg = tl_dbg;
+            }
+#endif
+            r = launch_wino4(op.NI, op.epi, tall, a, g4, st);
         } else {
             a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
             const int nt = batch * a.tilesX * a.tilesY;
             const int g = op.n_nblk * ((nt + 7) / 8) * 8;
             op.last_grid = g; op.last_waves = 16;
-            auto go16 = [&](auto kern, int ni) {
-                const int lds = wino16_lds_bytes(ni);
-                static std::unordered_set<const void*> attr_done;
-                if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-                hipLaunchKernelGGL(kern, dim3(g), dim3(WINO16_THREADS), lds, st, a);
-            };
             if (op.epi == EPI_LSTM && a.acc_init != nullptr) return hipErrorInvalidConfiguration;   // (set_weights never pairs a Winograd ConvLSTM with a separate unpooled chain)
-            if (op.epi == EPI_LSTM) go16(wino16_kernel<4, EPI_LSTM>, 4);
-            else if (op.epi == EPI_CONVA) { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVA>, 4); else go16(wino16_kernel<3, EPI_CONVA>, 3); }
-            else { if (op.NI == 4) go16(wino16_kernel<4, EPI_CONVP>, 4); else go16(wino16_kernel<3, EPI_CONVP>, 3); }
+            r = launch_wino16(op.NI, op.epi, a, g, st);
         }
-        r = hipGetLastError();
     } else {
     static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
     if (op.epi == EPI_CONVP && op.d_wraw && direct_p0) {  // image layer: HBM-bound, one thread per pixel (conv_mfma.h)

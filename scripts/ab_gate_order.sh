@@ -1,7 +1,7 @@
 #!/bin/bash
 # Same-box A/B of the canonical gate epilogue: EIG_GATE_ORDER=1 (the reference's knowable element-wise order,
 # the default build) against EIG_GATE_ORDER=0 (rounds 1-3), each as a matching pair of HIP library + C oracle:
-#   hipcc ... -DEIG_GATE_ORDER=0 -o evolutionary_illusion_generator_amd/libeigen_hip_gate0.so ...;  make -C oracle gate0
+#   python __graft_entry__.py --lib evolutionary_illusion_generator_amd/libeigen_hip_gate0.so -DEIG_GATE_ORDER=0;  make -C oracle gate0
 # For each: bench.py's parity leg (genome 0 bit-exact vs ITS oracle; all 256 genomes classified against the reference-order
 # implementations; the reference-order A-vs-B control) -> OUT/gate{0,1}.json and a one-line digest.
 R=${GRAFT_REPO_ROOT:-$(pwd)}

@@ -1,5 +1,5 @@
 """Measurement script (not product): per-SIMD timeline of the ConvLSTM kernel from an -DEIG_TIMING=1 build.
-    hipcc ... -DEIG_TIMING=1 -o scripts/_timing/libeigen_timing.so evolutionary_illusion_generator_amd/csrc/eigen_engine.hip
+    python __graft_entry__.py --lib scripts/_timing/libeigen_timing.so -DEIG_TIMING=1
     EIGEN_TIMELINE=gpurun_out python scripts/timeline.py [pop]
 Every wave of one steady-state launch of each ConvLSTM op records s_memtime at kernel entry / K-loop start / K-loop end /
 exit plus HW_ID; this script rebuilds, per SIMD, how much of the time two, one or no wave was inside the MFMA loop."""

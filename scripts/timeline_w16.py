@@ -1,6 +1,6 @@
 """Measurement script (not product): where the time between two K loops of the sixteen-wave Winograd ConvLSTM kernel goes, from an
 -DEIG_TIMING=1 build (csrc/conv_wino16.h: timeline).
-    hipcc ... -DEIG_TIMING=1 -o scripts/_timing/libeigen_timing.so evolutionary_illusion_generator_amd/csrc/eigen_engine.hip
+    python __graft_entry__.py --lib scripts/_timing/libeigen_timing.so -DEIG_TIMING=1
     EIGEN_TIMELINE=gpurun_out/tl python scripts/timeline_w16.py [pop]          (--analyze-only: read the .bin files again)
 Every wave of one steady-state launch of each ConvLSTM operator records the cycle counter at entry / set-up done (first DMA about to be
 issued) / K loop start / K loop end / exchange barrier passed / row transform done (gates start) / exit, and HW_ID.  Blocks are then
