@@ -125,13 +125,11 @@ struct ConvArgs {
     // Chain of an unpooled source (written by an EPI_UP4 launch at HALF this resolution), [B][4][n_nblk*NB][H/2][W/2], added to
     // this launch's chain with one fp32 addition after the K loop; nullptr: none.
     const float* acc_init;
-    // FUSE instantiation (EPI_LSTM, 16-wide tiles, 16-byte staging): the unpooled source R_{l+1} ITSELF -- its 2x2-form chain runs
-    // inside this launch (K-blocks of KC channels x 4 taps ahead of the E_l / h_l K-blocks, own accumulators, one fp32 addition
-    // at the end), so no EPI_UP4 pass and no partial-chain tensor exist for this operator.
+    // The unpooled source R_{l+1} ITSELF, for the operators that chain it inside their own launch: the Winograd ConvLSTMs (conv_wino16.h / conv_wino4.h: in the same
+    // chains, weights in wpk) -- no EPI_UP4 pass and no partial-chain tensor exist for them.
     const float* up_src;   // [B][up_C][H/2][W/2]
     int up_C;              // real channels of the unpooled source
     int up_kb;             // its K-blocks: ceil(up_C / KC)
-    const float* up_wpk;   // [n_nblk][up_kb][KC*4 rows = (channel, a, b)][4 classes][16 columns][4 gates], zero rows past up_C
     const float* zeros; // >= 64 zero bytes in device memory: DMA source for out-of-image / padded-channel positions
     unsigned long long* dbg;  // EIG_TIMING builds only: per-block cycle counters
 };
@@ -276,22 +274,6 @@ template <int NI, int TW, bool VEC, int TAPS = 9, bool ONEKB = false, int NT = 2
     return (ONEKB ? 1 : 2) * (conv_in_floats<NI, TW, VEC, NT, HALF>() + conv_w_floats<NI, TW, VEC, TAPS, NT>()) * 4;
 }
 
-// FUSE (conv3x3_mfma<4, 16, EPI_LSTM, true, false, true>): LDS buffer = max(main K-block, unpooled-source K-block).
-//   unpooled-source K-block: haloed tile of R_{l+1} at ITS resolution [KC][10 rows][16 floats = chunks X0-4 .. X0+11] = 5 KB
-//   (1.25 DMA rounds: the quarter round is issued by wave 0 alone) at float 0, weight slab [KC*4][4 classes][64] = 32 KB (8 rounds)
-//   at float UP_WOFF.
-constexpr int UP_S = 16, UP_PH = 10, UP_PLANE = UP_PH * UP_S, UP_CHUNKS_C = UP_PH * UP_S / 4;
-constexpr int UP_WOFF = 1536;                 // floats; >= KC * UP_PLANE = 1280
-constexpr int UP_WROW = 4 * 64;               // floats per k-row: [4 classes][16 columns][4 gates]
-constexpr int UP_WFLOATS = KC * 4 * UP_WROW;  // 8192
-constexpr int UP_NWR = UP_WFLOATS / 1024;     // 8 weight DMA rounds
-constexpr int UP_NSTEP = KC;                  // MFMA steps per K-block: one channel (4 taps) each
-template <int NI, int TW, bool VEC> constexpr int conv_fuse_buf_floats()
-{
-    return (conv_in_floats<NI, TW, VEC>() + conv_w_floats<NI, TW, VEC, 9>()) > (UP_WOFF + UP_WFLOATS) ? (conv_in_floats<NI, TW, VEC>() + conv_w_floats<NI, TW, VEC, 9>())
-                                                                                                  : (UP_WOFF + UP_WFLOATS);
-}
-
 #ifndef EIG_TIMING
 #define EIG_TIMING 0  // measurement-only builds: per-wave s_memtime breakdown of the K loop into a.dbg
 #endif
@@ -319,7 +301,7 @@ constexpr int CONV_THREADS = 256;  // 4 waves per block (W8 instantiations: 512 
 #ifndef EIG_ONEKB_OCC
 #define EIG_ONEKB_OCC 4  // single-K-block operators: one LDS buffer (32 KB), four blocks per CU -- their time is prologue + DMA round trip +
 #endif                   // epilogue around 216 MFMAs per wave, which only other blocks' MFMAs can cover
-template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE = false, int SPLIT = 0>
+template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, bool FUSE_ = false, int SPLIT = 0>   // (FUSE_: the in-kernel 2x2-form chain of rounds 3-5, removed in round 6; the parameter keeps the kernels' names)
 __global__ void __launch_bounds__(SPLIT == 1 ? 512 : CONV_THREADS, SPLIT ? EIG_W8_OCC : (ONEKB ? EIG_ONEKB_OCC : ((EPI == EPI_UP4 && NI == 4 && TW == 16 && VEC) ? EIG_UP4_OCC : EIG_CONV_OCC)))
 conv3x3_mfma(const ConvArgs a)
 {
@@ -330,8 +312,8 @@ conv3x3_mfma(const ConvArgs a)
     // reference's own 160 x 120): five strips = 94 % instead of six 8 x 8 tiles = 78 %.  A lane owns rows 4 q .. 4 q + 3 x the 4 columns, so
     // every epilogue indexes its accumulators exactly as the 16-wide map does; only as half blocks (the 12-float rows cost LDS).
     static_assert(TW != 4 || (H4 && VEC && EPI != EPI_LSTM_PACKED && EPI != EPI_UP4C), "4-wide tiles: half blocks with 16-byte staging only");
-    static_assert(!FUSE || (EPI == EPI_LSTM && NI == 4 && TW == 16 && VEC && KC == 8 && !ONEKB), "FUSE: the wide ConvLSTM instantiation only");
-    static_assert(!W8 || (VEC && !ONEKB && !FUSE && EPI != EPI_UP4C && EPI != EPI_LSTM_PACKED), "W8: 16-byte staging, per-pixel or pooled epilogues");
+    static_assert(!FUSE_, "the in-kernel chain of an unpooled source was removed in round 6 (a ConvLSTM chains it inside only in its Winograd forms)");
+    static_assert(!W8 || (VEC && !ONEKB && EPI != EPI_UP4C && EPI != EPI_LSTM_PACKED), "W8: 16-byte staging, per-pixel or pooled epilogues");
     constexpr int NT = SPLIT == 1 ? 512 : CONV_THREADS;  // threads per block; a DMA round is NT 16-byte chunks
     constexpr int NWS = H4 ? 2 : 4;              // 64-pixel regions per block
     constexpr int MI_N = W8 ? 2 : 4;             // 16-row sub-tiles (parity classes) per wave
@@ -357,7 +339,7 @@ conv3x3_mfma(const ConvArgs a)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr bool FAST = conv_fast_dma<NI, TW, VEC>();
     constexpr int INF = conv_in_floats<NI, TW, VEC, NT, H4>();  // floats of the input area (KC * PLANE, padded for FAST)
-    constexpr int BUF = FUSE ? conv_fuse_buf_floats<NI, TW, VEC>() : INF + conv_w_floats<NI, TW, VEC, epi_taps(EPI), NT>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
+    constexpr int BUF = INF + conv_w_floats<NI, TW, VEC, epi_taps(EPI), NT>();  // floats per LDS buffer: [KC][PLANE] inputs | [KC*9][NB] weights
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -550,49 +532,10 @@ conv3x3_mfma(const ConvArgs a)
     KB cur_kb = kb_first();
     int wrow = 0;  // first packed weight row of the current K-block
 
-    // ---- FUSE: staging of the unpooled source's K-blocks (branch-free like dma_fast: saturating adds push what must not be read
-    // out of the descriptors' ranges).  Tile slots: chunk p = tid + 256 r of [KC][10][4 chunks]; r = 1 holds 64 chunks (wave 0).
-    const int nup = FUSE ? a.up_kb : 0;
-    const int up_hw_f = (a.H >> 1) * (a.W >> 1);
-    int up_slot[2] = {-1, -1};
-    __amdgpu_buffer_rsrc_t rs_us = rsw, rs_uw = rsw;
-    if constexpr (FUSE) {
-        const int Hs = a.H >> 1, Ws = a.W >> 1;
 #pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            const int p = tid + r * 256;
-            const int c = p / UP_CHUNKS_C, rem = p - c * UP_CHUNKS_C;
-            const int yy = rem >> 2, xx = rem & 3;
-            const int gy = (y0 >> 1) - 1 + yy, gx = (x0 >> 1) - 4 + 4 * xx;
-            const bool ok = p < KC * UP_CHUNKS_C && gy >= 0 && gy < Hs && gx >= 0 && gx < Ws;
-            up_slot[r] = ok ? (c * up_hw_f + gy * Ws + gx) * 4 : -1;
-        }
-        rs_us = __builtin_amdgcn_make_buffer_rsrc((void*)(a.up_src + (size_t)b0 * a.up_C * up_hw_f), 0, a.up_C * up_hw_f * 4, 0x00020000);
-        rs_uw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.up_wpk + (size_t)nblk * a.up_kb * UP_WFLOATS), 0, a.up_kb * UP_WFLOATS * 4, 0x00020000);
-    }
-    constexpr int UP_NOPS = UP_NWR + 2;
-    const int up_s0 = up_slot[0], up_s1 = up_slot[1];
-    auto dma_up = [=](int j, unsigned soff_in, unsigned soff_w, float* buf) __attribute__((always_inline)) {
-        if (j < UP_NWR) {
-            const unsigned vo = __builtin_elementwise_add_sat((unsigned)(tid * 16 + j * 4096), soff_w);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_uw, (__attribute__((address_space(3))) void*)(buf + UP_WOFF + (j * 256 + wv * 64) * 4), 16, (int)vo, 0, 0, 0);
-            return;
-        }
-        const int r = j - UP_NWR;
-        if (r == 1 && wv != 0) return;  // wave-uniform: the quarter round
-        const unsigned vo = __builtin_elementwise_add_sat((unsigned)(r == 0 ? up_s0 : up_s1), soff_in);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_us, (__attribute__((address_space(3))) void*)(buf + (r * 256 + wv * 64) * 4), 16, (int)vo, 0, 0, 0);
-    };
-
-    if constexpr (FUSE) {
-#pragma unroll
-        for (int j = 0; j < UP_NOPS; ++j) dma_up(j, 0u, 0u, lds);   // K-block 0 of the unpooled source
-    } else {
-#pragma unroll
-        for (int j = 0; j < NOPS; ++j) {
-            if constexpr (FAST) dma_fast(j, cur_kb, rsrc_of(0), 0u, 0u, lds);
-            else dma_op(j, cur_kb, wrow, lds);
-        }
+    for (int j = 0; j < NOPS; ++j) {
+        if constexpr (FAST) dma_fast(j, cur_kb, rsrc_of(0), 0u, 0u, lds);
+        else dma_op(j, cur_kb, wrow, lds);
     }
     // (the first K-block is in flight: everything below up to the wait overlaps its latency)
 
@@ -642,7 +585,7 @@ conv3x3_mfma(const ConvArgs a)
     // one 16-byte load (8-wide tiles: row q, columns 0..3) from plane `class` of the chain tensor.  Issued in one burst they
     // saturate the wave's outstanding vector-memory operations and the CU's address path in front of the first MFMA (round 1:
     // 21K cycles, scripts/timeline.py), so they are SPREAD over the MFMA steps of K-block 0 and land long before the K loop ends.
-    constexpr bool HAS_UP = !FUSE && (EPI == EPI_LSTM || EPI == EPI_LSTM_PACKED || EPI == EPI_RAW);  // operators that can be handed an unpooled source's chain
+    constexpr bool HAS_UP = (EPI == EPI_LSTM || EPI == EPI_LSTM_PACKED || EPI == EPI_RAW);  // operators that can be handed an unpooled source's chain
     constexpr int UPV = (TW != 8) ? 2 : 1;              // loads per (class, N-tile)
     constexpr int NUPL = HAS_UP ? MI_N * NI * UPV : 0;  // loads per lane
     f32x4 upc[MI_N][HAS_UP ? NI : 1];
@@ -684,8 +627,8 @@ conv3x3_mfma(const ConvArgs a)
     unsigned long long t_mfma = 0, t_wait = 0, t_bar = 0, t_all0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
     auto kiter = [&](const int kb, auto kfirst_tag) __attribute__((always_inline)) {
         const unsigned long long tk0 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
-        float* const cur = lds + ((kb + nup) & 1) * BUF;   // FUSE: the unpooled source's nup K-blocks came first
-        float* const nxt = lds + (((kb + nup) & 1) ^ 1) * BUF;
+        float* const cur = lds + (kb & 1) * BUF;
+        float* const nxt = lds + ((kb & 1) ^ 1) * BUF;
         const KB nxt_kb = kb_next(cur_kb);
         const int wrow_nxt = wrow + cur_kb.kc * TAPS;
         const bool more_kb = (kb + 1 < nkb) && EIG_ABLATE != 1;
@@ -767,52 +710,6 @@ conv3x3_mfma(const ConvArgs a)
         __syncthreads();
         if (EIG_TIMING) { const unsigned long long tk3 = __builtin_readcyclecounter(); t_mfma += tk1 - tk0; t_wait += tk2 - tk1; t_bar += tk3 - tk2; }
     };
-    // ---- FUSE: the chain of the unpooled source, k = (channel, a, b) in its 2x2 form: sub-tile mi of the wave IS
-    // parity class mi, so the class-dependent pre-summed weights are an ordinary B operand per sub-tile (four ds_read_b128 per
-    // step instead of one); tap (a, b) = k-slot q of source pixel (Y, X) reads tile position (Y + a + py, X + b + px + 3).
-    f32x4 acc_up[FUSE ? 4 : 1][FUSE ? NI : 1];
-    if constexpr (FUSE) {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc_up[mi][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const int addr_up = (2 * wv + g_wy + (q >> 1)) * UP_S + g_wx + (q & 1) + 3;
-        const int woff_up = UP_WOFF + q * UP_WROW + col * 4;
-        const __amdgpu_buffer_rsrc_t rs_m0 = rsrc_of(0);
-        auto up_iter = [&](const int ub, auto last_tag) __attribute__((always_inline)) {
-            constexpr bool LAST = decltype(last_tag)::value;  // the next K-block is the first one of E_l
-            float* const cur = lds + (ub & 1) * BUF;
-            float* const nxt = lds + ((ub & 1) ^ 1) * BUF;
-            const unsigned soff_in_nxt = (unsigned)((ub + 1) * KC * up_hw_f * 4), soff_w_nxt = (unsigned)((ub + 1) * UP_WFLOATS * 4);
-#pragma unroll
-            for (int st = 0; st < UP_NSTEP; ++st) {
-                float av[4];
-                f32x4 b4[4];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-                    av[mi] = cur[addr_up + st * UP_PLANE + (mi >> 1) * UP_S + (mi & 1)];
-                    b4[mi] = *reinterpret_cast<const f32x4*>(cur + woff_up + st * 4 * UP_WROW + mi * 64);
-                }
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) acc_up[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mi], b4[mi][ni], acc_up[mi][ni], 0, 0, 0);
-                if constexpr (LAST) {
-#pragma unroll
-                    for (int j = 0; j < NOPS; ++j)
-                        if (j * UP_NSTEP / NOPS == st) dma_fast(j, cur_kb, rs_m0, 0u, 0u, nxt);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < UP_NOPS; ++j)
-                        if (j * UP_NSTEP / UP_NOPS == st) dma_up(j, soff_in_nxt, soff_w_nxt, nxt);
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        };
-        for (int ub = 0; ub + 1 < nup; ++ub) up_iter(ub, std::false_type{});
-        up_iter(nup - 1, std::true_type{});
-    }
     // K-block 0 of an operator with an unpooled-source chain is peeled: its steps carry that chain's loads
     int kb_begin = 0;
     if constexpr (HAS_UP) {
@@ -828,12 +725,6 @@ conv3x3_mfma(const ConvArgs a)
     const unsigned long long t_loop1 = EIG_TIMING ? __builtin_readcyclecounter() : 0;
 
     // ---------------------------------------------------------------- epilogue
-    if constexpr (FUSE) {  // one fp32 addition of the two chains, as chainer adds the outputs of its separate convolutions
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < NI; ++ni) acc[mi][ni] = acc[mi][ni] + acc_up[mi][ni];
-    }
     if (has_up) {
 #pragma unroll
         for (int mi = 0; mi < MI_N; ++mi)

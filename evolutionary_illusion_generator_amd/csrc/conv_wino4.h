@@ -24,16 +24,19 @@
 //     channel's plane: conflict-free, where 4-byte reads of the two end columns were 8-way conflicted and cost the first version 25 %), 12-18 operations for the
 //     row, 12 for the column pass;
 //   K-block = FOUR channels (one MFMA k-step): 6 NI MFMAs per wave in six chunks with the operand read of the next chunk, staging in slices between the chunks;
-//   LDS (156 KB): plane ring 3 x 4 x [18 rows][40 floats] (one DMA instruction per wave and K-block), then U ring 3 x 36 KB ([36 pos][4 ch][16 cols][NI]; the packed
-//     weights are [N-blocks][K-blocks of 4][36][4][16][NI], a position of a K-block = one contiguous KB = one LDS-DMA instruction, three per wave and K-block), then 12 KB;
+//   LDS (156 KB): plane ring 3 x 4 x [18 rows][40 floats] (one DMA instruction per wave and K-block) and U ring 3 x 36 KB ([36 pos][4 ch][16 cols][NI]; the packed
+//     weights are [N-blocks][K-blocks of 4][36][4][16][NI], a position of a K-block = one contiguous KB = one LDS-DMA instruction, three per wave and K-block);
 //     U(j) is fetched during K-block j - 2 and waited for at its end, plane(j) during j - 3 and waited for at the end of j - 2 (vmcnt(1)): both are visible to
 //     everyone during K-block j - 1, whose last instructions read the first operands of j in front of the barrier -- the barrier never drains the matrix pipe;
-//   output transform: along nu in-lane (c_xi,b: 4 x NI vectors), then the six waves of a region exchange their c rows through LDS, ONE N-tile per round (48 KB = U slot 2
-//     + the 12 KB behind it), and the outputs are finished in image order (see the epilogue).
+//   output transform: along nu in-lane (c_xi,b: 4 x NI vectors), then the six waves of a region exchange their c rows through LDS in two rounds of 96 KB (N-tiles 0, 1
+//     then 2, 3), and the outputs are finished in image order (see the epilogue).
 // WALK (round 6): a block computes `nwalk` consecutive N-blocks of ITS tile (ConvArgs::nwalk, nparts = n_nblk / nwalk blocks per tile).  Everything per-lane is the same
-// for every N-block of a tile; what changes is scalar (the weight descriptor, the output channel base).  Right behind the last K-block of N-block n the waves issue the
-// prologue DMAs of N-block n + 1 (U slabs of K-blocks 0, 1 -> U slots 0, 1; planes of K-blocks 0, 1, 2) and only then run the finishing phase of n, which lives in U
-// slot 2 + 12 KB: the DMA round trip, the block dispatch and the address set-up of a fresh block are hidden behind the exchange (profiles/r06_b_w4_walk.txt).
+// for every N-block of a tile; what changes is scalar (the weight descriptor, the output channel base).  LDS map: plane slots 0, 1 | U slot 0 | X = U slots 1, 2, plane slot
+// 2, 12 KB.  Right behind the last K-block of N-block n the waves issue PART A of the prologue of n + 1 (U slab of K-block 0, planes of K-blocks 0, 1: 60 KB outside X) and
+// only then run the finishing phase of n, whose exchange rounds live in X; part B (U slab of K-block 1, plane of K-block 2 -> X) follows behind the barrier at the top of
+// n + 1 and is waited for at the end of its K-block 0: the DMA round trip, the block dispatch and the address set-up of a fresh block are hidden behind the exchange
+// (profiles/r06_c_walk_v2_timeline.txt; DESIGN.md section 3.1 has the A/Bs and register tables of the three builds).
+// TALL: a second block shape, 32 rows x 16 columns, for narrow maps (see w4_row below).
 #pragma once
 #include "wino_launch.h"
 
