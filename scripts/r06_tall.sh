@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 6: the tall (32 x 16) block shape of the F(4x4) kernel -- parity with the shape forced on / off and as chosen by map size, then same-box A/Bs per shape
+# (recipe kept as the record of how profiles/r06_j_* were taken; second argument: a library variant under evolutionary_illusion_generator_amd/, default libeigen_tall.so = this tree)
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r06_j}; mkdir -p $O

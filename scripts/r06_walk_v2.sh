@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 6: walking F(4x4) kernel, layout v2 (two-round exchange outside the prefetched area) -- bit-exactness, same-box A/B against the round-5 kernel, per-wave timeline
+# (recipe kept as the record of how profiles/r06_c_* were taken: libeigen_base.so = the round-5 tree + the ABI-4 export, built with `python __graft_entry__.py --lib`;
+#  scripts/_timing/libeigen_timing.so = this tree with -DEIG_TIMING=1)
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r06_c}; mkdir -p $O
