@@ -101,16 +101,20 @@ template <typename V4> __device__ __forceinline__ void w4_out1d(const V4& m0, co
     for (int e = 0; e < 4; ++e) { Y[1][e] = fmaf(2.0f, w[e], d[e]); Y[2][e] = fmaf(4.0f, u[e], s[e]); Y[3][e] = fmaf(8.0f, w[e], d[e]) + m5[e]; }
 }
 
-template <int NI, int EPI, bool TALL = false>
-__global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
+// HALF (round 6): a block of ONE region -- 8 rows x 32 columns, six waves (wave = row xi of the position grid), everything else as the wide shape with rg = 0.  For launches
+// of less than one block per CU (configs[0]: 10 to 40 blocks): their time is ONE block's time, and a six-wave block has the CU's matrix pipe to itself for half the
+// multiply-adds.  A choice by launch size (eigen_engine.hip), like the walk; the chains do not depend on it.
+template <int NI, int EPI, bool TALL = false, bool HALF = false>
+__global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 {
+    static_assert(!(TALL && HALF), "half blocks exist in the wide shape only");
     static_assert(EPI == EPI_LSTM || EPI == EPI_CONVA || EPI == EPI_CONVP, "conv_wino4.h: ConvLSTM, ConvA, ConvP");
     static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
     static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
     constexpr int U4 = wino4_u_floats(NI);
     constexpr int KC = W4_KC, PS = w4_ps(TALL), W4_ROW = w4_row(TALL);
     constexpr int W4_P0 = w4_p(TALL, 0), W4_P1 = w4_p(TALL, 1), W4_P2 = w4_p(TALL, 2), W4_U0 = w4_u(TALL, 0), W4_U1 = w4_u(TALL, 1), W4_U2 = w4_u(TALL, 2);
-    constexpr bool WALK = !TALL;                     // (tall blocks: one N-block per block -- with 16 KB plane slots the prefetched part of a next N-block does not fit beside the exchange area)
+    constexpr bool WALK = !TALL && !HALF;                     // (tall blocks: one N-block per block -- with 16 KB plane slots the prefetched part of a next N-block does not fit beside the exchange area)
     constexpr int RGH = TALL ? 16 : 8;               // rows of a region
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py with EIG_TL_WAVES=12)
@@ -118,7 +122,9 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     float* const Ub = lds;
     float* const xb = lds + w4_x(TALL);
     const int wv_o = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int rg_o = wv_o & 1, xi_o = wv_o >> 1;
+    const int rg_o = HALF ? 0 : wv_o & 1, xi_o = HALF ? wv_o : wv_o >> 1;
+    constexpr int NWAVES = HALF ? W4_WAVES / 2 : W4_WAVES;
+    constexpr int UPW = 36 / NWAVES;                  // positions of a U slab a wave fetches: 3 (HALF: 6 -- its own row of the position grid)
     // The lane index, opaque to the compiler: every per-lane quantity of the K loop and of the finishing phase is derived from a FRESH copy at the point of use, so
     // that nothing per-lane is hoisted out of the walk and carried in registers (or scratch) across the phase that does not need it -- the walking kernel of round 5
     // spilled 42 registers that way, the first version of this one 9.
@@ -140,7 +146,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int eb = dv(tlin, tiles, a.mg[1]);
     const int t_ = tlin - eb * tiles;
     const int tyi = dv(t_, a.tilesX, a.mg[2]), txi = t_ - tyi * a.tilesX;
-    const int y0 = tyi * (TALL ? 32 : 16), x0 = txi * (TALL ? 16 : 32);
+    const int y0 = tyi * (TALL ? 32 : (HALF ? 8 : 16)), x0 = txi * (TALL ? 16 : 32);
     const int HW = a.H * a.W;
 
     const bool up_fused = EPI == EPI_LSTM && a.up_src != nullptr;
@@ -170,7 +176,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     int zs = 0;
     asm volatile("" : "+s"(zs));
     const int wv = wv_o + zs, rg = rg_o + zs, xi = xi_o + zs, nkb = nkb_o + zs, up_lo = up_lo_o + zs, up_hi = up_hi_o + zs;
-    const int pch = wv / 3, ppart = wv - pch * 3;
+    const int pch = HALF ? wv >> 1 : wv / 3, ppart = HALF ? wv & 1 : wv - pch * 3;   // this wave's plane DMA: channel, part of 64 chunks
     const int eb_i = eb + zs, y0_i = y0 + zs, x0_i = x0 + zs;
     const unsigned long long sb0 = (unsigned long long)(a.src[0].ptr + (size_t)eb_i * a.src[0].Ct * HW);
     const unsigned long long sb1 = has1 ? (unsigned long long)(a.src[1].ptr + (size_t)eb_i * a.src[1].Ct * HW) : sb0;
@@ -182,7 +188,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int q = lane >> 4, col = lane & 15;
     // wide: 18 rows x 10 chunks (unpooled source: 10 rows x 6 chunks at half resolution); tall: 34 rows x 6 chunks at a row stride of 7 (18 rows x 4 chunks), four parts
     // per channel: waves 0-3 fetch part 3 of channel wv with a second instruction (roff2 / uoff2)
-    constexpr int CPR = TALL ? 7 : 10, CREAL = TALL ? 6 : 10, NCHK = TALL ? 34 * 7 : 180, UROWS = TALL ? 18 : 10, UCHK = TALL ? 4 : 6;
+    constexpr int CPR = TALL ? 7 : 10, CREAL = TALL ? 6 : 10, NCHK = TALL ? 34 * 7 : (HALF ? 100 : 180), UROWS = TALL ? 18 : (HALF ? 6 : 10), UCHK = TALL ? 4 : 6;
     auto plane_offsets = [&](int part, int& ro, int& uo) __attribute__((always_inline)) {
         const int c = lane + 64 * part;
         const int row = c / CPR, cx = c - row * CPR;
@@ -193,8 +199,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     };
     int roff, uoff, roff2 = -1, uoff2 = -1;
     plane_offsets(ppart, roff, uoff);
-    const bool two_parts = TALL && wv_o < 4;   // (wave-uniform)
+    // second plane instruction of some waves: tall -- part 3 of channel wv (waves 0-3); half -- channel 3, part wv & 1 (waves 0, 1: eight parts over six waves)
+    const bool two_parts = (TALL && wv_o < 4) || (HALF && wv_o < 2);   // (wave-uniform)
     if (TALL) plane_offsets(3, roff2, uoff2);
+    if (HALF) { roff2 = roff; uoff2 = uoff; }
+    const int ch2 = HALF ? 3 : wv, part2 = HALF ? ppart : 3;
     auto dma_plane_at = [&](int jj, int slot_off) __attribute__((always_inline)) {   // (prologue) this wave's plane DMA of K-block min(jj, nkb - 1) -> the plane slot at float offset slot_off
         const int j = jj < nkb ? jj : nkb - 1;
         const bool up = EIG4_IS_UP(j);
@@ -210,8 +219,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + pch * PS + ppart * 256), 16,
                                                  (int)__builtin_elementwise_add_sat((unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (unsigned)mu), coff), 0, 0, 0);
         if (two_parts) {
-            const unsigned coff2 = (unsigned)((j - base) * KC + wv) * (unsigned)(hw * 4);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + wv * PS + 3 * 256), 16,
+            const unsigned coff2 = (unsigned)((j - base) * KC + ch2) * (unsigned)(hw * 4);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + ch2 * PS + part2 * 256), 16,
                                                      (int)__builtin_elementwise_add_sat((unsigned)roff2 + (((unsigned)uoff2 - (unsigned)roff2) & (unsigned)mu), coff2), 0, 0, 0);
         }
     };
@@ -227,17 +236,17 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     auto prologue_a = [&](int nb) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nb * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + W4_U0 + (3 * wv + i) * W4_UPOS), 16, uvo, (int)((unsigned)(3 * wv + i) * W4_POSB), 0, 0);
+        for (int i = 0; i < UPW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + W4_U0 + (UPW * wv + i) * W4_UPOS), 16, uvo, (int)((unsigned)(UPW * wv + i) * W4_POSB), 0, 0);
         dma_plane_at(0, W4_P0);
         dma_plane_at(1, W4_P1);
     };
     auto prologue_b = [&](int nb) __attribute__((always_inline)) {
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nb * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + W4_U1 + (3 * wv + i) * W4_UPOS), 16, uvo,
-                                                     (int)((unsigned)U4 * 4 + (unsigned)(3 * wv + i) * W4_POSB), 0, 0);
+        for (int i = 0; i < UPW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Ub + W4_U1 + (UPW * wv + i) * W4_UPOS), 16, uvo,
+                                                     (int)((unsigned)U4 * 4 + (unsigned)(UPW * wv + i) * W4_POSB), 0, 0);
         dma_plane_at(2, W4_P2);
     };
 
@@ -255,11 +264,11 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
         EIG4_WAITCNT(0x0F70);
     }
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)(a.wpk + (size_t)nblk * nkb * U4), 0, (nkb + 1) * U4 * 4, 0x00020000);
-    unsigned u_so = (unsigned)(3 * wv) * W4_POSB + 2u * (unsigned)U4 * 4u;   // (K-blocks 0, 1 came with the prologue)
+    unsigned u_so = (unsigned)(UPW * wv) * W4_POSB + 2u * (unsigned)U4 * 4u;   // (K-blocks 0, 1 came with the prologue)
     auto dma_u = [&](int slot_off) __attribute__((always_inline)) {   // -> the U slot at float offset slot_off
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(Ub + slot_off + (3 * wv + i) * W4_UPOS), 16, uvo,
+        for (int i = 0; i < UPW; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(Ub + slot_off + (UPW * wv + i) * W4_UPOS), 16, uvo,
                                                      (int)(u_so + (unsigned)i * W4_POSB), 0, 0);
         u_so += (unsigned)U4 * 4;
     };
@@ -281,7 +290,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
             unsigned hwid, xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            unsigned long long* dd = a.dbg + (((size_t)blockIdx.x * nwalk + it) * W4_WAVES + wv) * 8;
+            unsigned long long* dd = a.dbg + (((size_t)blockIdx.x * nwalk + it) * NWAVES + wv) * 8;
             const unsigned long long tq_end = __builtin_readcyclecounter();
             dd[0] = tq_entry; dd[1] = tq_setup; dd[2] = tq_k0; dd[3] = tq_k1; dd[4] = tq_x; dd[5] = tq_y; dd[6] = tq_end;
             dd[7] = (unsigned long long)hwid | ((unsigned long long)xcc << 32);
@@ -325,8 +334,8 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
                                                      (int)__builtin_elementwise_add_sat(o, pcoff), 0, 0, 0);
             if (two_parts) {
                 const unsigned o2 = (unsigned)roff2 + (((unsigned)uoff2 - (unsigned)roff2) & (0u - (unsigned)pup));
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + wv * PS + 3 * 256), 16,
-                                                         (int)__builtin_elementwise_add_sat(o2, pcoff + (unsigned)(wv - pch) * phw4), 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + ch2 * PS + part2 * 256), 16,
+                                                         (int)__builtin_elementwise_add_sat(o2, pcoff + (unsigned)(ch2 - pch) * phw4), 0, 0, 0);
             }
             if (__builtin_expect(pj + 1 == pbound, 0)) { if (pbound < nkb) plane_source(pj + 1); }   // (at the end the cursor stays on the last K-block)
             else { ++pj; pcoff += KC * phw4; }
@@ -511,7 +520,7 @@ __global__ void __launch_bounds__(W4_THREADS, 3) wino4_kernel(const ConvArgs a)
     const int j = TALL ? lane & 3 : lane & 7, chl = TALL ? lane >> 2 : lane >> 3, e_r = j & 3, ql = TALL ? 0 : j >> 2;
     int woff[4];                                                           // publishing lane (q, col): its slot in plane e
 #pragma unroll
-    for (int e = 0; e < 4; ++e) woff[e] = ((wv * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + (TALL ? 0 : 8 * (q & 1))) & 15)) * 4;
+    for (int e = 0; e < 4; ++e) woff[e] = (((2 * xi + rg) * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + (TALL ? 0 : 8 * (q & 1))) & 15)) * 4;
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
         // All twelve waves finish outputs, and they finish them in IMAGE order: the exchange is laid out so that a finishing lane reads the four pixels b = 0..3 of ONE tile
         // as a 16-byte vector, and finishing lane L takes the 16-byte chunk j = L & 7 of a 32-pixel block row (tile tx = j, writer lane q = 2 ty + (j >> 2), register e =

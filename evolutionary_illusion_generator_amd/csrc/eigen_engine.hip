@@ -520,6 +520,12 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             static const int tall_env = getenv("EIGEN_W4_TALL") ? atoi(getenv("EIGEN_W4_TALL")) : -1;
             const bool tall = tall_env >= 0 ? tall_env != 0 : ((op.W + 15) / 16) * ((op.H + 31) / 32) < ((op.W + 31) / 32) * ((op.H + 15) / 16);
             a.tilesX = tall ? (op.W + 15) / 16 : (op.W + 31) / 32; a.tilesY = tall ? (op.H + 31) / 32 : (op.H + 15) / 16;
+            // Half blocks (conv_wino4.h: HALF, 8 x 32 pixels on six waves) while even THEY are at most one block per CU: the launch's time is then ONE block's time, and a half
+            // block has the CU's matrix pipe to itself for half the multiply-adds (c1: +15 %; with more half blocks than CUs the second round costs more than the halving gains --
+            // c2's 20 x 15 top layer, 200 full blocks: -7 %).  A choice by launch size, like the walk.  EIGEN_W4_HALF = 0 / 1 forces it (A/B, tests).
+            static const int half_env = getenv("EIGEN_W4_HALF") ? atoi(getenv("EIGEN_W4_HALF")) : -1;
+            const bool half = !tall && (half_env >= 0 ? half_env != 0 : (long long)op.n_nblk * batch * a.tilesX * ((op.H + 7) / 8) <= e->n_cu);
+            if (half) a.tilesY = (op.H + 7) / 8;
             const int ntile4 = batch * a.tilesX * a.tilesY;
             // WALK (conv_wino4.h): nparts blocks per tile, each computing nwalk = n_nblk / nparts consecutive N-blocks of it: walks of three N-blocks where n_nblk allows, of
             // two otherwise (the blocks of a tile share its planes through the XCD's L2), no walk while the launch would not give every CU four blocks.  A property of the
@@ -533,23 +539,23 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
                 if ((long long)(op.n_nblk / nwalk) * ntile4 < 4ll * e->n_cu) nwalk = 1;
                 nparts = op.n_nblk / nwalk;
             }
-            if (tall) nparts = op.n_nblk;   // (tall blocks do not walk)
+            if (tall || half) nparts = op.n_nblk;   // (tall and half blocks do not walk)
             a.nparts = nparts; a.nwalk = op.n_nblk / nparts;
             const int g4 = nparts * ((ntile4 + 7) / 8) * 8;
             {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
                 auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };
                 a.mg[0] = magic(nparts); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
             }
-            op.last_grid = g4 * a.nwalk; op.last_waves = W4_WAVES;   // (timeline records: one per block and N-block of its walk)
+            op.last_grid = g4 * a.nwalk; op.last_waves = half ? W4_WAVES / 2 : W4_WAVES;   // (timeline records: one per block and N-block of its walk)
 #if EIG_TIMING
             if (tl_dbg) {   // sized from THIS launch's records (the buffer above was sized for the four-wave grid)
                 (void)hipFree(tl_dbg);
-                (void)hipMalloc((void**)&tl_dbg, (size_t)op.last_grid * W4_WAVES * 64);
-                (void)hipMemset(tl_dbg, 0, (size_t)op.last_grid * W4_WAVES * 64);
+                (void)hipMalloc((void**)&tl_dbg, (size_t)op.last_grid * op.last_waves * 64);
+                (void)hipMemset(tl_dbg, 0, (size_t)op.last_grid * op.last_waves * 64);
                 a.dbg = tl_dbg;
             }
 #endif
-            r = launch_wino4(op.NI, op.epi, tall, a, g4, st);
+            r = launch_wino4(op.NI, op.epi, tall ? W4_TALL : (half ? W4_HALF : W4_WIDE), a, g4, st);
         } else {
             a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
             const int nt = batch * a.tilesX * a.tilesY;

@@ -19,9 +19,10 @@ constexpr int W16_WAVES = 16;
 constexpr int wino_u_floats(int NI) { return 16 * KC * 16 * NI; }   // one packed K-block of F(2x2) weights: [16 pos][8 ch][16 cols][NI]: 8192 floats for NI = 4
 static_assert(KC == 8, "F(2x2) operators: 8-channel K-blocks");
 
-// grid blocks of wino4_kernel<NI, epi, tall> / wino16_kernel<NI, epi> on stream st (NI = 3 or 4; epi = EPI_LSTM (NI = 4 only), EPI_CONVA, EPI_CONVP); the first launch of an
-// instantiation sets its dynamic-LDS attribute
-hipError_t launch_wino4(int NI, int epi, bool tall, const ConvArgs& a, int grid, hipStream_t st);
+// grid blocks of wino4_kernel<NI, epi, shape> / wino16_kernel<NI, epi> on stream st (NI = 3 or 4; epi = EPI_LSTM (NI = 4 only), EPI_CONVA, EPI_CONVP); the first launch of an
+// instantiation sets its dynamic-LDS attribute.  shape: W4_WIDE 16 x 32-pixel blocks, W4_TALL 32 x 16, W4_HALF 8 x 32 (six waves)
+enum { W4_WIDE = 0, W4_TALL = 1, W4_HALF = 2 };
+hipError_t launch_wino4(int NI, int epi, int shape, const ConvArgs& a, int grid, hipStream_t st);
 hipError_t launch_wino16(int NI, int epi, const ConvArgs& a, int grid, hipStream_t st);
 
 }  // namespace eig
