@@ -39,8 +39,7 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 PEAK_HBM_TBS = 8.0            # MI355X_MICROARCH.md: HBM3E
 LSTM_KERNEL_TAG = "conv3x3_mfma<4, 16, 1"  # the dominant kernel's name in rocprofv3 output (EPI_LSTM = 1)
-WINO16_KERNEL_TAG = "wino16_kernel<4, 1>"    # ... when the ConvLSTM chains run in their Winograd form: the sixteen-wave F(2x2, 3x3) kernel (csrc/conv_wino16.h; EIGEN_WINOGRAD without bits 25-27)
-WINO4_KERNEL_TAG = "wino4_kernel<4, 1,"      # ... and the F(4x4, 3x3) kernel (csrc/conv_wino4.h, the default; third template argument: the block shape -- wide at the headline shape)
+WINO4_KERNEL_TAG = "wino4_kernel<4, 1,"      # ... when the ConvLSTM chains run in their Winograd form: the F(4x4, 3x3) kernel (csrc/conv_wino4.h, the default; third template argument: the block shape -- wide at the headline shape)
 N_STEPS_PREDNET = 21          # steps 1-20 + first extension (the 22nd step is never read on the population path)
 
 SHAPES = {
@@ -606,7 +605,7 @@ def main():
             elif pm.get("pop") != nb:
                 traffic_note = "PMC summary is for a device batch of %s genomes, this run uses %d: not reported" % (pm.get("pop"), nb)
             else:
-                tags = (WINO4_KERNEL_TAG, WINO16_KERNEL_TAG) if any(r.get("wino") for r in lstm) else (LSTM_KERNEL_TAG,)
+                tags = (WINO4_KERNEL_TAG,) if any(r.get("wino") for r in lstm) else (LSTM_KERNEL_TAG,)
                 for tag in tags:   # (the first tag the summary holds: the kernel that ran the ConvLSTMs of that build)
                     hit = [kv for kname, kv in pm["kernels"].items() if tag in kname]
                     if hit:
@@ -626,10 +625,8 @@ def main():
         alg_bytes = {l_: convlstm_algorithmic_bytes(CHANNELS, W, H, l_) * nb for l_ in s8d_layer}
         launches_l = {l_: sum(r["launches"] for r in lstm if r["layer"] == l_) for l_ in s8d_layer}
         alg_bytes_avg = sum(alg_bytes[l_] * launches_l[l_] for l_ in alg_bytes) / max(n_l, 1)
-        wmask = int(os.environ.get("EIGEN_WINOGRAD") or "0x0FFFFFFE", 0)
-        out["roofline"] = {"bound": "mfma", "kernel": (("wino4_kernel<4,EPI_LSTM> (ConvLSTM, E / unpooled R / h chains as Winograd F(4x4,3x3): 36 multiply-adds per channel and 4x4 outputs where the direct form needs 144, fused gates, v_mfma_f32_16x16x4_f32)"
-                                                        if (wmask >> 25) & 1 else
-                                                        "wino16_kernel<4,EPI_LSTM> (ConvLSTM, E / unpooled R / h chains as Winograd F(2x2,3x3): 16 of 36 multiply-adds, fused gates, v_mfma_f32_16x16x4_f32)")
+        wmask = int(engine_mod.load_library().eigen_winograd_mask()) & 0xFFFFFFFF
+        out["roofline"] = {"bound": "mfma", "kernel": ("wino4_kernel<4,EPI_LSTM> (ConvLSTM, E / unpooled R / h chains as Winograd F(4x4,3x3): 36 multiply-adds per channel and 4x4 outputs where the direct form needs 144, fused gates, v_mfma_f32_16x16x4_f32)"
                                                        if wino_rows else "conv3x3_mfma<4,16,EPI_LSTM> (fused ConvLSTM gates, v_mfma_f32_16x16x4_f32)"),
                            "winograd_mask": "0x%08X" % wmask,
                            "winograd_layers": sorted({r["layer"] for r in wino_rows}),

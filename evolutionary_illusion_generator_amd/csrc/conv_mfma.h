@@ -125,7 +125,7 @@ struct ConvArgs {
     // Chain of an unpooled source (written by an EPI_UP4 launch at HALF this resolution), [B][4][n_nblk*NB][H/2][W/2], added to
     // this launch's chain with one fp32 addition after the K loop; nullptr: none.
     const float* acc_init;
-    // The unpooled source R_{l+1} ITSELF, for the operators that chain it inside their own launch: the Winograd ConvLSTMs (conv_wino16.h / conv_wino4.h: in the same
+    // The unpooled source R_{l+1} ITSELF, for the operators that chain it inside their own launch: the Winograd ConvLSTMs (conv_wino4.h: in the same
     // chains, weights in wpk) -- no EPI_UP4 pass and no partial-chain tensor exist for them.
     const float* up_src;   // [B][up_C][H/2][W/2]
     int up_C;              // real channels of the unpooled source

@@ -1,5 +1,5 @@
 // conv_wino4.h -- the 3x3 convolutions of PredNet layers >= 1 (ConvLSTM over E_l / unpooled R_{l+1} / h_l, ConvA, ConvP) as Winograd F(4x4, 3x3) on the fp32
-// matrix pipe: 36 multiply-adds per channel and 4x4 output pixels where F(2x2, 3x3) (conv_wino16.h) needs 64 and the direct form 144.
+// matrix pipe: 36 multiply-adds per channel and 4x4 output pixels where F(2x2, 3x3) (rounds 4-5: a sixteen-wave kernel, removed in round 6) needs 64 and the direct form 144.
 // DESIGN.md section 3.1.
 //
 // Why: at fp32 only FEWER multiply-adds make the roll-out faster, and the parity half of the question was answered BEFORE this kernel was written

@@ -16,7 +16,7 @@
 #include "../../include/eigen_engine.h"
 #define EIG_ENGINE_UNIT 1   // (conv_mfma.h: the non-template kernels are defined in this unit)
 #include "conv_mfma.h"
-#include "wino_launch.h"   // the Winograd kernels live in wino4_kernels.hip / wino16_kernels.hip
+#include "wino_launch.h"   // the Winograd kernels live in wino4_kernels.hip / wino4t_kernels.hip / wino4h_kernels.hip / wino4h_kernels.hip
 #include "cppn_kernel.h"
 #include "farneback_kernels.h"
 #include "flow_kernels.h"
@@ -56,11 +56,10 @@ struct ConvOp {
     double macs = 0;  // algorithmic multiply-accumulates per image (real channels only)
     double ms = 0;    // profiling accumulator
     int launches = 0;
-    // Winograd ConvLSTM below the top layer: its unpooled source R_{l+1} rides inside the same chains (conv_wino16.h / conv_wino4.h: up_fused)
+    // Winograd ConvLSTM below the top layer: its unpooled source R_{l+1} rides inside the same chains (conv_wino4.h: up_fused)
     bool fused = false;
     int up_C = 0, up_kb = 0;
-    bool wino = false;  // Winograd form (conv_wino16.h / conv_wino4.h); epi stays the operator's epilogue
-    int wino_tile = 2;  // ... F(2x2, 3x3) or F(4x4, 3x3) (bits 25-27 of EIGEN_WINOGRAD; conv_wino4.h)
+    bool wino = false;  // Winograd F(4x4, 3x3) form (conv_wino4.h); epi stays the operator's epilogue
 };
 
 struct Layer {
@@ -344,10 +343,11 @@ static std::vector<float> pack_weights_up4c(const ConvOp& op, const float* const
     return out;
 }
 
-// ---- Winograd F(2x2, 3x3) form of the ConvLSTM's E_l / h_l chain (conv_wino16.h; oracle/eig_oracle.c: wino_weights states the same rule)
-// EIGEN_WINOGRAD: bit l = ConvLSTM_l, bit 8 + l = ConvA_l, bit 16 + l = ConvP_l may take the Winograd form (if eligible).  Default: all
-// of them -- measured faster at every shape tried, 256^2 / 512^2 / 640x480 / 160x120, colour and gray, incl. 40 x 30 maps that 16 x 16
-// tiles cover to 78 % (profiles/r04_h_wino_shapes.txt).  Eligibility (the same rule in oracle/eig_oracle.c: eig_wino_op) is a property
+// ---- Winograd F(4x4, 3x3) form of the 3x3 convolutions of layers >= 1 (conv_wino4.h; oracle/eig_oracle.c: wino4_* state the same rule)
+// EIGEN_WINOGRAD: bit l = ConvLSTM_l, bit 8 + l = ConvA_l, bit 16 + l = ConvP_l may take the Winograd form (if eligible) AND bit 25 / 26 / 27 enables it for the
+// ConvLSTMs / ConvAs / ConvPs as a class (rounds 4-5 had an F(2x2, 3x3) kernel behind the per-operator bits and F(4x4) behind the class bits; round 6 removed the
+// F(2x2) kernel -- nothing ran it -- and an operator whose class bit is clear now runs direct).  Default: all of them -- measured faster at every shape tried,
+// 256^2 / 512^2 / 640x480 / 160x120, colour and gray.  Eligibility (the same rule in oracle/eig_oracle.c: eig_wino_op) is a property
 // of the operator's shape only, never of the batch: results must not depend on the device batch a genome lands in.
 //   kind 0 ConvLSTM_l, 1 ConvA_l, 2 ConvP_l; Cin = channels of the full-resolution sources (multiples of 8 each), Cout per gate;
 //   H x W = the resolution the convolution runs at; odd H only for an operator of the TOP layer (nothing is pooled / unpooled from it)
@@ -366,27 +366,11 @@ static int wino_mask_env()
 }
 static bool wino_op(int mask, int kind, int l, int Cin, int Cout, int H, int W, bool top)
 {
-    if (!((mask >> (8 * kind + l)) & 1) || l < 1) return false;
+    if (!((mask >> (8 * kind + l)) & 1) || !((mask >> (25 + kind)) & 1) || l < 1) return false;
     if ((Cin % 8) || (Cout % 16) || (W % 4)) return false;
     if ((H % 2) && !(top && kind != 1)) return false;
     if (kind != 0 && (Cout % 48) && (Cout % 64)) return false;  // plain convolutions: N-blocks of 48 or 64 columns without padding
     return true;
-}
-static void wino_weight(const float* g, float* U)  // U = G g G^T: rows first, then columns; fp32, one rounding per operation
-{
-    volatile float s[4][3];
-    for (int j = 0; j < 3; ++j) {
-        s[0][j] = g[j];
-        { volatile float t = g[j] + g[3 + j]; t = t + g[6 + j]; s[1][j] = t * 0.5f; }
-        { volatile float t = g[j] - g[3 + j]; t = t + g[6 + j]; s[2][j] = t * 0.5f; }
-        s[3][j] = g[6 + j];
-    }
-    for (int i = 0; i < 4; ++i) {
-        U[i * 4 + 0] = s[i][0];
-        { volatile float t = s[i][0] + s[i][1]; t = t + s[i][2]; U[i * 4 + 1] = t * 0.5f; }
-        { volatile float t = s[i][0] - s[i][1]; t = t + s[i][2]; U[i * 4 + 2] = t * 0.5f; }
-        U[i * 4 + 3] = s[i][2];
-    }
 }
 // F(4x4, 3x3): U = G g G^T, 6 x 6 (oracle/eig_oracle.c: wino4_w1d / wino4_weights state the same operations in the same order; fmaf = one rounding, this file
 // is compiled with -ffp-contract=off)
@@ -406,16 +390,16 @@ static void wino4_weight(const float* g, float* U)
     for (int j = 0; j < 3; ++j) { wino4_w1d(g[j], g[3 + j], g[6 + j], W); for (int i = 0; i < 6; ++i) s[i][j] = W[i]; }
     for (int i = 0; i < 6; ++i) wino4_w1d(s[i][0], s[i][1], s[i][2], U + i * 6);
 }
-// [n_nblk][K-blocks: 8 (tile 4: 4) channels of one source, sources in order][16 (tile 4: 36) positions][8 (4) channels][16 columns][NI N-tiles]
+// [n_nblk][K-blocks: 4 channels of one source, sources in order][36 positions][4 channels][16 columns][NI N-tiles]
 // lstm: N-tile = gate, output channel = 16 nb + column (srcw[s][gate]); plain convolution: output channel = 16 (NI nb + N-tile) + column (srcw[s][0])
-static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm, int nsrc, const int* src_C, const int* src_Cw, const float* const srcw[3][4], int tile = 2)
+static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm, int nsrc, const int* src_C, const int* src_Cw, const float* const srcw[3][4])
 {
-    const int kc = tile == 4 ? 4 : KC;   // channels of a packed K-block: F(4x4) 4 (conv_wino4.h streams them with a running offset, and one K-block past the end: padding)
+    const int kc = W4_KC;   // channels of a packed K-block (conv_wino4.h streams them with a running offset, and one K-block past the end: padding)
     int nkb = 0;
     for (int s = 0; s < nsrc; ++s) nkb += src_C[s] / kc;
-    const int npos = tile == 4 ? 36 : 16;
-    const int uf = tile == 4 ? wino4_u_floats(NI) : wino_u_floats(NI);
-    std::vector<float> out((size_t)n_nblk * nkb * uf + (tile == 4 ? uf : 0), 0.0f);
+    const int npos = W4_NPOS;
+    const int uf = wino4_u_floats(NI);
+    std::vector<float> out((size_t)n_nblk * nkb * uf + uf, 0.0f);
     float U[36];
     for (int nb = 0; nb < n_nblk; ++nb) {
         int kb0 = 0;
@@ -425,8 +409,7 @@ static std::vector<float> pack_weights_wino(int C, int NI, int n_nblk, bool lstm
                     for (int n = 0; n < 16; ++n) {
                         const int o = lstm ? nb * 16 + n : (nb * NI + ni) * 16 + n;
                         if (o >= C) continue;
-                        if (tile == 4) wino4_weight(srcw[s][lstm ? ni : 0] + ((size_t)o * src_Cw[s] + c) * 9, U);
-                        else wino_weight(srcw[s][lstm ? ni : 0] + ((size_t)o * src_Cw[s] + c) * 9, U);
+                        wino4_weight(srcw[s][lstm ? ni : 0] + ((size_t)o * src_Cw[s] + c) * 9, U);
                         float* dst = &out[((size_t)nb * nkb + kb0 + c / kc) * uf];
                         for (int pos = 0; pos < npos; ++pos) dst[((pos * kc + (c % kc)) * 16 + n) * NI + ni] = U[pos];
                     }
@@ -494,7 +477,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     const bool vec = (op.W % 4) == 0;
 #if EIG_TIMING
     unsigned long long* tl_dbg = nullptr;
-    if (getenv("EIGEN_TIMELINE") && (op.epi == EPI_LSTM || (op.epi == EPI_UP4 && op.NI == 4) || (op.wino_tile == 4 && getenv("EIGEN_TIMELINE_ALL"))) && ++op.tl_seen == 6) {  // a steady-state launch of every ConvLSTM op and 2x2-form pass
+    if (getenv("EIGEN_TIMELINE") && (op.epi == EPI_LSTM || (op.epi == EPI_UP4 && op.NI == 4) || (op.wino && getenv("EIGEN_TIMELINE_ALL"))) && ++op.tl_seen == 6) {  // a steady-state launch of every ConvLSTM op and 2x2-form pass
         (void)hipMalloc((void**)&tl_dbg, (size_t)grid * 2 * 64 * 8);  // half blocks double the grid, W8 blocks have 8 waves
         (void)hipMemset(tl_dbg, 0, (size_t)grid * 2 * 64 * 8);
         a.dbg = tl_dbg;
@@ -512,58 +495,49 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     op.last_grid = grid; op.last_waves = (w8 == 1) ? 8 : 4;
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
-    if (op.wino) {  // Winograd form: F(4x4, 3x3) conv_wino4.h (twelve waves), F(2x2, 3x3) conv_wino16.h (sixteen waves)
-        if (op.wino_tile == 4) {   // 16 x 32-pixel blocks, twelve waves
-            if (op.epi == EPI_LSTM && a.acc_init != nullptr) return hipErrorInvalidConfiguration;   // (set_weights never pairs F(4x4) with a separate unpooled chain)
-            // Block shape (conv_wino4.h): 16 rows x 32 columns, or 32 x 16 ("tall") where that covers the MAP with fewer blocks -- 80 x 60: 10 instead of 12, 40 x 30: 3
-            // instead of 4 (the reference's 160 x 120); a function of the operator's map size alone, and the chains do not depend on it.  EIGEN_W4_TALL = 0 / 1 forces it (A/B, tests).
-            static const int tall_env = getenv("EIGEN_W4_TALL") ? atoi(getenv("EIGEN_W4_TALL")) : -1;
-            const bool tall = tall_env >= 0 ? tall_env != 0 : ((op.W + 15) / 16) * ((op.H + 31) / 32) < ((op.W + 31) / 32) * ((op.H + 15) / 16);
-            a.tilesX = tall ? (op.W + 15) / 16 : (op.W + 31) / 32; a.tilesY = tall ? (op.H + 31) / 32 : (op.H + 15) / 16;
-            // Half blocks (conv_wino4.h: HALF, 8 x 32 pixels on six waves) while even THEY are at most one block per CU: the launch's time is then ONE block's time, and a half
-            // block has the CU's matrix pipe to itself for half the multiply-adds (c1: +15 %; with more half blocks than CUs the second round costs more than the halving gains --
-            // c2's 20 x 15 top layer, 200 full blocks: -7 %).  A choice by launch size, like the walk.  EIGEN_W4_HALF = 0 / 1 forces it (A/B, tests).
-            static const int half_env = getenv("EIGEN_W4_HALF") ? atoi(getenv("EIGEN_W4_HALF")) : -1;
-            const bool half = !tall && (half_env >= 0 ? half_env != 0 : (long long)op.n_nblk * batch * a.tilesX * ((op.H + 7) / 8) <= e->n_cu);
-            if (half) a.tilesY = (op.H + 7) / 8;
-            const int ntile4 = batch * a.tilesX * a.tilesY;
-            // WALK (conv_wino4.h): nparts blocks per tile, each computing nwalk = n_nblk / nparts consecutive N-blocks of it: walks of three N-blocks where n_nblk allows, of
-            // two otherwise (the blocks of a tile share its planes through the XCD's L2), no walk while the launch would not give every CU four blocks.  A property of the
-            // launch only -- the bits do not depend on it.  EIGEN_W4_PARTS = n forces min(n, n_nblk) rounded down to a divisor (n >= n_nblk: one N-block per block), for A/B
-            // measurements and the parity tests.
-            static const int parts_env = getenv("EIGEN_W4_PARTS") ? atoi(getenv("EIGEN_W4_PARTS")) : 0;
-            int nparts;
-            if (parts_env > 0) { nparts = std::min(parts_env, op.n_nblk); while (op.n_nblk % nparts) --nparts; }
-            else {   // walks of three N-blocks where n_nblk allows (two otherwise), shorter while the launch would not give every CU four blocks
-                int nwalk = (op.n_nblk % 3 == 0) ? 3 : ((op.n_nblk % 2 == 0) ? 2 : 1);
-                if ((long long)(op.n_nblk / nwalk) * ntile4 < 4ll * e->n_cu) nwalk = 1;
-                nparts = op.n_nblk / nwalk;
-            }
-            if (tall || half) nparts = op.n_nblk;   // (tall and half blocks do not walk)
-            a.nparts = nparts; a.nwalk = op.n_nblk / nparts;
-            const int g4 = nparts * ((ntile4 + 7) / 8) * 8;
-            {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
-                auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };
-                a.mg[0] = magic(nparts); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
-            }
-            op.last_grid = g4 * a.nwalk; op.last_waves = half ? W4_WAVES / 2 : W4_WAVES;   // (timeline records: one per block and N-block of its walk)
-#if EIG_TIMING
-            if (tl_dbg) {   // sized from THIS launch's records (the buffer above was sized for the four-wave grid)
-                (void)hipFree(tl_dbg);
-                (void)hipMalloc((void**)&tl_dbg, (size_t)op.last_grid * op.last_waves * 64);
-                (void)hipMemset(tl_dbg, 0, (size_t)op.last_grid * op.last_waves * 64);
-                a.dbg = tl_dbg;
-            }
-#endif
-            r = launch_wino4(op.NI, op.epi, tall ? W4_TALL : (half ? W4_HALF : W4_WIDE), a, g4, st);
-        } else {
-            a.tilesX = (op.W + 15) / 16; a.tilesY = (op.H + 15) / 16;
-            const int nt = batch * a.tilesX * a.tilesY;
-            const int g = op.n_nblk * ((nt + 7) / 8) * 8;
-            op.last_grid = g; op.last_waves = 16;
-            if (op.epi == EPI_LSTM && a.acc_init != nullptr) return hipErrorInvalidConfiguration;   // (set_weights never pairs a Winograd ConvLSTM with a separate unpooled chain)
-            r = launch_wino16(op.NI, op.epi, a, g, st);
+    if (op.wino) {  // Winograd form: F(4x4, 3x3), conv_wino4.h
+        if (op.epi == EPI_LSTM && a.acc_init != nullptr) return hipErrorInvalidConfiguration;   // (set_weights never pairs F(4x4) with a separate unpooled chain)
+        // Block shape (conv_wino4.h): 16 rows x 32 columns, or 32 x 16 ("tall") where that covers the MAP with fewer blocks -- 80 x 60: 10 instead of 12, 40 x 30: 3
+        // instead of 4 (the reference's 160 x 120); a function of the operator's map size alone, and the chains do not depend on it.  EIGEN_W4_TALL = 0 / 1 forces it (A/B, tests).
+        static const int tall_env = getenv("EIGEN_W4_TALL") ? atoi(getenv("EIGEN_W4_TALL")) : -1;
+        const bool tall = tall_env >= 0 ? tall_env != 0 : ((op.W + 15) / 16) * ((op.H + 31) / 32) < ((op.W + 31) / 32) * ((op.H + 15) / 16);
+        a.tilesX = tall ? (op.W + 15) / 16 : (op.W + 31) / 32; a.tilesY = tall ? (op.H + 31) / 32 : (op.H + 15) / 16;
+        // Half blocks (conv_wino4.h: HALF, 8 x 32 pixels on six waves) while even THEY are at most one block per CU: the launch's time is then ONE block's time, and a half
+        // block has the CU's matrix pipe to itself for half the multiply-adds (c1: +15 %; with more half blocks than CUs the second round costs more than the halving gains --
+        // c2's 20 x 15 top layer, 200 full blocks: -7 %).  A choice by launch size, like the walk.  EIGEN_W4_HALF = 0 / 1 forces it (A/B, tests).
+        static const int half_env = getenv("EIGEN_W4_HALF") ? atoi(getenv("EIGEN_W4_HALF")) : -1;
+        const bool half = !tall && (half_env >= 0 ? half_env != 0 : (long long)op.n_nblk * batch * a.tilesX * ((op.H + 7) / 8) <= e->n_cu);
+        if (half) a.tilesY = (op.H + 7) / 8;
+        const int ntile4 = batch * a.tilesX * a.tilesY;
+        // WALK (conv_wino4.h): nparts blocks per tile, each computing nwalk = n_nblk / nparts consecutive N-blocks of it: walks of three N-blocks where n_nblk allows, of
+        // two otherwise (the blocks of a tile share its planes through the XCD's L2), no walk while the launch would not give every CU four blocks.  A property of the
+        // launch only -- the bits do not depend on it.  EIGEN_W4_PARTS = n forces min(n, n_nblk) rounded down to a divisor (n >= n_nblk: one N-block per block), for A/B
+        // measurements and the parity tests.
+        static const int parts_env = getenv("EIGEN_W4_PARTS") ? atoi(getenv("EIGEN_W4_PARTS")) : 0;
+        int nparts;
+        if (parts_env > 0) { nparts = std::min(parts_env, op.n_nblk); while (op.n_nblk % nparts) --nparts; }
+        else {   // walks of three N-blocks where n_nblk allows (two otherwise), shorter while the launch would not give every CU four blocks
+            int nwalk = (op.n_nblk % 3 == 0) ? 3 : ((op.n_nblk % 2 == 0) ? 2 : 1);
+            if ((long long)(op.n_nblk / nwalk) * ntile4 < 4ll * e->n_cu) nwalk = 1;
+            nparts = op.n_nblk / nwalk;
         }
+        if (tall || half) nparts = op.n_nblk;   // (tall and half blocks do not walk)
+        a.nparts = nparts; a.nwalk = op.n_nblk / nparts;
+        const int g4 = nparts * ((ntile4 + 7) / 8) * 8;
+        {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
+            auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };
+            a.mg[0] = magic(nparts); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
+        }
+        op.last_grid = g4 * a.nwalk; op.last_waves = half ? W4_WAVES / 2 : W4_WAVES;   // (timeline records: one per block and N-block of its walk)
+#if EIG_TIMING
+        if (tl_dbg) {   // sized from THIS launch's records (the buffer above was sized for the four-wave grid)
+            (void)hipFree(tl_dbg);
+            (void)hipMalloc((void**)&tl_dbg, (size_t)op.last_grid * op.last_waves * 64);
+            (void)hipMemset(tl_dbg, 0, (size_t)op.last_grid * op.last_waves * 64);
+            a.dbg = tl_dbg;
+        }
+#endif
+        r = launch_wino4(op.NI, op.epi, tall ? W4_TALL : (half ? W4_HALF : W4_WIDE), a, g4, st);
     } else {
     static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
     if (op.epi == EPI_CONVP && op.d_wraw && direct_p0) {  // image layer: HBM-bound, one thread per pixel (conv_mfma.h)
@@ -812,11 +786,11 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             if (wino_op(wino_env, 1, l, e->layer[l - 1].C, C, op.H, op.W, false)) {  // (the step-0 operator reads C_{l-1} channels: multiples of 8 too)
                 const int ni = (C % 64) ? 3 : 4, nb = C / (16 * ni);
                 const int sc[1] = {2 * e->layer[l - 1].C}, scw[1] = {2 * e->layer[l - 1].C}, sc0[1] = {e->layer[l - 1].C};
-                const int wt = ((wino_env >> 26) & 1) ? 4 : 2;   // F(4x4, 3x3): conv_wino4.h (oracle: eig_wino_tile)
-                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, scw, sw, wt);
-                std::vector<float> pw0 = pack_weights_wino(C, ni, nb, false, 1, sc0, scw, sw, wt);
+                const int wt = 4;   // F(4x4, 3x3) tiles
+                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, scw, sw);
+                std::vector<float> pw0 = pack_weights_wino(C, ni, nb, false, 1, sc0, scw, sw);
                 if (upload(&op.d_wpk, pw.data(), pw.size()) || upload(&t0.d_wpk, pw0.data(), pw0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvA%d, Winograd form)", l);
-                for (ConvOp* f : {&op, &t0}) { f->wino = true; f->wino_tile = wt; f->TW = 16; f->NI = ni; f->n_nblk = nb; }
+                for (ConvOp* f : {&op, &t0}) { f->wino = true; f->TW = 16; f->NI = ni; f->n_nblk = nb; }
                 const double tl = (double)((op.H + wt - 1) / wt) * ((op.W + wt - 1) / wt) * (wt + 2) * (wt + 2);   // tiles x positions
                 op.macs = tl * C * sc[0];
                 t0.macs = tl * C * sc0[0];
@@ -870,7 +844,7 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             if (upload(&t0.d_wpk, pk0.data(), pk0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, step 0)", l);
             // The chain of the unpooled source R_{l+1}.  Direct ConvLSTM (the image layer, ineligible shapes, EIGEN_WINOGRAD=0): a pass of its own at the source resolution
             // in 2x2 form (EPI_UP4 / EPI_UP4C), added to the ConvLSTM's chain with one fp32 addition.  Winograd ConvLSTM: INSIDE the same chains, between E_l and h_l
-            // (conv_wino16.h / conv_wino4.h: up_fused; oracle/eig_oracle.c: eig_wino_lstm) -- below the top layer the Winograd form exists only that way (16-byte rows at the
+            // (conv_wino4.h: up_fused; oracle/eig_oracle.c: eig_wino_lstm) -- below the top layer the Winograd form exists only that way (16-byte rows at the
             // source resolution: W % 8 == 0, 8-channel K-blocks: C_{l+1} % 8 == 0, bit 24 of the mask); an operator that cannot is a direct one.
             // EIGEN_WINOGRAD = bit mask of the operators that run in Winograd form (bit l ConvLSTM_l, 8 + l ConvA_l, 16 + l ConvP_l; bit 24: see above; bits 25-27: F(4x4, 3x3)
             // tiles) -- ANOTHER canonical summation order per setting, which the oracle follows through the same variable.  DEFAULT ON for every eligible operator
@@ -883,13 +857,13 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
                 for (int g = 0; g < 4; ++g) { w3[0][g] = wx0[g]; w3[1][g] = wino_fuse ? wx1[g] : wh[g]; w3[2][g] = wino_fuse ? wh[g] : nullptr; }
                 const int sc[3] = {2 * C, wino_fuse ? Cu : C, C}, sw[3] = {2 * C, wino_fuse ? Cu : C, C};
                 const int sc0[2] = {C, Cu}, sw0[2] = {2 * C, Cu};
-                const int wt = ((wino_env >> 25) & 1) ? 4 : 2;   // F(4x4, 3x3) (conv_wino4.h; oracle: eig_wino_tile)
-                std::vector<float> pw = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 3 : 2, sc, sw, w3, wt);
-                std::vector<float> pw0 = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 2 : 1, sc0, sw0, w3, wt);
+                const int wt = 4;   // F(4x4, 3x3) tiles
+                std::vector<float> pw = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 3 : 2, sc, sw, w3);
+                std::vector<float> pw0 = pack_weights_wino(C, 4, op.n_nblk, true, wino_fuse ? 2 : 1, sc0, sw0, w3);
                 if (upload(&op.d_wpk, pw.data(), pw.size()) || upload(&t0.d_wpk, pw0.data(), pw0.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvLSTM%d, Winograd form)", l);
-                op.wino = t0.wino = true; op.TW = t0.TW = 16; op.wino_tile = t0.wino_tile = wt;
+                op.wino = t0.wino = true; op.TW = t0.TW = 16;
                 const double tiles = (double)((y.H + wt - 1) / wt) * ((y.W + wt - 1) / wt);
-                const double pf = wt == 4 ? 36 : 16, pu = wt == 4 ? 25 : 9;
+                const double pf = 36, pu = 25;   // positions of a tile: full-resolution sources, the unpooled one
                 op.macs = tiles * pf * 4 * C * (3.0 * C) + tiles * pu * 4 * C * Cu;   // executed: 16 / 36 (unpooled source: 9 / 25) multiply-adds per channel and tile
                 t0.macs = tiles * pf * 4 * C * (1.0 * C) + tiles * pu * 4 * C * Cu;
                 if (wino_fuse)
@@ -936,10 +910,10 @@ int eigen_set_prednet_weights(eigen_engine* e, const float* const* t, int32_t n_
             if (wino_op(wino_env, 2, l, C, C, y.H, y.W, l == L - 1)) {
                 const int ni = (C % 64) ? 3 : 4, nb = C / (16 * ni);
                 const int sc[1] = {C};
-                const int wt = ((wino_env >> 27) & 1) ? 4 : 2;
-                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, sc, sw, wt);
+                const int wt = 4;
+                std::vector<float> pw = pack_weights_wino(C, ni, nb, false, 1, sc, sc, sw);
                 if (upload(&op.d_wpk, pw.data(), pw.size())) return fail(EIGEN_ERR_HIP, "weight upload failed (ConvP%d, Winograd form)", l);
-                op.wino = true; op.wino_tile = wt; op.TW = 16; op.NI = ni; op.n_nblk = nb;
+                op.wino = true; op.TW = 16; op.NI = ni; op.n_nblk = nb;
                 op.macs = (double)((y.H + wt - 1) / wt) * ((y.W + wt - 1) / wt) * (wt + 2) * (wt + 2) * C * C;
             }
         }

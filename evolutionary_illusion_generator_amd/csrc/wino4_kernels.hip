@@ -7,7 +7,7 @@
 namespace eig {
 
 hipError_t launch_wino4_tall(int NI, int epi, const ConvArgs& a, int grid, hipStream_t st);   // wino4t_kernels.hip
-hipError_t launch_wino4_half(int NI, int epi, const ConvArgs& a, int grid, hipStream_t st);   // wino4t_kernels.hip
+hipError_t launch_wino4_half(int NI, int epi, const ConvArgs& a, int grid, hipStream_t st);   // wino4h_kernels.hip
 
 hipError_t launch_wino4(int NI, int epi, int shape, const ConvArgs& a, int grid, hipStream_t st)
 {

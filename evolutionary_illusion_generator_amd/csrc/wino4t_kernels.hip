@@ -1,5 +1,4 @@
-// wino4t_kernels.hip -- translation unit of the Winograd F(4x4, 3x3) kernels on 32 x 16-pixel (tall) blocks and on 8 x 32-pixel half blocks (conv_wino4.h: TALL, HALF);
-// called through launch_wino4
+// wino4t_kernels.hip -- translation unit of the Winograd F(4x4, 3x3) kernels on 32 x 16-pixel (tall) blocks (conv_wino4.h: TALL); called through launch_wino4
 #include "conv_wino4.h"
 
 #include <unordered_set>
@@ -17,20 +16,6 @@ hipError_t launch_wino4_tall(int NI, int epi, const ConvArgs& a, int grid, hipSt
     if (epi == EPI_LSTM) return NI == 4 ? go(wino4_kernel<4, EPI_LSTM, true>) : hipErrorInvalidConfiguration;
     if (epi == EPI_CONVA) return NI == 4 ? go(wino4_kernel<4, EPI_CONVA, true>) : go(wino4_kernel<3, EPI_CONVA, true>);
     if (epi == EPI_CONVP) return NI == 4 ? go(wino4_kernel<4, EPI_CONVP, true>) : go(wino4_kernel<3, EPI_CONVP, true>);
-    return hipErrorInvalidConfiguration;
-}
-
-hipError_t launch_wino4_half(int NI, int epi, const ConvArgs& a, int grid, hipStream_t st)
-{
-    auto go = [&](auto kern) -> hipError_t {
-        static std::unordered_set<const void*> attr_done;
-        if (attr_done.insert((const void*)kern).second) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, wino4_lds_bytes());
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(W4_THREADS / 2), wino4_lds_bytes(), st, a);
-        return hipGetLastError();
-    };
-    if (epi == EPI_LSTM) return NI == 4 ? go(wino4_kernel<4, EPI_LSTM, false, true>) : hipErrorInvalidConfiguration;
-    if (epi == EPI_CONVA) return NI == 4 ? go(wino4_kernel<4, EPI_CONVA, false, true>) : go(wino4_kernel<3, EPI_CONVA, false, true>);
-    if (epi == EPI_CONVP) return NI == 4 ? go(wino4_kernel<4, EPI_CONVP, false, true>) : go(wino4_kernel<3, EPI_CONVP, false, true>);
     return hipErrorInvalidConfiguration;
 }
 

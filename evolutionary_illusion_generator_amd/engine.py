@@ -254,7 +254,7 @@ class Engine:
         rows = []
         for r in out[:n.value]:
             rows.append(dict(layer=int(r[0]), epi={1: "lstm", 2: "convA", 3: "convP", 4: "lstm", 5: "up4", 6: "up4"}.get(int(r[1]) & 15, "raw"), step0=bool((int(r[1]) >> 4) & 1),
-                             wino=bool(int(r[1]) & 32),  # Winograd form (csrc/conv_wino16.h, conv_wino4.h): flops_per_image counts ITS multiply-adds
+                             wino=bool(int(r[1]) & 32),  # Winograd form (csrc/conv_wino4.h): flops_per_image counts ITS multiply-adds
                              NI=int(r[2]), TW=int(r[3]),
                              launches=int(r[4]), ms=float(r[5]), flops_per_image=float(r[6]), n_nblk=int(r[7])))
         return rows

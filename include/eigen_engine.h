@@ -237,7 +237,7 @@ int eigen_get_timings(eigen_engine* e, double* h_ms6);
 
 /* Per-op profile of the roll-out convolutions.  enable=1 brackets every conv launch with HIP events recorded on the
  * launch stream (and waits for each).  h_out rows (8 doubles each, at most max_ops rows):
- * [layer, epilogue (1 LSTM, 2 ConvA, 3 ConvP, 4 packed LSTM, 5 / 6 the 2x2-form pass over the ConvLSTM's unpooled source (6: all four parity classes in one block); +32 for an operator in its Winograd F(2x2, 3x3) form (csrc/conv_wino.h; FLOPs then count its 16 multiply-adds per channel and 2x2 outputs); +16 for the step-0 operators, which skip the sources
+ * [layer, epilogue (1 LSTM, 2 ConvA, 3 ConvP, 4 packed LSTM, 5 / 6 the 2x2-form pass over the ConvLSTM's unpooled source (6: all four parity classes in one block); +32 for an operator in its Winograd F(4x4, 3x3) form (csrc/conv_wino4.h; FLOPs then count its 36 multiply-adds per channel and 4x4 outputs -- 25 for an unpooled source); +16 for the step-0 operators, which skip the sources
  *  that are identically zero after reset_state()), NI, TW, launches, total_ms, FLOPs per launch per image (2 x the
  *  multiply-accumulates executed), n_nblk].  At most 6 rows per layer.  reset=1 clears the accumulators after reading. */
 int eigen_conv_profile(eigen_engine* e, int32_t enable, int32_t reset, double* h_out, int32_t max_ops, int32_t* n_ops);

@@ -118,13 +118,13 @@ def tensor_names(n_layers):
 
 # EIGEN_WINOGRAD unset: every eligible operator -- bit l ConvLSTM_l, bit 8 + l ConvA_l, bit 16 + l ConvP_l (eig_oracle.c: eig_wino_op; the
 # engine's default is the same mask); bit 24: the unpooled source inside the Winograd ConvLSTM's chains (eig_wino_fuse_up); bits 25 / 26 / 27:
-# ConvLSTM / ConvA / ConvP in F(4x4, 3x3) instead of F(2x2, 3x3) (eig_wino_tile; round 5)
+# the class bits of the ConvLSTMs / ConvAs / ConvPs -- an operator is a Winograd F(4x4, 3x3) one only with its own bit AND its class bit set (eig_wino_op)
 WINO_AUTO = 0x0FFFFFFE
 
 
 def wino_mask_default():
-    """Which ConvLSTM layers run their E_l / h_l chain as Winograd F(2x2, 3x3): the engine's switch EIGEN_WINOGRAD (bit l = layer
-    l), so that checker and library follow the same setting by default."""
+    """Which operators run as Winograd F(4x4, 3x3): the engine's switch EIGEN_WINOGRAD (bits as above), so that checker and library
+    follow the same setting by default."""
     v = os.environ.get("EIGEN_WINOGRAD")
     m = WINO_AUTO if v is None or v == "" else int(v, 0)
     if os.environ.get("EIGEN_WINO_FUSEUP") == "0":   # (the engine reads the same variable)

@@ -152,7 +152,7 @@ typedef struct {
     float* up;   /* chain of the unpooled source scratch */
     float* tmp;  /* ConvA full-resolution scratch */
     int order;   /* 0: the build's canonical arithmetic; 1: the reference's element-wise order (lstm_reference_order) */
-    int wino_mask; /* canonical order only: which operators run as Winograd F(2x2, 3x3) (eig_wino_op) */
+    int wino_mask; /* canonical order only: which operators run as Winograd F(4x4, 3x3) (eig_wino_op) */
 } prednet_t;
 
 /* Tensor table order shared with the Python wrapper (oracle/__init__.py: tensor_table()). */
@@ -303,8 +303,9 @@ static void conv_up2x2_chain(float* acc, const float* src, const float* w, int C
     free(w4);
 }
 
-/* ---- Winograd F(2x2, 3x3) form of a 3x3 'same' convolution, fp32, ONE fixed order of operations (the HIP kernel conv_wino16.h runs
- * exactly these; eligibility and switch: see eig_wino_op).  Per 2x2 output tile T = (ty, tx), input patch d[4][4] =
+/* ---- Winograd F(2x2, 3x3) form of a 3x3 'same' convolution, fp32, ONE fixed order of operations.  Rounds 4-5 shipped a HIP kernel that ran exactly these; round 6
+ * removed it (nothing ran it once F(4x4) was the default) and NO operator of the roll-out below takes this form any more -- it stays reachable through
+ * eig_oracle_wino_chain_m(m = 2) for tests/studies/winograd_study.py and the "same convolution" test.  Per 2x2 output tile T = (ty, tx), input patch d[4][4] =
  * in[c][2ty-1+i][2tx-1+j] (zeros outside the image):
  *   input transform   t_ij = rows:  t0j = d0j - d2j, t1j = d1j + d2j, t2j = d2j - d1j, t3j = d1j - d3j   (B^T d)
  *                     V_ij = cols:  Vi0 = ti0 - ti2, Vi1 = ti1 + ti2, Vi2 = ti2 - ti1, Vi3 = ti1 - ti3   ((B^T d) B)
@@ -483,17 +484,17 @@ static void wino_finish(float* out, const float* M, int Cout, int H, int W, int 
             }
 }
 static size_t wino_m_floats(int Cout, int H, int W, int m) { return (size_t)WINO_NPOS(m) * Cout * wino_th(H, m) * wino_tw(W, m); }
-/* tile size of a Winograd operator of kind 0 ConvLSTM / 1 ConvA / 2 ConvP: bits 25 / 26 / 27 of wino_mask select F(4x4, 3x3) (csrc/conv_wino4.h), else F(2x2, 3x3) */
-static int eig_wino_tile(int wino_mask, int kind) { return ((wino_mask >> (25 + kind)) & 1) ? 4 : 2; }
+#define EIG_WINO_M 4   /* tile size of every Winograd operator of the roll-out: F(4x4, 3x3) (csrc/conv_wino4.h) */
 
 /* Which operators take the Winograd form (the HIP engine applies the same rule, eigen_engine.hip: wino_op).  wino_mask: bit l =
- * ConvLSTM_l, bit 8 + l = ConvA_l, bit 16 + l = ConvP_l.  kind 0 ConvLSTM_l, 1 ConvA_l, 2 ConvP_l; Cin: every full-resolution source
+ * ConvLSTM_l, bit 8 + l = ConvA_l, bit 16 + l = ConvP_l, AND the class bit 25 / 26 / 27 of the ConvLSTMs / ConvAs / ConvPs (rounds 4-5: the class bit chose F(4x4) over
+ * F(2x2); with the F(2x2) kernel gone an operator whose class bit is clear is a direct one).  kind 0 ConvLSTM_l, 1 ConvA_l, 2 ConvP_l; Cin: every full-resolution source
  * has a multiple of 8 channels; Cout (per gate): 16-channel groups, and for the plain convolutions N-blocks of 48 or 64 columns
  * without padding; rows of 16-byte chunks; odd H only for an operator of the TOP layer.  A property of the operator's shape only,
  * never of the batch: results must not depend on how a population is split into device batches. */
 static int eig_wino_op(int wino_mask, int kind, int l, int Cin, int Cout, int H, int W, int top)
 {
-    if (!((wino_mask >> (8 * kind + l)) & 1) || l < 1) return 0;
+    if (!((wino_mask >> (8 * kind + l)) & 1) || !((wino_mask >> (25 + kind)) & 1) || l < 1) return 0;
     if ((Cin % 8) || (Cout % 16) || (W % 4)) return 0;
     if ((H % 2) && !(top && kind != 1)) return 0;
     if (kind != 0 && (Cout % 48) && (Cout % 64)) return 0;
@@ -656,7 +657,7 @@ static void prednet_step(prednet_t* n, const float* x)
         fill_padded(n->pad, n->E[l - 1], Ci, Hi, Wi, 0);
         memset(n->tmp, 0, sizeof(float) * (size_t)Co * Hi * Wi);
         if (eig_wino_op(n->wino_mask, 1, l, n->ch[l - 1], Co, Hi, Wi, 0)) {  /* Winograd form: the 2x2 tile is the pooling window */
-            const int wm = eig_wino_tile(n->wino_mask, 1);
+            const int wm = EIG_WINO_M;
             float* M = (float*)calloc(wino_m_floats(Co, Hi, Wi, wm), sizeof(float));
             wino_accumulate(M, n->pad, n->convA_w[l], Co, Ci, Hi, Wi, wm);
             wino_finish(n->tmp, M, Co, Hi, Wi, wm);
@@ -692,7 +693,7 @@ static void prednet_step(prednet_t* n, const float* x)
         /* one chain over the full-resolution sources E_l, h_l (ConvLSTM.__call__: x_*0, h_*) ... */
         if (eig_wino_lstm(n->wino_mask, l, L, C, H, W, l < L - 1 ? n->ch[l + 1] : 0)) {  /* ... in its Winograd form: (m + 2)^2 chains per m x m tile */
             const int fuse = l < L - 1;   /* (below the top layer the Winograd form exists only with the unpooled source inside the chains: eig_wino_lstm) */
-            const int wm = eig_wino_tile(n->wino_mask, 0);
+            const int wm = EIG_WINO_M;
             const size_t mf = wino_m_floats(C, H, W, wm);
             float* M = (float*)calloc(4 * mf, sizeof(float));   /* the chains of each of the four gates */
             float* V;
@@ -768,7 +769,7 @@ static void prednet_step(prednet_t* n, const float* x)
         fill_padded(n->pad, n->h[l], C, H, W, 0);
         memset(n->gate, 0, sizeof(float) * C * hw);
         if (eig_wino_op(n->wino_mask, 2, l, C, C, H, W, l == L - 1)) {
-            const int wm = eig_wino_tile(n->wino_mask, 2);
+            const int wm = EIG_WINO_M;
             float* M = (float*)calloc(wino_m_floats(C, H, W, wm), sizeof(float));
             wino_accumulate(M, n->pad, n->convP_w[l], C, C, H, W, wm);
             wino_finish(n->gate, M, C, H, W, wm);

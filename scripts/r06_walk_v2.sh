@@ -9,5 +9,5 @@ timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "winograd_
 for p in 1 99; do EIGEN_W4_PARTS=$p timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "winograd_operators_frames_bit_exact and None" > $O/pytest_parts$p.log 2>&1; echo "EIGEN_W4_PARTS=$p: $(tail -1 $O/pytest_parts$p.log)"; done
 ARGS="--steps 4" bash scripts/ab_libs.sh $O/ab libeigen_base.so 2>&1 | tee $O/ab_libs.txt
 REPS=1 bash scripts/ab_env.sh $O/abenv "EIGEN_W4_PARTS=99" "EIGEN_W4_PARTS=1" "" "EIGEN_HIP_LIB=$GRAFT_REPO_ROOT/evolutionary_illusion_generator_amd/libeigen_base.so" 2>&1 | tee $O/ab_env.txt
-EIG_TL_WAVES=12 EIGEN_TIMELINE_ALL=1 EIGEN_TIMELINE=$O/tl python scripts/timeline_w16.py > $O/timeline_walk.txt 2>&1; grep -E "^==|MATRIX|per wave" $O/timeline_walk.txt | cut -c1-260
+EIG_TL_WAVES=12 EIGEN_TIMELINE_ALL=1 EIGEN_TIMELINE=$O/tl python scripts/timeline_wino4.py > $O/timeline_walk.txt 2>&1; grep -E "^==|MATRIX|per wave" $O/timeline_walk.txt | cut -c1-260
 rm -f $O/tl/*.bin

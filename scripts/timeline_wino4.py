@@ -1,7 +1,7 @@
-"""Measurement script (not product): where the time between two K loops of the sixteen-wave Winograd ConvLSTM kernel goes, from an
--DEIG_TIMING=1 build (csrc/conv_wino16.h: timeline).
+"""Measurement script (not product): where the time between two K loops of the Winograd F(4x4) kernel goes, from an
+-DEIG_TIMING=1 build (csrc/conv_wino4.h: timeline; written in round 4 for the sixteen-wave F(2x2) kernel, which round 6 removed -- EIG_TL_WAVES=12 is the F(4x4) block).
     python __graft_entry__.py --lib scripts/_timing/libeigen_timing.so -DEIG_TIMING=1
-    EIGEN_TIMELINE=gpurun_out/tl python scripts/timeline_w16.py [pop]          (--analyze-only: read the .bin files again)
+    EIGEN_TIMELINE=gpurun_out/tl EIG_TL_WAVES=12 EIGEN_TIMELINE_ALL=1 python scripts/timeline_wino4.py [pop]          (--analyze-only: read the .bin files again)
 Every wave of one steady-state launch of each ConvLSTM operator records the cycle counter at entry / set-up done (first DMA about to be
 issued) / K loop start / K loop end / exchange barrier passed / row transform done (gates start) / exit, and HW_ID.  Blocks are then
 ordered per CU: the matrix pipe of a CU is idle from the K-loop end of one block to the K-loop start of the next (ONE block per CU),
@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 
 GHZ = float(os.environ.get("EIG_GFX_GHZ", "2.4"))
-NW = int(os.environ.get("EIG_TL_WAVES", "16"))   # waves per block: 16 = conv_wino16.h, 12 = conv_wino4.h (one record per block and N-block of its walk)
+NW = int(os.environ.get("EIG_TL_WAVES", "12"))   # waves per block of conv_wino4.h (6: half blocks); one record per block and N-block of its walk
 out_dir = os.environ.setdefault("EIGEN_TIMELINE", "gpurun_out/tl")
 os.makedirs(out_dir, exist_ok=True)
 if "--analyze-only" not in sys.argv:

@@ -444,7 +444,7 @@ print("WINO_OK" if ok else "WINO_FAIL")
 """
 
 
-@pytest.mark.parametrize("switch", [None, "parts=1", "tall=1", "half=1", "0x03FFFFFE", "0x0DFEFEFE", "0x01FFFFFE", "0x0E0E00", "0x0100000E"])
+@pytest.mark.parametrize("switch", [None, "parts=1", "tall=1", "half=1", "0x03FFFFFE", "0x0C0E0E00"])
 def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     """The Winograd forms of the 3x3 convolutions against the oracle's statement of exactly that arithmetic (eig_oracle.c: wino_*, wino4_*; the oracle follows the
     same environment switch): all frames of four small roll-outs, bit for bit -- incl. step-0 operators (one source), ragged tiles, a top layer without an unpooled
@@ -454,9 +454,8 @@ def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     maps, which take the tall shape, and a 20 x 15 one, which does not); "parts=1": the same with a block of that kernel walking ALL N-blocks of its tile (EIGEN_W4_PARTS: the
     launch geometry must not show in a single bit; test_specialised_operators... covers 2 / 99 and the forced shapes on other roll-outs); "tall=1": every F(4x4) operator on
     32 x 16-pixel blocks (EIGEN_W4_TALL); "half=1": every F(4x4) operator on 8 x 32-pixel half blocks of six waves (EIGEN_W4_HALF; the shape of launches smaller than one
-    block per compute unit); 0x03FFFFFE: only the ConvLSTMs in F(4x4), ConvA / ConvP in F(2x2); 0x0DFEFEFE: ConvA and ConvP in F(4x4), the
-    ConvLSTMs direct except the top one (bit 24 clear: below the top layer a ConvLSTM is a Winograd operator only with its unpooled source inside the chains) in F(2x2).
-    0x01FFFFFE: everything in F(2x2, 3x3) on the sixteen-wave kernel (csrc/conv_wino16.h; the round-4 default); 0x0E0E00: ConvA and ConvP only; 0x0100000E: the ConvLSTMs with their unpooled source fused, everything else direct."""
+    block per compute unit); 0x03FFFFFE: only the ConvLSTMs in F(4x4), ConvA / ConvP direct (class bits 26 / 27 clear); 0x0C0E0E00: ConvA and ConvP in
+    F(4x4), every ConvLSTM direct.  (The F(2x2, 3x3) sixteen-wave kernel of rounds 4-5 and its masks went in round 6.)"""
     import subprocess
     env = dict(os.environ)
     env.pop("EIGEN_WINOGRAD", None)

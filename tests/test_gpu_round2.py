@@ -402,56 +402,59 @@ def test_bench_gpus_flag_launches_ranks(cuda):
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     small = ["--shape", "c2", "--pop", "8", "--steps", "1", "--warmup", "1", "--no-roofline", "--no-cpu-baseline"]
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    bench = os.path.join(ROOT, "bench.py")
+
+    def torchrun(n):
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), bench, "--gpus", str(n)]
+    env_gloo = dict(env, EIGEN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    # the six launches are independent processes (tiny workloads sharing the one GPU): started three at a time, checked in order
+    jobs = {
+        "one": ([sys.executable, bench, "--gpus", "1"] + small, env),
+        # the multi-rank reporting path (RCCL group, per-rank device times out of the all-gather, leaving the group before rank 0's
+        # untimed legs) in a group of ONE rank: what a single-GPU box can run of `--gpus N`
+        "single_rank_group": ([sys.executable, bench, "--gpus", "1"] + small[:-2] + ["--no-cpu-baseline"], dict(env, EIGEN_DIST_SINGLE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")),
+        # TWO ranks for real (sharding, broadcast, all-gather with per-rank times, rank 1 leaving while rank 0 profiles) -- on a 1-GPU
+        # box they share the device and gloo carries the collectives (RCCL refuses two ranks on one device): control flow, not a number
+        "two_ranks": (torchrun(2) + small[:-2] + ["--no-cpu-baseline"], env_gloo),
+        # EIGHT ranks at the HEADLINE shape: pop 256 -> 32 genomes per rank, engines at max_batch 32, the broadcast of
+        # the 256-genome wire arrays, the all-gather, all ranks leaving the group together -- what the driver's `--gpus 8` run does,
+        # executed once on a GPU box (the eight ranks share its one device over gloo: control flow, not a measurement)
+        "eight_ranks": (torchrun(8) + ["--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-parity", "--no-supplementary"], env_gloo),
+        "two_without_launcher": ([sys.executable, bench, "--gpus", "2"] + small, env),
+        # joined under a launcher with the wrong world size: refuse
+        "wrong_world_size": ([sys.executable, bench, "--gpus", "2"] + small, dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")),
+    }
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=3) as pool:
+        res = dict(zip(jobs, pool.map(lambda j: subprocess.run(j[0], env=j[1], capture_output=True, text=True, timeout=900), jobs.values())))
+
+    def json_line(r):
+        assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, "exactly ONE JSON line (rank 0's)"
+        return json.loads(lines[0])
+    line = json_line(res["one"])
     assert line["n_gpus"] == 1 and line["config"]["global_pop"] == 8 and line["scaling"] == "strong" and line["value"] > 0
-    # the multi-rank reporting path (RCCL group, per-rank device times out of the all-gather, leaving the group before rank 0's
-    # untimed legs) in a group of ONE rank: what a single-GPU box can run of `--gpus N`
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small[:-2] + ["--no-cpu-baseline"],
-                       env=dict(env, EIGEN_DIST_SINGLE="1", HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    line = json_line(res["single_rank_group"])
     assert "RCCL" in line["config"]["parallelism"] and len(line["multi_gpu"]["per_rank_device_ms"]) == 1 and line["multi_gpu"]["device_ms_max"] > 0
     assert line["multi_gpu"]["ranks_seen"] == [0] and line["multi_gpu"]["backend"] == "nccl" and line["multi_gpu"]["rccl_version"]
     assert line["multi_gpu"]["hsa_ipc_mode_legacy"] == "0"
     assert line["roofline"]["all_conv_kernels"]["launches"] > 0   # rank 0's roofline pass ran after the group was left
-    # TWO ranks for real (sharding, broadcast, all-gather with per-rank times, rank 1 leaving while rank 0 profiles) -- on a 1-GPU
-    # box they share the device and gloo carries the collectives (RCCL refuses two ranks on one device): control flow, not a number
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small[:-2] + ["--no-cpu-baseline"],
-                       env=dict(env, EIGEN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, "exactly ONE JSON line (rank 0's)"
-    line = json.loads(lines[0])
+    line = json_line(res["two_ranks"])
     assert line["n_gpus"] == 2 and line["config"]["genomes_per_gpu"] == 4 and len(line["multi_gpu"]["per_rank_device_ms"]) == 2
     assert min(line["multi_gpu"]["per_rank_device_ms"]) > 0 and line["roofline"]["all_conv_kernels"]["launches"] > 0 and line["nonzero_fitness"] >= 0
     assert line["multi_gpu"]["ranks_seen"] == [0, 1] and line["multi_gpu"]["world_size"] == 2 and line["multi_gpu"]["backend"] == "gloo"
-    # EIGHT ranks at the HEADLINE shape: pop 256 -> 32 genomes per rank, engines at max_batch 32, the broadcast of
-    # the 256-genome wire arrays, the all-gather, all ranks leaving the group together -- what the driver's `--gpus 8` run does,
-    # executed once on a GPU box (the eight ranks share its one device over gloo: control flow, not a measurement)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "1",
-                        "--no-cpu-baseline", "--no-parity", "--no-supplementary"],
-                       env=dict(env, EIGEN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4"), capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    line = json.loads(lines[0])
+    line = json_line(res["eight_ranks"])
     assert line["n_gpus"] == 8 and line["config"]["global_pop"] == 256 and line["config"]["genomes_per_gpu"] == 32 and line["config"]["device_batch"] == 32
     assert line["multi_gpu"]["ranks_seen"] == list(range(8)) and len(line["multi_gpu"]["per_rank_device_ms"]) == 8
     assert line["scaling"] == "strong" and line["nonzero_fitness"] >= 100 and line["roofline"]["all_conv_kernels"]["launches"] > 0
     n = 2
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)] + small, env=env, capture_output=True, text=True, timeout=900)
+    r = res["two_without_launcher"]
     if torch.cuda.device_count() >= n:
-        assert r.returncode == 0, r.stderr[-2000:]
-        line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+        line = json_line(r)
         assert line["n_gpus"] == n and line["config"]["genomes_per_gpu"] == 4 and "RCCL" in line["config"]["parallelism"]
         assert len(line["multi_gpu"]["per_rank_device_ms"]) == n
     else:
         assert r.returncode != 0 and "GPU(s) visible" in (r.stderr + r.stdout)
-    # joined under a launcher with the wrong world size: refuse
-    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, env=env2, capture_output=True, text=True, timeout=900)
+    r = res["wrong_world_size"]
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
