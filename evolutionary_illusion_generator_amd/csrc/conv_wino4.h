@@ -104,23 +104,32 @@ template <typename V4> __device__ __forceinline__ void w4_out1d(const V4& m0, co
 // HALF (round 6): a block of ONE region -- 8 rows x 32 columns, six waves (wave = row xi of the position grid), everything else as the wide shape with rg = 0.  For launches
 // of less than one block per CU (configs[0]: 10 to 40 blocks): their time is ONE block's time, and a six-wave block has the CU's matrix pipe to itself for half the
 // multiply-adds.  A choice by launch size (eigen_engine.hip), like the walk; the chains do not depend on it.
-template <int NI, int EPI, bool TALL = false, bool HALF = false>
+//
+// PACK (round 6; a half block): the block's sixteen MFMA rows are sixteen CONSECUTIVE tiles of the launch's linear tile list (image-major, then tile row, then tile
+// column) instead of a 2 x 8 rectangle of one image -- for maps of 16 or 20 columns and 13 to 16 rows (4 x 4 or 5 x 4 tiles: the 20 x 15 top layer of the reference's
+// own 160 x 120), which fill half / 62 % of a wide block.  A region then spans at most two images: the plane of a channel is [2 images][18 rows][7 chunks] (252 chunks
+// = four DMA parts, sixteen (channel, part) instructions per K-block over the six waves: three for waves 0-3, two for 4 and 5) in the tall shape's LDS map; the
+// A-operand base, the exchange slot and the output address of a lane come from its tile's (image, ty, tx).  Operators without an unpooled source, ConvLSTM / ConvP.
+template <int NI, int EPI, bool TALL = false, bool HALF = false, bool PACK = false>
 __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 {
     static_assert(!(TALL && HALF), "half blocks exist in the wide shape only");
+    static_assert(!PACK || (HALF && EPI != EPI_CONVA), "packed tiles: a half block, ConvLSTM / ConvP");
+    constexpr bool TGEO = TALL || PACK;              // plane rows of 28 floats, 16 KB plane slots, the tall LDS map
     static_assert(EPI == EPI_LSTM || EPI == EPI_CONVA || EPI == EPI_CONVP, "conv_wino4.h: ConvLSTM, ConvA, ConvP");
     static_assert(EPI != EPI_LSTM || NI == 4, "ConvLSTM: the four N-tiles are the four gates");
     static_assert(NI == 3 || NI == 4, "N-blocks of 48 or 64 columns");
     constexpr int U4 = wino4_u_floats(NI);
-    constexpr int KC = W4_KC, PS = w4_ps(TALL), W4_ROW = w4_row(TALL);
-    constexpr int W4_P0 = w4_p(TALL, 0), W4_P1 = w4_p(TALL, 1), W4_P2 = w4_p(TALL, 2), W4_U0 = w4_u(TALL, 0), W4_U1 = w4_u(TALL, 1), W4_U2 = w4_u(TALL, 2);
+    constexpr int KC = W4_KC, PS = w4_ps(TGEO), W4_ROW = w4_row(TGEO);
+    constexpr int W4_P0 = w4_p(TGEO, 0), W4_P1 = w4_p(TGEO, 1), W4_P2 = w4_p(TGEO, 2), W4_U0 = w4_u(TGEO, 0), W4_U1 = w4_u(TGEO, 1), W4_U2 = w4_u(TGEO, 2);
+    constexpr int PK_ROWS = 18, PK_CX = 7, PK_IMG = PK_ROWS * PK_CX;   // PACK: chunks of one image's plane
     constexpr bool WALK = !TALL && !HALF;                     // (tall blocks: one N-block per block -- with 16 KB plane slots the prefetched part of a next N-block does not fit beside the exchange area)
     constexpr int RGH = TALL ? 16 : 8;               // rows of a region
     extern __shared__ __attribute__((aligned(16))) float lds[];
     unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py with EIG_TL_WAVES=12)
     float* const Pb = lds;                          // (slot offsets W4_P0 / W4_P1 / W4_P2, W4_U0 / W4_U1 / W4_U2 are absolute)
     float* const Ub = lds;
-    float* const xb = lds + w4_x(TALL);
+    float* const xb = lds + w4_x(TGEO);
     const int wv_o = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     const int rg_o = HALF ? 0 : wv_o & 1, xi_o = HALF ? wv_o : wv_o >> 1;
     constexpr int NWAVES = HALF ? W4_WAVES / 2 : W4_WAVES;
@@ -130,8 +139,8 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     // spilled 42 registers that way, the first version of this one 9.
     auto lane_id = [&]() __attribute__((always_inline)) { int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(l)); return l; };
 
-    const int tiles = a.tilesX * a.tilesY;
-    const int ntile = a.B * tiles;
+    const int tiles = a.tilesX * a.tilesY;            // (PACK: the tiles of ONE image, tilesX x tilesY of 4 x 4 pixels)
+    const int ntile = PACK ? (a.B * tiles + 15) >> 4 : a.B * tiles;
     const int xcd = blockIdx.x & 7, xi_ = blockIdx.x >> 3;
     // (divisions by launch constants through their host-side reciprocals, ConvArgs::mg: a run-time integer division is ~25 dependent scalar instructions:
     // profiles/r05_f_w4_timeline.txt)
@@ -143,13 +152,14 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + q0 : q0 * 8 + xcd;
     if (tlin >= ntile) return;
     const int nwalk = WALK ? a.nwalk : 1, nb0 = part * nwalk;   // this block computes N-blocks nb0 .. nb0 + nwalk - 1 of its tile
-    const int eb = dv(tlin, tiles, a.mg[1]);
-    const int t_ = tlin - eb * tiles;
+    const int eb = dv(PACK ? tlin * 16 : tlin, tiles, a.mg[1]);   // (PACK: the image of the block's first tile, t_ = that tile's index in it)
+    const int t_ = (PACK ? tlin * 16 : tlin) - eb * tiles;
     const int tyi = dv(t_, a.tilesX, a.mg[2]), txi = t_ - tyi * a.tilesX;
-    const int y0 = tyi * (TALL ? 32 : (HALF ? 8 : 16)), x0 = txi * (TALL ? 16 : 32);
+    const int y0 = PACK ? 0 : tyi * (TALL ? 32 : (HALF ? 8 : 16)), x0 = PACK ? 0 : txi * (TALL ? 16 : 32);
+    const int o0_o = t_;
     const int HW = a.H * a.W;
 
-    const bool up_fused = EPI == EPI_LSTM && a.up_src != nullptr;
+    const bool up_fused = !PACK && EPI == EPI_LSTM && a.up_src != nullptr;
     const int nkb0 = a.src[0].C / KC;
     const int nkbu = up_fused ? (a.up_C / KC) : 0;
     const bool has1 = a.nsrc > 1;
@@ -177,10 +187,12 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     asm volatile("" : "+s"(zs));
     const int wv = wv_o + zs, rg = rg_o + zs, xi = xi_o + zs, nkb = nkb_o + zs, up_lo = up_lo_o + zs, up_hi = up_hi_o + zs;
     const int pch = HALF ? wv >> 1 : wv / 3, ppart = HALF ? wv & 1 : wv - pch * 3;   // this wave's plane DMA: channel, part of 64 chunks
-    const int eb_i = eb + zs, y0_i = y0 + zs, x0_i = x0 + zs;
+    const int eb_i = eb + zs, y0_i = y0 + zs, x0_i = x0 + zs, o0 = o0_o + zs;
     const unsigned long long sb0 = (unsigned long long)(a.src[0].ptr + (size_t)eb_i * a.src[0].Ct * HW);
     const unsigned long long sb1 = has1 ? (unsigned long long)(a.src[1].ptr + (size_t)eb_i * a.src[1].Ct * HW) : sb0;
-    const int sz0 = a.src[0].C * HW * 4, sz1 = has1 ? a.src[1].C * HW * 4 : sz0;
+    // (PACK: the descriptor's range takes in the block's second image -- lanes whose image does not exist carry the out-of-range offset)
+    const int ist0 = a.src[0].Ct * HW * 4, ist1 = has1 ? a.src[1].Ct * HW * 4 : ist0;   // bytes from an image to the next
+    const int sz0 = a.src[0].C * HW * 4 + (PACK ? ist0 : 0), sz1 = has1 ? a.src[1].C * HW * 4 + (PACK ? ist1 : 0) : sz0;
     const int Hh = a.H >> 1, Wh = a.W >> 1, HWh = Hh * Wh;
     const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb_i * a.up_C * HWh) : sb0;
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
@@ -197,10 +209,26 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
         const int hy = (y0_i >> 1) - 1 + row, hx = (x0_i >> 1) - 4 + 4 * cx;
         uo = (row < UROWS && cx < UCHK && hy >= 0 && hy < Hh && hx >= 0 && hx < Wh) ? (hy * Wh + hx) * 4 : -1;
     };
+    // PACK: wave wv issues the (channel, part) pairs idx = wv + 6 k < 16 (k = 0, 1, 2): channel idx >> 2, part idx & 3; chunk c = lane + 64 part of [2][18][7]
+    int pk_ro[3] = {-1, -1, -1};
+    unsigned pk_sel[3] = {0u, 0u, 0u};   // all ones: the chunk belongs to the block's second image
+    const int pk_n = wv_o < 4 ? 3 : 2;   // (wave-uniform)
+    if constexpr (PACK) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int c = lane + 64 * ((wv_o + 6 * k) & 3);
+            const int i = c >= PK_IMG ? 1 : 0, c1 = c - PK_IMG * i;
+            const int row = c1 / PK_CX, cx = c1 - row * PK_CX;
+            const int gy = row - 1, gx = 4 * cx - 4;
+            const bool ok = c < 2 * PK_IMG && eb_i + i < a.B && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            pk_ro[k] = ok ? (gy * a.W + gx) * 4 : -1;
+            pk_sel[k] = (ok && i) ? ~0u : 0u;
+        }
+    }
     int roff, uoff, roff2 = -1, uoff2 = -1;
     plane_offsets(ppart, roff, uoff);
     // second plane instruction of some waves: tall -- part 3 of channel wv (waves 0-3); half -- channel 3, part wv & 1 (waves 0, 1: eight parts over six waves)
-    const bool two_parts = (TALL && wv_o < 4) || (HALF && wv_o < 2);   // (wave-uniform)
+    const bool two_parts = (TALL && wv_o < 4) || (HALF && !PACK && wv_o < 2);   // (wave-uniform)
     if (TALL) plane_offsets(3, roff2, uoff2);
     if (HALF) { roff2 = roff; uoff2 = uoff; }
     const int ch2 = HALF ? 3 : wv, part2 = HALF ? ppart : 3;
@@ -215,6 +243,18 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
         const int sz = sz0 + ((sz1 - sz0) & (int)m1) + ((szu - sz0) & (int)mu);
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(sz), 0x00020000);
         const int base = (up_lo & (int)mu) + (up_hi & (int)m1), hw = HW + ((HWh - HW) & (int)mu);
+        if constexpr (PACK) {
+            const unsigned ist = (unsigned)(ist0 + ((ist1 - ist0) & (int)m1));
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (k >= pk_n) break;
+                const int idx = wv_o + 6 * k;
+                const unsigned coffk = (unsigned)((j - base) * KC + (idx >> 2)) * (unsigned)(hw * 4);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + (idx >> 2) * PS + (idx & 3) * 256), 16,
+                                                         (int)__builtin_elementwise_add_sat((unsigned)pk_ro[k] + (pk_sel[k] & ist), coffk), 0, 0, 0);
+            }
+            return;
+        }
         const unsigned coff = (unsigned)((j - base) * KC + pch) * (unsigned)(hw * 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + pch * PS + ppart * 256), 16,
                                                  (int)__builtin_elementwise_add_sat((unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (unsigned)mu), coff), 0, 0, 0);
@@ -225,7 +265,10 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
         }
     };
     // "the U fetch of this K-block has landed, its plane fetch (one instruction, two for waves 0-3 of a tall block) may stay in flight"
-    auto wait_u = [&]() __attribute__((always_inline)) { if (two_parts) EIG4_WAITCNT(0x0F72); else EIG4_WAITCNT(0x0F71); };
+    auto wait_u = [&]() __attribute__((always_inline)) {
+        if constexpr (PACK) { if (pk_n == 3) EIG4_WAITCNT(0x0F73); else EIG4_WAITCNT(0x0F72); }
+        else { if (two_parts) EIG4_WAITCNT(0x0F72); else EIG4_WAITCNT(0x0F71); }
+    };
     // ---- U fetch (every wave: positions 3 wv .. 3 wv + 2 of the next K-block in line): one position of a packed 4-channel K-block = one contiguous KB (NI = 3: 768 B).
     // The scalar offset runs along the packed K-blocks (no index arithmetic in the K loop; the last two fetches read the next N-block's first K-blocks or the
     // buffer's padding into slots nobody reads).
@@ -252,8 +295,12 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
 
     // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) of region rg (rows RGH rg .. of the block): wide (col >> 3, col & 7), MFMA row r = 8 ty + tx;
     // tall (col >> 2, col & 3), r = 4 ty + tx
-    const int t_ty = TALL ? col >> 2 : col >> 3, t_tx = TALL ? col & 3 : col & 7;
-    const float* const pbase_n = Pb + q * PS + (RGH * rg + 4 * t_ty) * W4_ROW + 4 * t_tx;        // patch row 0, the aligned chunk that holds patch column 0 in its last float: columns 0 .. 5 = floats 3 .. 8
+    // PACK: MFMA row col = tile o0 + col of the linear list: image i (0 / 1 of the block's two), tile (ty, tx) of it
+    const int pk_i = (PACK && o0 + col >= tiles) ? 1 : 0, pk_t = o0 + col - (pk_i ? tiles : 0);
+    const int pk_ty = PACK ? dv(pk_t, a.tilesX, a.mg[2]) : 0, pk_tx = pk_t - pk_ty * a.tilesX;
+    const int t_ty = PACK ? 0 : (TALL ? col >> 2 : col >> 3), t_tx = PACK ? pk_tx : (TALL ? col & 3 : col & 7);
+    const int pk_row = PACK ? PK_ROWS * pk_i + 4 * pk_ty : 0;   // (first plane row of the tile's patch in [2][18] rows)
+    const float* const pbase_n = Pb + q * PS + (RGH * rg + 4 * t_ty + pk_row) * W4_ROW + 4 * t_tx;        // patch row 0, the aligned chunk that holds patch column 0 in its last float: columns 0 .. 5 = floats 3 .. 8
     const float* const pbase_u = Pb + q * PS + ((RGH / 2) * rg + 2 * t_ty) * W4_ROW + 2 * t_tx + 3;    // source row s, column s of an unpooled patch (half-resolution plane)
     const int b_off = xi * 6 * W4_UPOS + (q * 16 + col) * NI;   // U[pos = 6 xi + nu][ch = q][col][0 .. NI)
 
@@ -312,7 +359,7 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
         // fetch cursor of the planes (K-block pj = kb + 3, clamped to the last one): the descriptor of its source as scalars (a mutable descriptor OBJECT ends in
         // scratch memory), the byte offset of this wave's channel, the slot
         int pj = 0, psz = 0, pbound = 0;
-        unsigned pcoff = 0, plo = 0, phi = 0, phw4 = 0;
+        unsigned pcoff = 0, plo = 0, phi = 0, phw4 = 0, pist = 0;
         bool pup = false;
         auto plane_source = [&](int j) __attribute__((always_inline)) {   // (re)position the cursor on K-block j: at the start and where a source begins
             const bool up = EIG4_IS_UP(j);
@@ -323,15 +370,26 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
             psz = __builtin_amdgcn_readfirstlane(sz0 + ((sz1 - sz0) & (int)m1) + ((szu - sz0) & (int)mu));
             const int base = (up_lo & (int)mu) + (up_hi & (int)m1);
             phw4 = (unsigned)((HW + ((HWh - HW) & (int)mu)) * 4);
-            pcoff = (unsigned)((j - base) * KC + pch) * phw4;
+            pcoff = (unsigned)((j - base) * KC + (PACK ? 0 : pch)) * phw4;
+            if constexpr (PACK) pist = (unsigned)(ist0 + ((ist1 - ist0) & (int)m1));
             pup = up; pj = j;
             pbound = j < up_lo ? up_lo : (j < up_hi ? up_hi : nkb);   // where the next source begins (or the K-blocks end)
         };
         auto dma_plane = [&]() __attribute__((always_inline)) {   // this wave's plane DMA of K-block pj -> the slot at po0, then advance the cursor
             const unsigned o = (unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (0u - (unsigned)pup));
             const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)phi << 32) | plo), 0, psz, 0x00020000);
+            if constexpr (PACK) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (k >= pk_n) break;
+                    const int idx = wv + 6 * k;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + (idx >> 2) * PS + (idx & 3) * 256), 16,
+                                                             (int)__builtin_elementwise_add_sat((unsigned)pk_ro[k] + (pk_sel[k] & pist), pcoff + (unsigned)(idx >> 2) * phw4), 0, 0, 0);
+                }
+            } else {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + pch * PS + ppart * 256), 16,
                                                      (int)__builtin_elementwise_add_sat(o, pcoff), 0, 0, 0);
+            }
             if (two_parts) {
                 const unsigned o2 = (unsigned)roff2 + (((unsigned)uoff2 - (unsigned)roff2) & (0u - (unsigned)pup));
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + ch2 * PS + part2 * 256), 16,
@@ -512,7 +570,7 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     {   // (own scope: per-lane quantities from a FRESH lane_id(), scalars from coordinates offset by a fresh opaque zero: see the top of the kernel / of the walk)
     int zf = 0;
     asm volatile("" : "+s"(zf));
-    const int eb = eb_i + zf, y0 = y0_i + zf, x0 = x0_i + zf, wv = wv_o + zf, rg = rg_o + zf, xi = xi_o + zf, HWf = HW + zf, Cout = a.Cout + zf;
+    const int eb = eb_i + zf, y0 = y0_i + zf, x0 = x0_i + zf, wv = wv_o + zf, rg = rg_o + zf, xi = xi_o + zf, HWf = HW + zf, Cout = a.Cout + zf, o0f = o0_o + zf;
     const int lane = lane_id();
     const int q = lane >> 4, col = lane & 15;
     const size_t cHW = (size_t)HWf;
@@ -520,7 +578,12 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     const int j = TALL ? lane & 3 : lane & 7, chl = TALL ? lane >> 2 : lane >> 3, e_r = j & 3, ql = TALL ? 0 : j >> 2;
     int woff[4];                                                           // publishing lane (q, col): its slot in plane e
 #pragma unroll
-    for (int e = 0; e < 4; ++e) woff[e] = (((2 * xi + rg) * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + (TALL ? 0 : 8 * (q & 1))) & 15)) * 4;
+    for (int e = 0; e < 4; ++e) woff[e] = (((2 * xi + rg) * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + (PACK ? q : (TALL ? 0 : 8 * (q & 1)))) & 15)) * 4;
+    // PACK: finishing lane L takes tile r = L & 15 of the block (writer lane group r >> 2, register r & 3) for channel 4 cq + (L >> 4); a unit = one channel quarter cq;
+    // the writer's slot q 16 + ((col + 4 e + q) & 15) spreads the sixteen tiles of a reader group over all sixteen slots.  The tile's image / row / column as in the K loop.
+    const int fr = lane & 15, fchl = lane >> 4;
+    const int f_i = (PACK && o0f + fr >= tiles) ? 1 : 0, f_t = o0f + fr - (f_i ? tiles : 0);
+    const int f_ty = PACK ? dv(f_t, a.tilesX, a.mg[2]) : 0, f_tx = f_t - f_ty * a.tilesX;
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
         // All twelve waves finish outputs, and they finish them in IMAGE order: the exchange is laid out so that a finishing lane reads the four pixels b = 0..3 of ONE tile
         // as a 16-byte vector, and finishing lane L takes the 16-byte chunk j = L & 7 of a 32-pixel block row (tile tx = j, writer lane q = 2 ty + (j >> 2), register e =
@@ -535,6 +598,10 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
         for (int un = 0; un < 3; ++un) {   // (tall: MFMA row r = 4 ty + tx -- the writer lane group q IS the tile row, a unit = one of the four tile rows for all 16 channels)
             const int ty = TALL ? (xi < 4 ? un : 3) : (xi < 4 ? (un >> 1) : 1), chh = TALL ? 0 : (xi < 4 ? (un & 1) : 1);
             xoff[un] = TALL ? (e_r * 64 + ty * 16 + ((chl + 4 * e_r) & 15)) * 4 : (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
+            if constexpr (PACK) {
+                const int cq = xi < 4 ? un : 3;
+                xoff[un] = ((fr & 3) * 64 + (fr >> 2) * 16 + ((4 * cq + fchl + 4 * (fr & 3) + (fr >> 2)) & 15)) * 4;
+            }
         }
         auto finish = [&](int arow, int nr, int off) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3
             auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + ((x * 2 + rg) * 2 + nr) * 1024 + off); };
@@ -592,14 +659,17 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
             if (un >= nun) break;
             const int ty = TALL ? (xi < 4 ? un : 3) : (xi < 4 ? (un >> 1) : 1), chh = TALL ? 0 : (xi < 4 ? (un & 1) : 1);
             const int arow = xi < 4 ? xi : 2 * (xi - 4) + un;
-            const int gy = y0 + RGH * rg + 4 * ty + arow, gx = x0 + 4 * j;
+            const int gy = PACK ? 4 * f_ty + arow : y0 + RGH * rg + 4 * ty + arow, gx = PACK ? 4 * f_tx : x0 + 4 * j;
             if (gy >= a.H || gx >= a.W) continue;
+            const int ebo = PACK ? eb + f_i : eb;   // (PACK: the tile's image)
+            if (PACK && ebo >= a.B) continue;       // (past the last tile of the launch)
             const size_t pix = (size_t)gy * a.W + gx;
+            const int chq = PACK ? 4 * (xi < 4 ? un : 3) + fchl : 8 * chh + chl;
             if constexpr (EPI == EPI_LSTM) {
-                const int ch = nblk * 16 + 8 * chh + chl;
+                const int ch = nblk * 16 + chq;
                 if (ch >= Cout) continue;
                 const float bi = a.bias[ch], bf = a.bias[Cout + ch], bc = a.bias[2 * Cout + ch], bo = a.bias[3 * Cout + ch];
-                const size_t cbase = ((size_t)eb * Cout + ch) * cHW, ps = (size_t)Cout * cHW, pbase = (size_t)ch * cHW;
+                const size_t cbase = ((size_t)ebo * Cout + ch) * cHW, ps = (size_t)Cout * cHW, pbase = (size_t)ch * cHW;
                 const f32x4 cold4 = *reinterpret_cast<const f32x4*>(a.c_state + cbase + pix);
                 const f32x4 pi4 = *reinterpret_cast<const f32x4*>(a.peep + pbase + pix);
                 const f32x4 pf4 = *reinterpret_cast<const f32x4*>(a.peep + ps + pbase + pix);
@@ -616,13 +686,13 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
             } else {
 #pragma unroll
                 for (int ni = 0; ni < NI; ++ni) {
-                    const int ch = (nblk * NI + ni) * 16 + 8 * chh + chl;
+                    const int ch = (nblk * NI + ni) * 16 + chq;
                     if (ch >= Cout) continue;
                     const float bb_ = a.bias[ch];
                     f32x4 v4;
 #pragma unroll
                     for (int b = 0; b < 4; ++b) v4[b] = relu_f(ys[ni][un][b] + bb_);
-                    *reinterpret_cast<f32x4*>(a.Pout + ((size_t)eb * Cout + ch) * cHW + pix) = v4;
+                    *reinterpret_cast<f32x4*>(a.Pout + ((size_t)ebo * Cout + ch) * cHW + pix) = v4;
                 }
             }
         }

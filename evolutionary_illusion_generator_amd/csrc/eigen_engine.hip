@@ -436,7 +436,7 @@ template <int NI, int TW, int EPI, bool VEC, bool ONEKB = false, int SPLIT = 0> 
 // eight-wave / half-block / strip instantiations in round 6: with the Winograd forms as the default nothing at any BASELINE shape ran them)
 template <int NI, int TW, int EPI> static hipError_t launch_inst(const ConvArgs& a, int grid, hipStream_t st, bool vec, int w8 = 0)
 {
-    if constexpr (EPI == EPI_CONVA && TW == 16) {   // (16-wide tiles only: the image layer's ConvA never runs on 8 x 8 tiles at a reference shape)
+    if constexpr (EPI == EPI_CONVA && TW == 16 && NI < 4) {   // (16-wide tiles only: the image layer's ConvA never runs on 8 x 8 tiles at a reference shape; a 64-column ConvA is a Winograd operator)
         if (w8 && vec) return launch_inst2<NI, TW, EPI, true, false, 1>(a, grid, st);
     }
     return vec ? launch_inst2<NI, TW, EPI, true>(a, grid, st) : launch_inst2<NI, TW, EPI, false>(a, grid, st);
@@ -491,7 +491,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
     // Eight-wave instantiation of the direct ConvA (conv_mfma.h: W8): launches of at most four rounds of the device's block slots gain 4-5 % from twice as many waves out
     // of the same few blocks (profiles/r03_b_ab_w8.txt); EIGEN_W8 = 0 / 1 forces it off / on (A/B measurements and the parity tests).
     static const int w8_env = getenv("EIGEN_W8") ? atoi(getenv("EIGEN_W8")) : -1;
-    const int w8 = (vec && op.epi == EPI_CONVA && (w8_env >= 0 ? w8_env != 0 : grid <= 8 * e->n_cu)) ? 1 : 0;
+    const int w8 = (vec && op.epi == EPI_CONVA && op.TW == 16 && op.NI < 4 && (w8_env >= 0 ? w8_env != 0 : grid <= 8 * e->n_cu)) ? 1 : 0;
     op.last_grid = grid; op.last_waves = (w8 == 1) ? 8 : 4;
     if (e->profile_convs) (void)hipEventRecord(e->pev0, st);
     hipError_t r;
@@ -508,7 +508,21 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         static const int half_env = getenv("EIGEN_W4_HALF") ? atoi(getenv("EIGEN_W4_HALF")) : -1;
         const bool half = !tall && (half_env >= 0 ? half_env != 0 : (long long)op.n_nblk * batch * a.tilesX * ((op.H + 7) / 8) <= e->n_cu);
         if (half) a.tilesY = (op.H + 7) / 8;
-        const int ntile4 = batch * a.tilesX * a.tilesY;
+        // Packed tiles (conv_wino4.h: PACK, half blocks of sixteen consecutive tiles of the launch's linear tile list): maps of 4 x 4 or 5 x 4 tiles -- the 20 x 15 top layer of
+        // the reference's 160 x 120 fills 62 % of a wide block -- for ConvLSTMs without an unpooled source and ConvPs.  Taken when its rounds of half blocks (a half block
+        // takes about two thirds of a full one's time) cost less than the rounds of full blocks: ref160's ConvLSTM_3, 600 blocks = 3 rounds -> 756 half blocks = 3 rounds
+        // of two thirds; configs[1]'s, 200 blocks -> 252 half blocks, one round each.  A choice by map and launch size; the chains do not depend on it.  EIGEN_W4_PACK = 0 / 1
+        // forbids / forces it for every operator it can run.
+        static const int pack_env = getenv("EIGEN_W4_PACK") ? atoi(getenv("EIGEN_W4_PACK")) : -1;
+        const int ptx = (op.W + 3) / 4, pty = (op.H + 3) / 4;
+        const bool pack_can = op.epi != EPI_CONVA && a.up_src == nullptr && (ptx == 4 || ptx == 5) && pty == 4 && tall_env < 0 && half_env < 0;
+        bool pack = false;
+        if (pack_can) {
+            const long long nhalf = (long long)op.n_nblk * (((long long)batch * ptx * pty + 15) / 16), nfull = (long long)op.n_nblk * batch;
+            pack = pack_env >= 0 ? pack_env != 0 : 2 * ((nhalf + e->n_cu - 1) / e->n_cu) < 3 * ((nfull + e->n_cu - 1) / e->n_cu);
+        }
+        if (pack) { a.tilesX = ptx; a.tilesY = pty; }
+        const int ntile4 = pack ? (batch * ptx * pty + 15) / 16 : batch * a.tilesX * a.tilesY;
         // WALK (conv_wino4.h): nparts blocks per tile, each computing nwalk = n_nblk / nparts consecutive N-blocks of it: walks of three N-blocks where n_nblk allows, of
         // two otherwise (the blocks of a tile share its planes through the XCD's L2), no walk while the launch would not give every CU four blocks.  A property of the
         // launch only -- the bits do not depend on it.  EIGEN_W4_PARTS = n forces min(n, n_nblk) rounded down to a divisor (n >= n_nblk: one N-block per block), for A/B
@@ -521,14 +535,14 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             if ((long long)(op.n_nblk / nwalk) * ntile4 < 4ll * e->n_cu) nwalk = 1;
             nparts = op.n_nblk / nwalk;
         }
-        if (tall || half) nparts = op.n_nblk;   // (tall and half blocks do not walk)
+        if (tall || half || pack) nparts = op.n_nblk;   // (tall and half blocks do not walk)
         a.nparts = nparts; a.nwalk = op.n_nblk / nparts;
         const int g4 = nparts * ((ntile4 + 7) / 8) * 8;
         {   // q = umulhi(x, ceil(2^32 / d)) = x / d for every x with x * d < 2^32 (x < number of blocks here)
-            auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };
+            auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * 16 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };   // (x 16: a packed block divides its first TILE's index)
             a.mg[0] = magic(nparts); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
         }
-        op.last_grid = g4 * a.nwalk; op.last_waves = half ? W4_WAVES / 2 : W4_WAVES;   // (timeline records: one per block and N-block of its walk)
+        op.last_grid = g4 * a.nwalk; op.last_waves = (half || pack) ? W4_WAVES / 2 : W4_WAVES;   // (timeline records: one per block and N-block of its walk)
 #if EIG_TIMING
         if (tl_dbg) {   // sized from THIS launch's records (the buffer above was sized for the four-wave grid)
             (void)hipFree(tl_dbg);
@@ -537,7 +551,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             a.dbg = tl_dbg;
         }
 #endif
-        r = launch_wino4(op.NI, op.epi, tall ? W4_TALL : (half ? W4_HALF : W4_WIDE), a, g4, st);
+        r = launch_wino4(op.NI, op.epi, pack ? W4_PACK : (tall ? W4_TALL : (half ? W4_HALF : W4_WIDE)), a, g4, st);
     } else {
     static const bool direct_p0 = !(getenv("EIGEN_CONVP0_MFMA") && atoi(getenv("EIGEN_CONVP0_MFMA")));  // A/B measurements only
     if (op.epi == EPI_CONVP && op.d_wraw && direct_p0) {  // image layer: HBM-bound, one thread per pixel (conv_mfma.h)

@@ -8,6 +8,7 @@ namespace eig {
 
 hipError_t launch_wino4_tall(int NI, int epi, const ConvArgs& a, int grid, hipStream_t st);   // wino4t_kernels.hip
 hipError_t launch_wino4_half(int NI, int epi, const ConvArgs& a, int grid, hipStream_t st);   // wino4h_kernels.hip
+hipError_t launch_wino4_pack(int NI, int epi, const ConvArgs& a, int grid, hipStream_t st);   // wino4p_kernels.hip
 
 hipError_t launch_wino4(int NI, int epi, int shape, const ConvArgs& a, int grid, hipStream_t st)
 {
@@ -20,6 +21,7 @@ hipError_t launch_wino4(int NI, int epi, int shape, const ConvArgs& a, int grid,
     if (NI != 3 && NI != 4) return hipErrorInvalidConfiguration;
     if (shape == W4_TALL) return launch_wino4_tall(NI, epi, a, grid, st);
     if (shape == W4_HALF) return launch_wino4_half(NI, epi, a, grid, st);
+    if (shape == W4_PACK) return launch_wino4_pack(NI, epi, a, grid, st);
     {
         if (epi == EPI_LSTM) return NI == 4 ? go(wino4_kernel<4, EPI_LSTM>) : hipErrorInvalidConfiguration;
         if (epi == EPI_CONVA) return NI == 4 ? go(wino4_kernel<4, EPI_CONVA>) : go(wino4_kernel<3, EPI_CONVA>);

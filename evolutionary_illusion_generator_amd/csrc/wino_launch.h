@@ -1,5 +1,5 @@
 // wino_launch.h -- what the engine's translation unit (eigen_engine.hip) needs to know of the Winograd kernels: their packed-weight geometry and the launcher.
-// The kernels themselves are compiled in translation units of their own (wino4_kernels.hip: the wide blocks; wino4t_kernels.hip: the tall ones; wino4h_kernels.hip: the half blocks), so that
+// The kernels themselves are compiled in translation units of their own (wino4_kernels.hip: the wide blocks; wino4t_kernels.hip: the tall ones; wino4h_kernels.hip: the half blocks; wino4p_kernels.hip: half blocks of packed tiles), so that
 // the hipcc runs of a build go side by side (__graft_entry__.build()).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -15,8 +15,9 @@ constexpr int W4_NPOS = 36;
 constexpr int wino4_u_floats(int NI) { return W4_NPOS * 4 * 16 * NI; }   // one 4-channel K-block of the packed weights: [36 pos][4 ch][16 cols][NI] (the buffer ends in one K-block of padding: the fetch runs one K-block past the end)
 
 // grid blocks of wino4_kernel<NI, epi, shape> on stream st (NI = 3 or 4; epi = EPI_LSTM (NI = 4 only), EPI_CONVA, EPI_CONVP); the first launch of an
-// instantiation sets its dynamic-LDS attribute.  shape: W4_WIDE 16 x 32-pixel blocks, W4_TALL 32 x 16, W4_HALF 8 x 32 (six waves)
-enum { W4_WIDE = 0, W4_TALL = 1, W4_HALF = 2 };
+// instantiation sets its dynamic-LDS attribute.  shape: W4_WIDE 16 x 32-pixel blocks, W4_TALL 32 x 16, W4_HALF 8 x 32 (six waves), W4_PACK sixteen consecutive tiles of the
+// linear tile list (six waves; ConvLSTM / ConvP only)
+enum { W4_WIDE = 0, W4_TALL = 1, W4_HALF = 2, W4_PACK = 3 };
 hipError_t launch_wino4(int NI, int epi, int shape, const ConvArgs& a, int grid, hipStream_t st);
 
 }  // namespace eig

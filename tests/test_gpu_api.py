@@ -205,7 +205,8 @@ sys.path.insert(0, %(root)r)
 from evolutionary_illusion_generator_amd import weights
 from evolutionary_illusion_generator_amd.engine import Engine
 out = []
-for (w, h, ch) in [(64, 64, [3, 12, 24, 48]), (96, 64, [1, 8, 16]), (80, 64, [1, 4, 8])]:  # the last one has 20 x 16 maps: 4-wide strips
+# (80 x 64: 20 x 16 maps, 4-wide strips; 160 x 120 gray: Winograd ConvLSTMs on 80 x 60 / 40 x 30 / 20 x 15 maps -- tall blocks, packed tiles)
+for (w, h, ch) in [(64, 64, [3, 12, 24, 48]), (96, 64, [1, 8, 16]), (80, 64, [1, 4, 8]), (160, 120, [1, 16, 32, 48])]:
     rng = np.random.default_rng(7)
     B = 3
     img = rng.integers(0, 256, (B, ch[0], h, w), dtype=np.uint8)
@@ -247,7 +248,7 @@ def test_specialised_operators_equal_the_general_mfma_path(cuda):
     #  half-block / 4-column-strip / in-kernel-2x2-chain instantiations of the direct kernel and the eight-wave Winograd kernel went the same way.)
     envs = [{sw: "1"} for sw in ("EIGEN_NO_T0", "EIGEN_NO_ONEKB", "EIGEN_NO_UP4C", "EIGEN_LSTM0_MFMA", "EIGEN_CONVP0_MFMA")]
     envs += [{"EIGEN_W8": "0"}, {"EIGEN_W8": "1"}, {"EIGEN_TILE_MAP": "0"}, {"EIGEN_TILE_MAP": "1"},
-             {"EIGEN_W4_PARTS": "1"}, {"EIGEN_W4_PARTS": "2"}, {"EIGEN_W4_PARTS": "99"}, {"EIGEN_W4_TALL": "0"}, {"EIGEN_W4_TALL": "1"}, {"EIGEN_W4_TALL": "0", "EIGEN_W4_HALF": "1"}, {"EIGEN_W4_HALF": "0"}, {"EIGEN_SIDE_STREAM": "1"}, {"EIGEN_SIDE_STREAM": "0"}]   # (ConvP_l of layers > 0 on a side stream: the default at these sizes / off)   # the walk of the F(4x4) kernel: all N-blocks of a tile in one block ... one block per N-block
+             {"EIGEN_W4_PARTS": "1"}, {"EIGEN_W4_PARTS": "2"}, {"EIGEN_W4_PARTS": "99"}, {"EIGEN_W4_TALL": "0"}, {"EIGEN_W4_TALL": "1"}, {"EIGEN_W4_TALL": "0", "EIGEN_W4_HALF": "1"}, {"EIGEN_W4_HALF": "0"}, {"EIGEN_W4_PACK": "0"}, {"EIGEN_W4_PACK": "1"}, {"EIGEN_SIDE_STREAM": "1"}, {"EIGEN_SIDE_STREAM": "0"}]   # (ConvP_l of layers > 0 on a side stream: the default at these sizes / off)   # the walk of the F(4x4) kernel: all N-blocks of a tile in one block ... one block per N-block
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=4) as pool:   # (fresh processes sharing the one GPU: the runs are tiny)
         for env, got in zip(envs, pool.map(run, envs)):

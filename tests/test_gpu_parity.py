@@ -421,7 +421,9 @@ ok = True
 # (w, h, channels, batch): 16-channel gate groups at layers >= 1; ragged 16 x 16 tiles (40 x 24, 20 x 12 maps), a 4-layer net, a top
 # layer without an unpooled source, colour and gray image layers (which keep the direct operators); 48- / 96- / 192-channel ConvA and
 # ConvP (N-blocks of 48 and of 64 columns); the reference's own 160 x 120 with its 20 x 15 top layer (odd height)
-for (w, h, ch, B) in [(64, 64, [3, 16, 32], 3), (80, 48, [1, 16, 32, 48], 2), (96, 64, [3, 48, 96], 2), (160, 120, [3, 48, 96, 192], 2)]:
+# and at three images (tiles of three images in one packed block's list: 60 tiles = 3.75 blocks); 128 x 128 with a 16 x 16 top layer of 48 channels (packed tiles, 4 x 4 per image,
+# ConvP in N-blocks of 48 columns)
+for (w, h, ch, B) in [(64, 64, [3, 16, 32], 3), (80, 48, [1, 16, 32, 48], 2), (96, 64, [3, 48, 96], 2), (160, 120, [3, 48, 96, 192], 3), (128, 128, [3, 16, 32, 48], 3)]:
     rng = np.random.default_rng(11)
     img = rng.integers(0, 256, (B, ch[0], h, w), dtype=np.uint8)
     wts = weights.synthetic_prednet_weights(ch, w, h, seed=5)
@@ -444,7 +446,7 @@ print("WINO_OK" if ok else "WINO_FAIL")
 """
 
 
-@pytest.mark.parametrize("switch", [None, "parts=1", "tall=1", "half=1", "0x03FFFFFE", "0x0C0E0E00"])
+@pytest.mark.parametrize("switch", [None, "parts=1", "tall=1", "half=1", "pack=0", "0x03FFFFFE", "0x0C0E0E00"])
 def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     """The Winograd forms of the 3x3 convolutions against the oracle's statement of exactly that arithmetic (eig_oracle.c: wino_*, wino4_*; the oracle follows the
     same environment switch): all frames of four small roll-outs, bit for bit -- incl. step-0 operators (one source), ragged tiles, a top layer without an unpooled
@@ -454,7 +456,8 @@ def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     maps, which take the tall shape, and a 20 x 15 one, which does not); "parts=1": the same with a block of that kernel walking ALL N-blocks of its tile (EIGEN_W4_PARTS: the
     launch geometry must not show in a single bit; test_specialised_operators... covers 2 / 99 and the forced shapes on other roll-outs); "tall=1": every F(4x4) operator on
     32 x 16-pixel blocks (EIGEN_W4_TALL); "half=1": every F(4x4) operator on 8 x 32-pixel half blocks of six waves (EIGEN_W4_HALF; the shape of launches smaller than one
-    block per compute unit); 0x03FFFFFE: only the ConvLSTMs in F(4x4), ConvA / ConvP direct (class bits 26 / 27 clear); 0x0C0E0E00: ConvA and ConvP in
+    block per compute unit); "pack=0": no packed tiles (EIGEN_W4_PACK: by default the ConvLSTM and the ConvP of a 20 x 15 or 16 x 16 top layer run on half blocks
+    of sixteen consecutive tiles of the launch's linear tile list -- the 160 x 120 and the 128 x 128 roll-outs here); 0x03FFFFFE: only the ConvLSTMs in F(4x4), ConvA / ConvP direct (class bits 26 / 27 clear); 0x0C0E0E00: ConvA and ConvP in
     F(4x4), every ConvLSTM direct.  (The F(2x2, 3x3) sixteen-wave kernel of rounds 4-5 and its masks went in round 6.)"""
     import subprocess
     env = dict(os.environ)
@@ -462,6 +465,10 @@ def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     env.pop("EIGEN_W4_PARTS", None)
     env.pop("EIGEN_W4_TALL", None)
     env.pop("EIGEN_W4_HALF", None)
+    env.pop("EIGEN_W4_PACK", None)
+    if switch is not None and switch.startswith("pack="):
+        env["EIGEN_W4_PACK"] = switch.split("=")[1]
+        switch = None
     if switch is not None and switch.startswith("half="):
         env["EIGEN_W4_TALL"] = "0"
         env["EIGEN_W4_HALF"] = switch.split("=")[1]
