@@ -63,6 +63,9 @@ constexpr int w4_x(bool tall) { return tall ? w4_u(true, 0) : w4_u(false, 1); }
 constexpr int W4_X_FLOATS = W4_WAVES * 2 * 4 * 64 * 4;          // one exchange round = two N-tiles: [12 waves][2][4 e][64 lanes] 16-byte vectors = 96 KB
 constexpr int wino4_lds_bytes() { return (w4_x(false) + W4_X_FLOATS) * 4; }   // 159744, both shapes (tall: 3 x 16 KB + 3 x 36 KB)
 static_assert((w4_u(true, 2) + W4_U_FLOATS) * 4 == wino4_lds_bytes() && (w4_p(false, 2) + w4_pslot(false)) * 4 <= wino4_lds_bytes(), "LDS maps");
+#ifndef EIG_W4_DEEPU
+#define EIG_W4_DEEPU 1   // 0: measurement builds only (the half blocks' U slabs waited for one K-block earlier, as the full blocks do: profiles/r06_y_*)
+#endif
 #ifndef EIG_W4_DIAG
 #define EIG_W4_DIAG 0   // measurement builds only (WRONG RESULTS): 1 no wait for the K loop's DMAs, 2 no barrier in the K loop, 4 no A-operand build, 8 no plane DMA, 16 no U DMA
 #endif
@@ -105,14 +108,28 @@ template <typename V4> __device__ __forceinline__ void w4_out1d(const V4& m0, co
 // of less than one block per CU (configs[0]: 10 to 40 blocks): their time is ONE block's time, and a six-wave block has the CU's matrix pipe to itself for half the
 // multiply-adds.  A choice by launch size (eigen_engine.hip), like the walk; the chains do not depend on it.
 //
-// PACK (round 6; a half block): the block's sixteen MFMA rows are sixteen CONSECUTIVE tiles of the launch's linear tile list (image-major, then tile row, then tile
-// column) instead of a 2 x 8 rectangle of one image -- for maps of 16 or 20 columns and 13 to 16 rows (4 x 4 or 5 x 4 tiles: the 20 x 15 top layer of the reference's
-// own 160 x 120), which fill half / 62 % of a wide block.  A region then spans at most two images: the plane of a channel is [2 images][18 rows][7 chunks] (252 chunks
-// = four DMA parts, sixteen (channel, part) instructions per K-block over the six waves: three for waves 0-3, two for 4 and 5) in the tall shape's LDS map; the
-// A-operand base, the exchange slot and the output address of a lane come from its tile's (image, ty, tx).  Operators without an unpooled source, ConvLSTM / ConvP.
-template <int NI, int EPI, bool TALL = false, bool HALF = false, bool PACK = false>
-__global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_kernel(const ConvArgs a)
+// PACK (round 6; a half block): for maps of 16 or 20 columns and 13 to 16 rows (4 x 4 or 5 x 4 tiles: the 20 x 15 top layer of the reference's own 160 x 120), which fill
+// half / 62 % of a wide block.  The block's sixteen MFMA rows are either the 4 x 4 tiles of tile columns 0-3 of ONE image (a "main" block: MFMA row r = 4 ty + tx, the
+// tall shape's region) or, for 5-column maps, tile column 4 of FOUR consecutive images (an "edge" block: r = 4 image + ty) -- five blocks per four images, every MFMA row
+// a real tile (the launch's B main blocks first, then the edge blocks).  The plane container of a channel is [2][18 rows][7 chunks] in the tall shape's LDS map (row stride 28 floats): a main block fills [0] with its image's
+// columns -4 .. 23; an edge block puts columns 12 .. 23 of image 2 p + b into chunks 3 b .. 3 b + 2 of [p] -- in both, the sixteen 16-byte patch reads of a lane group
+// fall on sixteen different bank slots (a linear tile list with 5-tile rows cannot: profiles/r06_z_pmc_ref160.txt, half of the LDS cycles were conflicts).  Sixteen
+// (channel, part) DMA instructions per K-block over the block's waves; the A-operand base, the exchange slot and the output address of a lane come from its tile's
+// (image, ty, tx).  Operators without an unpooled source, ConvLSTM / ConvP.
+//
+// NSPLIT (round 6; a half block of TWELVE waves): wave (ng, xi) multiplies the block's sixteen tiles for the six positions of row xi and the N-tiles 2 ng, 2 ng + 1 only --
+// twelve MFMAs per K-block instead of 24, three waves on every SIMD instead of two on two of them: the six-wave half block leaves the matrix pipe of two SIMDs
+// half empty.  Both waves of a row build the same A operands; the exchange is ONE round (wave (ng, xi) publishes its two N-tiles), and the sixteen finishing units of
+// the region go over twelve waves (two for (0, xi < 4), one for the others).  64-column N-blocks, ConvLSTM / ConvP.
+template <int NI, int EPI, bool TALL = false, bool HALF = false, bool PACK = false, bool NSPLIT = false>
+__global__ void __launch_bounds__((HALF && !NSPLIT) ? W4_THREADS / 2 : W4_THREADS, 3) wino4_kernel(const ConvArgs a)
 {
+    static_assert(!NSPLIT || (HALF && NI == 4 && EPI != EPI_CONVA), "N-split: a half block, 64-column N-blocks, ConvLSTM / ConvP");
+    constexpr int NIW = NSPLIT ? 2 : NI;             // N-tiles a wave multiplies
+    // Half blocks: a K-block is 0.5 us of matrix work, less than the round trip of an LDS-DMA -- with the U slab of K-block j waited for at the end of j - 2 (the K-block
+    // it is issued in) the loop ran at the DMA's latency, 1.1 us per K-block (profiles/r06_y_*).  DEEPU: U(j) is waited for at the end of j - 1 instead (the wait at the
+    // end of a K-block lets that K-block's own U and plane fetches stay in flight); the first B operand of a K-block is then read behind the barrier in front of it.
+    constexpr bool DEEPU = HALF && EIG_W4_DEEPU;
     static_assert(!(TALL && HALF), "half blocks exist in the wide shape only");
     static_assert(!PACK || (HALF && EPI != EPI_CONVA), "packed tiles: a half block, ConvLSTM / ConvP");
     constexpr bool TGEO = TALL || PACK;              // plane rows of 28 floats, 16 KB plane slots, the tall LDS map
@@ -131,8 +148,9 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     float* const Ub = lds;
     float* const xb = lds + w4_x(TGEO);
     const int wv_o = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-    const int rg_o = HALF ? 0 : wv_o & 1, xi_o = HALF ? wv_o : wv_o >> 1;
-    constexpr int NWAVES = HALF ? W4_WAVES / 2 : W4_WAVES;
+    const int rg_o = HALF ? 0 : wv_o & 1, xi_o = (HALF && !NSPLIT) ? wv_o : wv_o >> 1;
+    const int ng_o = NSPLIT ? wv_o & 1 : 0;          // N-split: the wave's N-tile pair
+    constexpr int NWAVES = (HALF && !NSPLIT) ? W4_WAVES / 2 : W4_WAVES;
     constexpr int UPW = 36 / NWAVES;                  // positions of a U slab a wave fetches: 3 (HALF: 6 -- its own row of the position grid)
     // The lane index, opaque to the compiler: every per-lane quantity of the K loop and of the finishing phase is derived from a FRESH copy at the point of use, so
     // that nothing per-lane is hoisted out of the walk and carried in registers (or scratch) across the phase that does not need it -- the walking kernel of round 5
@@ -140,7 +158,8 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     auto lane_id = [&]() __attribute__((always_inline)) { int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); asm volatile("" : "+v"(l)); return l; };
 
     const int tiles = a.tilesX * a.tilesY;            // (PACK: the tiles of ONE image, tilesX x tilesY of 4 x 4 pixels)
-    const int ntile = PACK ? (a.B * tiles + 15) >> 4 : a.B * tiles;
+    const bool pk5 = PACK && a.tilesX == 5;           // (PACK: 5-column maps have edge blocks)
+    const int ntile = PACK ? a.B + (pk5 ? (a.B + 3) >> 2 : 0) : a.B * tiles;   // (PACK: the main blocks of the B images, then the edge blocks of the image groups of four)
     const int xcd = blockIdx.x & 7, xi_ = blockIdx.x >> 3;
     // (divisions by launch constants through their host-side reciprocals, ConvArgs::mg: a run-time integer division is ~25 dependent scalar instructions:
     // profiles/r05_f_w4_timeline.txt)
@@ -152,11 +171,11 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     const int tlin = a.tile_map ? xcd * ((ntile + 7) >> 3) + q0 : q0 * 8 + xcd;
     if (tlin >= ntile) return;
     const int nwalk = WALK ? a.nwalk : 1, nb0 = part * nwalk;   // this block computes N-blocks nb0 .. nb0 + nwalk - 1 of its tile
-    const int eb = dv(PACK ? tlin * 16 : tlin, tiles, a.mg[1]);   // (PACK: the image of the block's first tile, t_ = that tile's index in it)
-    const int t_ = (PACK ? tlin * 16 : tlin) - eb * tiles;
+    const bool pk_edge_o = pk5 && tlin >= a.B;
+    const int eb = PACK ? (pk_edge_o ? 4 * (tlin - a.B) : tlin) : dv(tlin, tiles, a.mg[1]);   // (PACK: the block's (first) image)
+    const int t_ = PACK ? 0 : tlin - eb * tiles;
     const int tyi = dv(t_, a.tilesX, a.mg[2]), txi = t_ - tyi * a.tilesX;
     const int y0 = PACK ? 0 : tyi * (TALL ? 32 : (HALF ? 8 : 16)), x0 = PACK ? 0 : txi * (TALL ? 16 : 32);
-    const int o0_o = t_;
     const int HW = a.H * a.W;
 
     const bool up_fused = !PACK && EPI == EPI_LSTM && a.up_src != nullptr;
@@ -185,14 +204,16 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     // scratch, reloads inside the K loop; the non-walking kernel: 88 / 0 / 0).
     int zs = 0;
     asm volatile("" : "+s"(zs));
-    const int wv = wv_o + zs, rg = rg_o + zs, xi = xi_o + zs, nkb = nkb_o + zs, up_lo = up_lo_o + zs, up_hi = up_hi_o + zs;
+    const int wv = wv_o + zs, rg = rg_o + zs, xi = xi_o + zs, ng = ng_o + zs, nkb = nkb_o + zs, up_lo = up_lo_o + zs, up_hi = up_hi_o + zs;
     const int pch = HALF ? wv >> 1 : wv / 3, ppart = HALF ? wv & 1 : wv - pch * 3;   // this wave's plane DMA: channel, part of 64 chunks
-    const int eb_i = eb + zs, y0_i = y0 + zs, x0_i = x0 + zs, o0 = o0_o + zs;
+    const bool has_plane = !(NSPLIT && !PACK) || wv_o < 8;   // (N-split: the eight (channel, part) pairs of a half block's plane go to waves 0-7; wave-uniform)
+    const int eb_i = eb + zs, y0_i = y0 + zs, x0_i = x0 + zs;
+    const bool pk_edge = (pk_edge_o ? 1 : 0) + zs != 0;
     const unsigned long long sb0 = (unsigned long long)(a.src[0].ptr + (size_t)eb_i * a.src[0].Ct * HW);
     const unsigned long long sb1 = has1 ? (unsigned long long)(a.src[1].ptr + (size_t)eb_i * a.src[1].Ct * HW) : sb0;
-    // (PACK: the descriptor's range takes in the block's second image -- lanes whose image does not exist carry the out-of-range offset)
+    // (PACK: the descriptor's range takes in the four images of an edge block -- lanes whose image does not exist carry the out-of-range offset)
     const int ist0 = a.src[0].Ct * HW * 4, ist1 = has1 ? a.src[1].Ct * HW * 4 : ist0;   // bytes from an image to the next
-    const int sz0 = a.src[0].C * HW * 4 + (PACK ? ist0 : 0), sz1 = has1 ? a.src[1].C * HW * 4 + (PACK ? ist1 : 0) : sz0;
+    const int sz0 = a.src[0].C * HW * 4 + (PACK ? 3 * ist0 : 0), sz1 = has1 ? a.src[1].C * HW * 4 + (PACK ? 3 * ist1 : 0) : sz0;
     const int Hh = a.H >> 1, Wh = a.W >> 1, HWh = Hh * Wh;
     const unsigned long long sbu = up_fused ? (unsigned long long)(a.up_src + (size_t)eb_i * a.up_C * HWh) : sb0;
     const int szu = up_fused ? a.up_C * HWh * 4 : sz0;
@@ -209,26 +230,28 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
         const int hy = (y0_i >> 1) - 1 + row, hx = (x0_i >> 1) - 4 + 4 * cx;
         uo = (row < UROWS && cx < UCHK && hy >= 0 && hy < Hh && hx >= 0 && hx < Wh) ? (hy * Wh + hx) * 4 : -1;
     };
-    // PACK: wave wv issues the (channel, part) pairs idx = wv + 6 k < 16 (k = 0, 1, 2): channel idx >> 2, part idx & 3; chunk c = lane + 64 part of [2][18][7]
+    // PACK: wave wv issues the (channel, part) pairs idx = wv + NWAVES k < 16 (k = 0, 1, 2): channel idx >> 2, part idx & 3; chunk c = lane + 64 part of [2][18][7]
     int pk_ro[3] = {-1, -1, -1};
-    unsigned pk_sel[3] = {0u, 0u, 0u};   // all ones: the chunk belongs to the block's second image
-    const int pk_n = wv_o < 4 ? 3 : 2;   // (wave-uniform)
+    unsigned pk_mul[3] = {0u, 0u, 0u};   // the chunk's image, relative to the block's first
+    const int pk_n = (wv_o < 4 ? 2 : 1) + (NSPLIT ? 0 : 1);   // (wave-uniform: 16 (channel, part) pairs over the block's six / twelve waves)
     if constexpr (PACK) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const int c = lane + 64 * ((wv_o + 6 * k) & 3);
-            const int i = c >= PK_IMG ? 1 : 0, c1 = c - PK_IMG * i;
-            const int row = c1 / PK_CX, cx = c1 - row * PK_CX;
+            const int c = lane + 64 * ((wv_o + NWAVES * k) & 3);
+            const int p = c >= PK_IMG ? 1 : 0, c1 = c - PK_IMG * p;
+            const int row = c1 / PK_CX, slot = c1 - row * PK_CX;
+            const int b = slot >= 3 ? (slot >= 6 ? 2 : 1) : 0;                       // (edge: three chunks per image, slot 6 unused)
+            const int irel = pk_edge ? 2 * p + b : 0, cx = pk_edge ? 4 + slot - 3 * b : slot;
             const int gy = row - 1, gx = 4 * cx - 4;
-            const bool ok = c < 2 * PK_IMG && eb_i + i < a.B && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const bool ok = (pk_edge ? (c < 2 * PK_IMG && b < 2) : c < PK_IMG) && eb_i + irel < a.B && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
             pk_ro[k] = ok ? (gy * a.W + gx) * 4 : -1;
-            pk_sel[k] = (ok && i) ? ~0u : 0u;
+            pk_mul[k] = ok ? (unsigned)irel : 0u;
         }
     }
     int roff, uoff, roff2 = -1, uoff2 = -1;
     plane_offsets(ppart, roff, uoff);
     // second plane instruction of some waves: tall -- part 3 of channel wv (waves 0-3); half -- channel 3, part wv & 1 (waves 0, 1: eight parts over six waves)
-    const bool two_parts = (TALL && wv_o < 4) || (HALF && !PACK && wv_o < 2);   // (wave-uniform)
+    const bool two_parts = (TALL && wv_o < 4) || (HALF && !PACK && !NSPLIT && wv_o < 2);   // (wave-uniform)
     if (TALL) plane_offsets(3, roff2, uoff2);
     if (HALF) { roff2 = roff; uoff2 = uoff; }
     const int ch2 = HALF ? 3 : wv, part2 = HALF ? ppart : 3;
@@ -248,13 +271,14 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k >= pk_n) break;
-                const int idx = wv_o + 6 * k;
+                const int idx = wv_o + NWAVES * k;
                 const unsigned coffk = (unsigned)((j - base) * KC + (idx >> 2)) * (unsigned)(hw * 4);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + (idx >> 2) * PS + (idx & 3) * 256), 16,
-                                                         (int)__builtin_elementwise_add_sat((unsigned)pk_ro[k] + (pk_sel[k] & ist), coffk), 0, 0, 0);
+                                                         (int)__builtin_elementwise_add_sat((unsigned)pk_ro[k] + pk_mul[k] * ist, coffk), 0, 0, 0);
             }
             return;
         }
+        if (!has_plane) return;
         const unsigned coff = (unsigned)((j - base) * KC + pch) * (unsigned)(hw * 4);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(Pb + slot_off + pch * PS + ppart * 256), 16,
                                                  (int)__builtin_elementwise_add_sat((unsigned)roff + (((unsigned)uoff - (unsigned)roff) & (unsigned)mu), coff), 0, 0, 0);
@@ -266,8 +290,19 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     };
     // "the U fetch of this K-block has landed, its plane fetch (one instruction, two for waves 0-3 of a tall block) may stay in flight"
     auto wait_u = [&]() __attribute__((always_inline)) {
-        if constexpr (PACK) { if (pk_n == 3) EIG4_WAITCNT(0x0F73); else EIG4_WAITCNT(0x0F72); }
-        else { if (two_parts) EIG4_WAITCNT(0x0F72); else EIG4_WAITCNT(0x0F71); }
+        const int npl = PACK ? pk_n : (two_parts ? 2 : (has_plane ? 1 : 0));   // plane instructions of this wave per K-block (wave-uniform)
+        switch (npl + (DEEPU ? UPW : 0)) {   // (DEEPU: ... and the U fetch of this K-block)
+            case 0: EIG4_WAITCNT(0x0F70); break;
+            case 1: EIG4_WAITCNT(0x0F71); break;
+            case 2: EIG4_WAITCNT(0x0F72); break;
+            case 3: EIG4_WAITCNT(0x0F73); break;
+            case 4: EIG4_WAITCNT(0x0F74); break;
+            case 5: EIG4_WAITCNT(0x0F75); break;
+            case 6: EIG4_WAITCNT(0x0F76); break;
+            case 7: EIG4_WAITCNT(0x0F77); break;
+            case 8: EIG4_WAITCNT(0x0F78); break;
+            default: EIG4_WAITCNT(0x0F79); break;
+        }
     };
     // ---- U fetch (every wave: positions 3 wv .. 3 wv + 2 of the next K-block in line): one position of a packed 4-channel K-block = one contiguous KB (NI = 3: 768 B).
     // The scalar offset runs along the packed K-blocks (no index arithmetic in the K loop; the last two fetches read the next N-block's first K-blocks or the
@@ -295,14 +330,14 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
 
     // ---- A operands: lane (q, col) -> channel q of the K-block, tile (ty, tx) of region rg (rows RGH rg .. of the block): wide (col >> 3, col & 7), MFMA row r = 8 ty + tx;
     // tall (col >> 2, col & 3), r = 4 ty + tx
-    // PACK: MFMA row col = tile o0 + col of the linear list: image i (0 / 1 of the block's two), tile (ty, tx) of it
-    const int pk_i = (PACK && o0 + col >= tiles) ? 1 : 0, pk_t = o0 + col - (pk_i ? tiles : 0);
-    const int pk_ty = PACK ? dv(pk_t, a.tilesX, a.mg[2]) : 0, pk_tx = pk_t - pk_ty * a.tilesX;
-    const int t_ty = PACK ? 0 : (TALL ? col >> 2 : col >> 3), t_tx = PACK ? pk_tx : (TALL ? col & 3 : col & 7);
-    const int pk_row = PACK ? PK_ROWS * pk_i + 4 * pk_ty : 0;   // (first plane row of the tile's patch in [2][18] rows)
+    // PACK: MFMA row col = main: tile (col >> 2, col & 3) of the block's image, at chunk tx of row 4 ty of [0]; edge: tile (ty = col & 3, 4) of image col >> 2 = 2 p + b,
+    // at chunk 3 b of row 4 ty of [p]
+    const int pk_ir = pk_edge ? col >> 2 : 0, pk_ty = pk_edge ? col & 3 : col >> 2;
+    const int t_ty = PACK ? 0 : (TALL ? col >> 2 : col >> 3), t_tx = PACK ? (pk_edge ? 3 * (pk_ir & 1) : col & 3) : (TALL ? col & 3 : col & 7);
+    const int pk_row = PACK ? PK_ROWS * (pk_ir >> 1) + 4 * pk_ty : 0;   // (first plane row of the tile's patch in [2][18] rows)
     const float* const pbase_n = Pb + q * PS + (RGH * rg + 4 * t_ty + pk_row) * W4_ROW + 4 * t_tx;        // patch row 0, the aligned chunk that holds patch column 0 in its last float: columns 0 .. 5 = floats 3 .. 8
     const float* const pbase_u = Pb + q * PS + ((RGH / 2) * rg + 2 * t_ty) * W4_ROW + 2 * t_tx + 3;    // source row s, column s of an unpooled patch (half-resolution plane)
-    const int b_off = xi * 6 * W4_UPOS + (q * 16 + col) * NI;   // U[pos = 6 xi + nu][ch = q][col][0 .. NI)
+    const int b_off = xi * 6 * W4_UPOS + (q * 16 + col) * NI + 2 * ng;   // U[pos = 6 xi + nu][ch = q][col][0 .. NI)  (N-split: N-tiles 2 ng, 2 ng + 1)
 
     unsigned long long tq_setup = tq_entry;
     if (it == 0) {
@@ -320,11 +355,11 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
         u_so += (unsigned)U4 * 4;
     };
     // accumulators: position (xi, nu), N-tile ni
-    f32x4 acc[6][NI];
+    f32x4 acc[6][NIW];
 #pragma unroll
     for (int p = 0; p < 6; ++p)
 #pragma unroll
-        for (int ni = 0; ni < NI; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int ni = 0; ni < NIW; ++ni) acc[p][ni] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // (a fresh block waited for part A of its prologue above; a walking block's waves each waited for theirs -- vmcnt(0) -- in front of the previous finishing phase's
     // gate loads.)  Behind this barrier nobody reads the exchange area any more: part B goes into it.
     EIG4_BARRIER();
@@ -350,7 +385,7 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     auto kloops = [&](auto role_tag) __attribute__((always_inline)) {
         constexpr int XI = decltype(role_tag)::value;
         float v[6];            // A operands of the current K-block (built at the end of the previous one)
-        float bq[NI];          // B operand of the current K-block's first chunk, read before the barrier in front of it
+        float bq[NIW];         // B operand of the current K-block's first chunk, read before the barrier in front of it
         // Rings of three, all in the phase kb % 3, as ROTATING float offsets (one set of moves per K-block; slot counters cost an add, a compare, a select and a multiply
         // each, in every K-block's instruction stream): U slots of K-blocks kb, kb + 1 and of the fetch (kb + 2); plane slots of the fetch (kb + 3 -> slot kb % 3), of the
         // patch rows read next (kb + 1) and the third
@@ -382,11 +417,11 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     if (k >= pk_n) break;
-                    const int idx = wv + 6 * k;
+                    const int idx = wv + NWAVES * k;
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + (idx >> 2) * PS + (idx & 3) * 256), 16,
-                                                             (int)__builtin_elementwise_add_sat((unsigned)pk_ro[k] + (pk_sel[k] & pist), pcoff + (unsigned)(idx >> 2) * phw4), 0, 0, 0);
+                                                             (int)__builtin_elementwise_add_sat((unsigned)pk_ro[k] + pk_mul[k] * pist, pcoff + (unsigned)(idx >> 2) * phw4), 0, 0, 0);
                 }
-            } else {
+            } else if (has_plane) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(prs, (__attribute__((address_space(3))) void*)(Pb + po0 + pch * PS + ppart * 256), 16,
                                                      (int)__builtin_elementwise_add_sat(o, pcoff), 0, 0, 0);
             }
@@ -457,7 +492,10 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
         };
         auto read_b = [&](int slot_off, int nu, float* dst) __attribute__((always_inline)) {
             const float* const bsrc = Ub + slot_off + b_off + nu * W4_UPOS;
-            if constexpr (NI == 4) {
+            if constexpr (NSPLIT) {
+                const f32x2 b2 = *reinterpret_cast<const f32x2*>(bsrc);
+                dst[0] = b2[0]; dst[1] = b2[1];
+            } else if constexpr (NI == 4) {
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(bsrc);
                 dst[0] = b4[0]; dst[1] = b4[1]; dst[2] = b4[2]; dst[3] = b4[3];
             } else {
@@ -473,11 +511,11 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
             constexpr int KIND = decltype(kind_tag)::value;
             constexpr int NK = decltype(nk_tag)::value;
             constexpr bool LAST = decltype(last_tag)::value;
-            constexpr bool FIRST = decltype(first_tag)::value;   // K-block 0: the U slab of K-block 1 (prologue part B) is only known to have landed at this K-block's END -- its first operand is read behind the barrier
+            constexpr bool FIRST = decltype(first_tag)::value || (DEEPU && !LAST);   // K-block 0 (DEEPU: every K-block): the U slab of K-block 1 (prologue part B) is only known to have landed at this K-block's END -- its first operand is read behind the barrier
             constexpr bool UP = KIND == 1;   // (run-time kind = the last K-block of all: an unpooled-source one there runs the full body on its exact-zero operands -- fma(0, u, M) = M)
             constexpr bool IDLE = UP && XI == 2;   // nothing to multiply
             constexpr int NCH = IDLE ? 0 : (UP ? 5 : 6);   // chunks: nu = 0, 1, (2,) 3, 4, 5
-            float bv[2][NI];
+            float bv[2][NIW];
             // slices of staging work behind the chunks: the U fetch behind chunk 0, the plane fetch behind chunk 1, the patch rows of K-block kb + 1 and row XI of
             // B^T d in two phases behind chunks NCH - 4 .. NCH - 2 (their registers are needed late), the column pass behind the last chunk
             auto slice = [&](int i) __attribute__((always_inline)) {
@@ -508,7 +546,7 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
                     } else if constexpr (!LAST && !FIRST) read_b(uo1, 0, bq);
                     const float* const b = i == 0 ? bq : bv[i & 1];
 #pragma unroll
-                    for (int ni = 0; ni < NI; ++ni) acc[nu][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], b[ni], acc[nu][ni], 0, 0, 0);
+                    for (int ni = 0; ni < NIW; ++ni) acc[nu][ni] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[nu], b[ni], acc[nu][ni], 0, 0, 0);
                     slice(i);
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -556,9 +594,9 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     if (more) prologue_a(nblk + 1);
 
     // ---- output transform.  Along nu in-lane: c_xi,b (b = 0..3) of every N-tile.
-    f32x4 cc[4][NI];
+    f32x4 cc[4][NIW];
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
+    for (int ni = 0; ni < NIW; ++ni) {
         f32x4 Y[4];
         w4_out1d(acc[0][ni], acc[1][ni], acc[2][ni], acc[3][ni], acc[4][ni], acc[5][ni], Y);
 #pragma unroll
@@ -570,7 +608,8 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     {   // (own scope: per-lane quantities from a FRESH lane_id(), scalars from coordinates offset by a fresh opaque zero: see the top of the kernel / of the walk)
     int zf = 0;
     asm volatile("" : "+s"(zf));
-    const int eb = eb_i + zf, y0 = y0_i + zf, x0 = x0_i + zf, wv = wv_o + zf, rg = rg_o + zf, xi = xi_o + zf, HWf = HW + zf, Cout = a.Cout + zf, o0f = o0_o + zf;
+    const int eb = eb_i + zf, y0 = y0_i + zf, x0 = x0_i + zf, wv = wv_o + zf, rg = rg_o + zf, xi = xi_o + zf, HWf = HW + zf, Cout = a.Cout + zf, ngf = ng_o + zf;
+    const bool pk_edge_f = (pk_edge_o ? 1 : 0) + zf != 0;
     const int lane = lane_id();
     const int q = lane >> 4, col = lane & 15;
     const size_t cHW = (size_t)HWf;
@@ -578,12 +617,11 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
     const int j = TALL ? lane & 3 : lane & 7, chl = TALL ? lane >> 2 : lane >> 3, e_r = j & 3, ql = TALL ? 0 : j >> 2;
     int woff[4];                                                           // publishing lane (q, col): its slot in plane e
 #pragma unroll
-    for (int e = 0; e < 4; ++e) woff[e] = (((2 * xi + rg) * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + (PACK ? q : (TALL ? 0 : 8 * (q & 1)))) & 15)) * 4;
+    for (int e = 0; e < 4; ++e) woff[e] = (((2 * xi + (NSPLIT ? ngf : rg)) * 2 * 4 + e) * 64 + q * 16 + ((col + 4 * e + (PACK ? q : (TALL ? 0 : 8 * (q & 1)))) & 15)) * 4;
     // PACK: finishing lane L takes tile r = L & 15 of the block (writer lane group r >> 2, register r & 3) for channel 4 cq + (L >> 4); a unit = one channel quarter cq;
     // the writer's slot q 16 + ((col + 4 e + q) & 15) spreads the sixteen tiles of a reader group over all sixteen slots.  The tile's image / row / column as in the K loop.
     const int fr = lane & 15, fchl = lane >> 4;
-    const int f_i = (PACK && o0f + fr >= tiles) ? 1 : 0, f_t = o0f + fr - (f_i ? tiles : 0);
-    const int f_ty = PACK ? dv(f_t, a.tilesX, a.mg[2]) : 0, f_tx = f_t - f_ty * a.tilesX;
+    const int f_i = pk_edge_f ? fr >> 2 : 0, f_ty = pk_edge_f ? fr & 3 : fr >> 2, f_tx = pk_edge_f ? 4 : fr & 3;
     if constexpr (EPI == EPI_LSTM || EPI == EPI_CONVP) {
         // All twelve waves finish outputs, and they finish them in IMAGE order: the exchange is laid out so that a finishing lane reads the four pixels b = 0..3 of ONE tile
         // as a 16-byte vector, and finishing lane L takes the 16-byte chunk j = L & 7 of a 32-pixel block row (tile tx = j, writer lane q = 2 ty + (j >> 2), register e =
@@ -592,19 +630,22 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
         // profiles/r05_f_w4_timeline.txt).  Units of 64 chunks: wave xi < 4 takes output row a = xi of (tile row ty, channel half chh) = (0,0), (0,1), (1,0); waves 4 / 5
         // take (1,1) of rows 0, 1 / 2, 3 -- 12 or 8 cells per lane.  Rounds: N-tiles (gates) 0, 1 then 2, 3: [12 waves][2][4 e][64 lanes] 16-byte vectors = 96 KB each; the
         // slot of writer lane (q, col) in plane e is q 16 + ((col + 4 e + 8 (q & 1)) & 15), which spreads every 16-lane service group of the b128 reads over all 16 slots.
-        const int nun = xi < 4 ? 3 : 2;
+        // The sixteen units of a region: (output row arow, quarter cq) -- cq = (tile row ty, channel half chh) = (cq >> 1, cq & 1) in the wide shape, the tile row in the
+        // tall one, the channel quarter with packed tiles.  Six waves per region: wave xi < 4 takes row xi of quarters 0, 1, 2; waves 4 / 5 quarter 3 of rows 0, 1 / 2, 3.
+        // N-split (twelve waves, one region): (0, xi < 4) row xi of quarters 0, 1; (1, xi < 4) of quarter 2; (ng, 4) / (ng, 5) quarter 3 of row ng / 2 + ng.
+        const int nun = NSPLIT ? ((xi < 4 && ngf == 0) ? 2 : 1) : (xi < 4 ? 3 : 2);
+        auto unit_cq = [&](int un) __attribute__((always_inline)) { return xi < 4 ? (NSPLIT ? (ngf ? 2 : un) : un) : 3; };
+        auto unit_arow = [&](int un) __attribute__((always_inline)) { return xi < 4 ? xi : 2 * (xi - 4) + (NSPLIT ? ngf : un); };
         int xoff[3];
 #pragma unroll
         for (int un = 0; un < 3; ++un) {   // (tall: MFMA row r = 4 ty + tx -- the writer lane group q IS the tile row, a unit = one of the four tile rows for all 16 channels)
-            const int ty = TALL ? (xi < 4 ? un : 3) : (xi < 4 ? (un >> 1) : 1), chh = TALL ? 0 : (xi < 4 ? (un & 1) : 1);
+            const int cq = unit_cq(un);
+            const int ty = TALL ? cq : cq >> 1, chh = TALL ? 0 : cq & 1;
             xoff[un] = TALL ? (e_r * 64 + ty * 16 + ((chl + 4 * e_r) & 15)) * 4 : (e_r * 64 + (2 * ty + ql) * 16 + ((8 * chh + chl + 4 * e_r + 8 * ql) & 15)) * 4;
-            if constexpr (PACK) {
-                const int cq = xi < 4 ? un : 3;
-                xoff[un] = ((fr & 3) * 64 + (fr >> 2) * 16 + ((4 * cq + fchl + 4 * (fr & 3) + (fr >> 2)) & 15)) * 4;
-            }
+            if constexpr (PACK) xoff[un] = ((fr & 3) * 64 + (fr >> 2) * 16 + ((4 * cq + fchl + 4 * (fr & 3) + (fr >> 2)) & 15)) * 4;
         }
-        auto finish = [&](int arow, int nr, int off) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3
-            auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + ((x * 2 + rg) * 2 + nr) * 1024 + off); };
+        auto finish = [&](int arow, int nr, int off, int xw) __attribute__((always_inline)) -> f32x4 {   // output row arow of the reader's chunk: pixels b = 0..3 (xw: the region / N-split: the N-tile pair)
+            auto C = [&](int x) __attribute__((always_inline)) { return *reinterpret_cast<const f32x4*>(xb + ((x * 2 + xw) * 2 + nr) * 1024 + off); };
             const f32x4 c1 = C(1), c2 = C(2), c3 = C(3), c4 = C(4);
             const f32x4 s_ = c1 + c2, d_ = c1 - c2, u_ = c3 + c4, w_ = c3 - c4;
             f32x4 y;
@@ -615,6 +656,36 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
             return y;
         };
         f32x4 ys[NI][3];   // [N-tile][unit]: the four pixels of the lane's chunk
+        auto finish_unit = [&](int ni, int nr, int xw, int un) __attribute__((always_inline)) {   // (the output row is a compile-time constant of the wave's role)
+            const int sel = NSPLIT ? ngf : un;   // waves 4, 5: which of their two rows
+            switch (xi) {
+                case 0: ys[ni][un] = finish(0, nr, xoff[un], xw); break;
+                case 1: ys[ni][un] = finish(1, nr, xoff[un], xw); break;
+                case 2: ys[ni][un] = finish(2, nr, xoff[un], xw); break;
+                case 3: ys[ni][un] = finish(3, nr, xoff[un], xw); break;
+                case 4: ys[ni][un] = sel ? finish(1, nr, xoff[un], xw) : finish(0, nr, xoff[un], xw); break;
+                default: ys[ni][un] = sel ? finish(3, nr, xoff[un], xw) : finish(2, nr, xoff[un], xw); break;
+            }
+        };
+        if constexpr (NSPLIT) {   // ONE round: wave (ng, xi) publishes its two N-tiles, every finishing lane reads all four
+#pragma unroll
+            for (int nr = 0; nr < 2; ++nr)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x4 t;
+                    t[0] = cc[0][nr][e]; t[1] = cc[1][nr][e]; t[2] = cc[2][nr][e]; t[3] = cc[3][nr][e];
+                    *reinterpret_cast<f32x4*>(xb + woff[e] + nr * 1024) = t;
+                }
+            EIG4_LDS_BARRIER();
+            if (EIG_TIMING) tq_x = __builtin_readcyclecounter();
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+                for (int un = 0; un < 2; ++un) {
+                    if (un >= nun) break;
+                    finish_unit(ni, ni & 1, ni >> 1, un);
+                }
+        } else {
 #pragma unroll
         for (int rnd = 0; rnd < 2; ++rnd) {
             if (2 * rnd >= NI) break;
@@ -639,16 +710,10 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
 #pragma unroll
                 for (int un = 0; un < 3; ++un) {
                     if (un >= nun) break;
-                    switch (xi) {
-                        case 0: ys[ni][un] = finish(0, nr, xoff[un]); break;
-                        case 1: ys[ni][un] = finish(1, nr, xoff[un]); break;
-                        case 2: ys[ni][un] = finish(2, nr, xoff[un]); break;
-                        case 3: ys[ni][un] = finish(3, nr, xoff[un]); break;
-                        case 4: ys[ni][un] = un ? finish(1, nr, xoff[un]) : finish(0, nr, xoff[un]); break;
-                        default: ys[ni][un] = un ? finish(3, nr, xoff[un]) : finish(2, nr, xoff[un]); break;
-                    }
+                    finish_unit(ni, nr, rg, un);
                 }
             }
+        }
         }
         // WALK: this wave's share of part A has landed (issued ~3 us ago) -- waited for HERE, ahead of the gate loads and the stores, so that the barrier at the top
         // of the next N-block needs no vmcnt wait of its own (which would wait for the stores below as well)
@@ -657,14 +722,15 @@ __global__ void __launch_bounds__(HALF ? W4_THREADS / 2 : W4_THREADS, 3) wino4_k
 #pragma unroll
         for (int un = 0; un < 3; ++un) {
             if (un >= nun) break;
-            const int ty = TALL ? (xi < 4 ? un : 3) : (xi < 4 ? (un >> 1) : 1), chh = TALL ? 0 : (xi < 4 ? (un & 1) : 1);
-            const int arow = xi < 4 ? xi : 2 * (xi - 4) + un;
+            const int cq = unit_cq(un);
+            const int ty = TALL ? cq : cq >> 1, chh = TALL ? 0 : cq & 1;
+            const int arow = unit_arow(un);
             const int gy = PACK ? 4 * f_ty + arow : y0 + RGH * rg + 4 * ty + arow, gx = PACK ? 4 * f_tx : x0 + 4 * j;
             if (gy >= a.H || gx >= a.W) continue;
             const int ebo = PACK ? eb + f_i : eb;   // (PACK: the tile's image)
             if (PACK && ebo >= a.B) continue;       // (past the last tile of the launch)
             const size_t pix = (size_t)gy * a.W + gx;
-            const int chq = PACK ? 4 * (xi < 4 ? un : 3) + fchl : 8 * chh + chl;
+            const int chq = PACK ? 4 * cq + fchl : 8 * chh + chl;
             if constexpr (EPI == EPI_LSTM) {
                 const int ch = nblk * 16 + chq;
                 if (ch >= Cout) continue;

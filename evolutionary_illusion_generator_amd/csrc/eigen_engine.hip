@@ -508,21 +508,21 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         static const int half_env = getenv("EIGEN_W4_HALF") ? atoi(getenv("EIGEN_W4_HALF")) : -1;
         const bool half = !tall && (half_env >= 0 ? half_env != 0 : (long long)op.n_nblk * batch * a.tilesX * ((op.H + 7) / 8) <= e->n_cu);
         if (half) a.tilesY = (op.H + 7) / 8;
-        // Packed tiles (conv_wino4.h: PACK, half blocks of sixteen consecutive tiles of the launch's linear tile list): maps of 4 x 4 or 5 x 4 tiles -- the 20 x 15 top layer of
-        // the reference's 160 x 120 fills 62 % of a wide block -- for ConvLSTMs without an unpooled source and ConvPs.  Taken when its rounds of half blocks (a half block
-        // takes about two thirds of a full one's time) cost less than the rounds of full blocks: ref160's ConvLSTM_3, 600 blocks = 3 rounds -> 756 half blocks = 3 rounds
-        // of two thirds; configs[1]'s, 200 blocks -> 252 half blocks, one round each.  A choice by map and launch size; the chains do not depend on it.  EIGEN_W4_PACK = 0 / 1
-        // forbids / forces it for every operator it can run.
+        // Packed tiles (conv_wino4.h: PACK): maps of 4 x 4 or 5 x 4 tiles -- the 20 x 15 top layer of the reference's 160 x 120 fills 62 % of a wide block -- on half blocks
+        // whose sixteen MFMA rows are all real tiles: tile columns 0-3 of one image, or tile column 4 of four images (five blocks per four images).  For ConvLSTMs without
+        // an unpooled source and ConvPs.  Taken when its rounds of half blocks (a half block takes about two thirds of a full one's time) cost less than the rounds of
+        // full blocks: ref160's ConvLSTM_3, 600 blocks = 3 rounds -> 756 half blocks = 3 rounds of two thirds; configs[1]'s, 200 blocks -> 252 half blocks, one round each.  A choice
+        // by map and launch size; the chains do not depend on it.  EIGEN_W4_PACK = 0 / 1 forbids / forces it for every operator it can run.
         static const int pack_env = getenv("EIGEN_W4_PACK") ? atoi(getenv("EIGEN_W4_PACK")) : -1;
         const int ptx = (op.W + 3) / 4, pty = (op.H + 3) / 4;
         const bool pack_can = op.epi != EPI_CONVA && a.up_src == nullptr && (ptx == 4 || ptx == 5) && pty == 4 && tall_env < 0 && half_env < 0;
         bool pack = false;
         if (pack_can) {
-            const long long nhalf = (long long)op.n_nblk * (((long long)batch * ptx * pty + 15) / 16), nfull = (long long)op.n_nblk * batch;
+            const long long nhalf = (long long)op.n_nblk * (batch + (ptx == 5 ? (batch + 3) / 4 : 0)), nfull = (long long)op.n_nblk * batch;
             pack = pack_env >= 0 ? pack_env != 0 : 2 * ((nhalf + e->n_cu - 1) / e->n_cu) < 3 * ((nfull + e->n_cu - 1) / e->n_cu);
         }
         if (pack) { a.tilesX = ptx; a.tilesY = pty; }
-        const int ntile4 = pack ? (batch * ptx * pty + 15) / 16 : batch * a.tilesX * a.tilesY;
+        const int ntile4 = pack ? batch + (ptx == 5 ? (batch + 3) / 4 : 0) : batch * a.tilesX * a.tilesY;
         // WALK (conv_wino4.h): nparts blocks per tile, each computing nwalk = n_nblk / nparts consecutive N-blocks of it: walks of three N-blocks where n_nblk allows, of
         // two otherwise (the blocks of a tile share its planes through the XCD's L2), no walk while the launch would not give every CU four blocks.  A property of the
         // launch only -- the bits do not depend on it.  EIGEN_W4_PARTS = n forces min(n, n_nblk) rounded down to a divisor (n >= n_nblk: one N-block per block), for A/B
@@ -542,7 +542,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
             auto magic = [&](long long d) -> unsigned { return (d > 1 && (long long)g4 * 16 * d < (1ll << 32)) ? (unsigned)(((1ll << 32) + d - 1) / d) : 0u; };   // (x 16: a packed block divides its first TILE's index)
             a.mg[0] = magic(nparts); a.mg[1] = magic((long long)a.tilesX * a.tilesY); a.mg[2] = magic(a.tilesX);
         }
-        op.last_grid = g4 * a.nwalk; op.last_waves = (half || pack) ? W4_WAVES / 2 : W4_WAVES;   // (timeline records: one per block and N-block of its walk)
+        op.last_grid = g4 * a.nwalk; op.last_waves = ((half || pack) && !(op.NI == 4 && op.epi != EPI_CONVA)) ? W4_WAVES / 2 : W4_WAVES;   // (64-column ConvLSTM / ConvP half blocks: twelve waves, conv_wino4.h: NSPLIT)   // (timeline records: one per block and N-block of its walk)
 #if EIG_TIMING
         if (tl_dbg) {   // sized from THIS launch's records (the buffer above was sized for the four-wave grid)
             (void)hipFree(tl_dbg);
