@@ -625,7 +625,8 @@ def main():
         alg_bytes = {l_: convlstm_algorithmic_bytes(CHANNELS, W, H, l_) * nb for l_ in s8d_layer}
         launches_l = {l_: sum(r["launches"] for r in lstm if r["layer"] == l_) for l_ in s8d_layer}
         alg_bytes_avg = sum(alg_bytes[l_] * launches_l[l_] for l_ in alg_bytes) / max(n_l, 1)
-        wmask = int(engine_mod.load_library().eigen_winograd_mask()) & 0xFFFFFFFF
+        from evolutionary_illusion_generator_amd import engine as engine_mod
+        wmask = int(engine_mod.load_library().eigen_winograd_mask()) & 0xFFFFFFFF   # (the effective mask, as the library resolved it)
         out["roofline"] = {"bound": "mfma", "kernel": ("wino4_kernel<4,EPI_LSTM> (ConvLSTM, E / unpooled R / h chains as Winograd F(4x4,3x3): 36 multiply-adds per channel and 4x4 outputs where the direct form needs 144, fused gates, v_mfma_f32_16x16x4_f32)"
                                                        if wino_rows else "conv3x3_mfma<4,16,EPI_LSTM> (fused ConvLSTM gates, v_mfma_f32_16x16x4_f32)"),
                            "winograd_mask": "0x%08X" % wmask,
