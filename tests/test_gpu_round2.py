@@ -110,15 +110,11 @@ def test_hip_fitness_vs_reference_element_order_c3(cuda, oracle_lib):
     _few_cpu_threads()
     nz = [i for i in range(len(genomes)) if hip[i] != 0][:4]
     assert len(nz) == 4, "fewer than four non-zero genomes among 24: vacuous"
-    from concurrent.futures import ThreadPoolExecutor
-    with ThreadPoolExecutor(max_workers=2) as pool:   # (the two checkers side by side: both are CPU legs that leave the interpreter lock)
-        f_t = pool.submit(classify.population_report, structure, w, h, imgs, frames, vecs, hip, PredNetTorch(wts, ch, w, h, order="chainer"), batch=1)
-        f_c = pool.submit(classify.population_report, structure, w, h, imgs[nz], frames[nz], [vecs[i] for i in nz], np.asarray(hip)[nz],
-                          oracle_lib.PredNetC(wts, ch, w, h, order="chainer"), batch=1)
-        s, _ = f_t.result()
-        sc, rows = f_c.result()
+    s, _ = classify.population_report(structure, w, h, imgs, frames, vecs, hip, PredNetTorch(wts, ch, w, h, order="chainer"), batch=1)
     print("\nC3 256x256 colour vs chainer element order (torch-CPU): %s" % s)
     _assert_explained(s, 8, 0.88, 0.80)
+    sc, rows = classify.population_report(structure, w, h, imgs[nz], frames[nz], [vecs[i] for i in nz], np.asarray(hip)[nz],
+                                          oracle_lib.PredNetC(wts, ch, w, h, order="chainer"), batch=1)
     print("C3 genomes %s vs chainer element order (C oracle): %s" % (nz, sc))
     assert sc["max_byte_diff"] <= 1 and sc["byte_flip_rate"] <= 2e-5, sc
     assert sc["zero_on_one_side_only"] == 0 and sc["outside_1e-4_unexplained"] == 0, sc["outside_1e-4_detail"]
