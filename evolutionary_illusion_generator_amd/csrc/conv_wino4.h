@@ -104,16 +104,16 @@ template <typename V4> __device__ __forceinline__ void w4_out1d(const V4& m0, co
     for (int e = 0; e < 4; ++e) { Y[1][e] = fmaf(2.0f, w[e], d[e]); Y[2][e] = fmaf(4.0f, u[e], s[e]); Y[3][e] = fmaf(8.0f, w[e], d[e]) + m5[e]; }
 }
 
-// HALF (round 6): a block of ONE region -- 8 rows x 32 columns, six waves (wave = row xi of the position grid), everything else as the wide shape with rg = 0.  For launches
-// of less than one block per CU (configs[0]: 10 to 40 blocks): their time is ONE block's time, and a six-wave block has the CU's matrix pipe to itself for half the
-// multiply-adds.  A choice by launch size (eigen_engine.hip), like the walk; the chains do not depend on it.
+// HALF (round 6): a block of ONE region -- 8 rows x 32 columns, six waves (wave = row xi of the position grid; twelve with NSPLIT below), everything else as the wide shape
+// with rg = 0.  For launches of at most one half block per CU (configs[0]: 10 to 40 blocks): their time is ONE block's time, and a half block has the CU's matrix pipe to
+// itself for half the multiply-adds.  A choice by launch size (eigen_engine.hip), like the walk; the chains do not depend on it.
 //
 // PACK (round 6; a half block): for maps of 16 or 20 columns and 13 to 16 rows (4 x 4 or 5 x 4 tiles: the 20 x 15 top layer of the reference's own 160 x 120), which fill
 // half / 62 % of a wide block.  The block's sixteen MFMA rows are either the 4 x 4 tiles of tile columns 0-3 of ONE image (a "main" block: MFMA row r = 4 ty + tx, the
 // tall shape's region) or, for 5-column maps, tile column 4 of FOUR consecutive images (an "edge" block: r = 4 image + ty) -- five blocks per four images, every MFMA row
 // a real tile (the launch's B main blocks first, then the edge blocks).  The plane container of a channel is [2][18 rows][7 chunks] in the tall shape's LDS map (row stride 28 floats): a main block fills [0] with its image's
 // columns -4 .. 23; an edge block puts columns 12 .. 23 of image 2 p + b into chunks 3 b .. 3 b + 2 of [p] -- in both, the sixteen 16-byte patch reads of a lane group
-// fall on sixteen different bank slots (a linear tile list with 5-tile rows cannot: profiles/r06_z_pmc_ref160.txt, half of the LDS cycles were conflicts).  Sixteen
+// fall on sixteen different bank slots (a linear tile list with 5-tile rows cannot: profiles/r06_z_pmc_ref160_lds_linear_pack.txt, half of the LDS cycles were conflicts).  Sixteen
 // (channel, part) DMA instructions per K-block over the block's waves; the A-operand base, the exchange slot and the output address of a lane come from its tile's
 // (image, ty, tx).  Operators without an unpooled source, ConvLSTM / ConvP.
 //
@@ -126,9 +126,9 @@ __global__ void __launch_bounds__((HALF && !NSPLIT) ? W4_THREADS / 2 : W4_THREAD
 {
     static_assert(!NSPLIT || (HALF && NI == 4 && EPI != EPI_CONVA), "N-split: a half block, 64-column N-blocks, ConvLSTM / ConvP");
     constexpr int NIW = NSPLIT ? 2 : NI;             // N-tiles a wave multiplies
-    // Half blocks: a K-block is 0.5 us of matrix work, less than the round trip of an LDS-DMA -- with the U slab of K-block j waited for at the end of j - 2 (the K-block
-    // it is issued in) the loop ran at the DMA's latency, 1.1 us per K-block (profiles/r06_y_*).  DEEPU: U(j) is waited for at the end of j - 1 instead (the wait at the
-    // end of a K-block lets that K-block's own U and plane fetches stay in flight); the first B operand of a K-block is then read behind the barrier in front of it.
+    // Half blocks: a K-block is 0.5 us of matrix work, less than the round trip of an LDS-DMA that misses the L2.  DEEPU: the U slab of K-block j, issued in j - 2, is waited
+    // for at the end of j - 1 instead of j - 2 (the wait at the end of a K-block lets that K-block's own U and plane fetches stay in flight); the first B operand of a K-block
+    // is then read behind the barrier in front of it.  Worth 1 % (profiles/r06_y_half_blocks_nsplit_pack.txt): what bounds a half block is the RATE of its U stream.
     constexpr bool DEEPU = HALF && EIG_W4_DEEPU;
     static_assert(!(TALL && HALF), "half blocks exist in the wide shape only");
     static_assert(!PACK || (HALF && EPI != EPI_CONVA), "packed tiles: a half block, ConvLSTM / ConvP");
@@ -143,7 +143,7 @@ __global__ void __launch_bounds__((HALF && !NSPLIT) ? W4_THREADS / 2 : W4_THREAD
     constexpr bool WALK = !TALL && !HALF;                     // (tall blocks: one N-block per block -- with 16 KB plane slots the prefetched part of a next N-block does not fit beside the exchange area)
     constexpr int RGH = TALL ? 16 : 8;               // rows of a region
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_w16.py with EIG_TL_WAVES=12)
+    unsigned long long tq_entry = EIG_TIMING ? __builtin_readcyclecounter() : 0;   // measurement builds (-DEIG_TIMING=1, scripts/timeline_wino4.py)
     float* const Pb = lds;                          // (slot offsets W4_P0 / W4_P1 / W4_P2, W4_U0 / W4_U1 / W4_U2 are absolute)
     float* const Ub = lds;
     float* const xb = lds + w4_x(TGEO);

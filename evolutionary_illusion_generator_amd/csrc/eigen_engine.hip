@@ -502,7 +502,7 @@ static hipError_t launch_conv(eigen_engine* e, ConvOp& op, ConvArgs& a, int batc
         static const int tall_env = getenv("EIGEN_W4_TALL") ? atoi(getenv("EIGEN_W4_TALL")) : -1;
         const bool tall = tall_env >= 0 ? tall_env != 0 : ((op.W + 15) / 16) * ((op.H + 31) / 32) < ((op.W + 31) / 32) * ((op.H + 15) / 16);
         a.tilesX = tall ? (op.W + 15) / 16 : (op.W + 31) / 32; a.tilesY = tall ? (op.H + 31) / 32 : (op.H + 15) / 16;
-        // Half blocks (conv_wino4.h: HALF, 8 x 32 pixels on six waves) while even THEY are at most one block per CU: the launch's time is then ONE block's time, and a half
+        // Half blocks (conv_wino4.h: HALF, 8 x 32 pixels, six or twelve waves) while even THEY are at most one block per CU: the launch's time is then ONE block's time, and a half
         // block has the CU's matrix pipe to itself for half the multiply-adds (c1: +15 %; with more half blocks than CUs the second round costs more than the halving gains --
         // c2's 20 x 15 top layer, 200 full blocks: -7 %).  A choice by launch size, like the walk.  EIGEN_W4_HALF = 0 / 1 forces it (A/B, tests).
         static const int half_env = getenv("EIGEN_W4_HALF") ? atoi(getenv("EIGEN_W4_HALF")) : -1;

@@ -1,4 +1,4 @@
-// wino4h_kernels.hip -- translation unit of the Winograd F(4x4, 3x3) kernels on 8 x 32-pixel half blocks of six waves (conv_wino4.h: HALF); called through launch_wino4
+// wino4h_kernels.hip -- translation unit of the Winograd F(4x4, 3x3) kernels on 8 x 32-pixel half blocks (conv_wino4.h: HALF); called through launch_wino4
 #include "conv_wino4.h"
 
 #include <unordered_set>

@@ -15,8 +15,8 @@ constexpr int W4_NPOS = 36;
 constexpr int wino4_u_floats(int NI) { return W4_NPOS * 4 * 16 * NI; }   // one 4-channel K-block of the packed weights: [36 pos][4 ch][16 cols][NI] (the buffer ends in one K-block of padding: the fetch runs one K-block past the end)
 
 // grid blocks of wino4_kernel<NI, epi, shape> on stream st (NI = 3 or 4; epi = EPI_LSTM (NI = 4 only), EPI_CONVA, EPI_CONVP); the first launch of an
-// instantiation sets its dynamic-LDS attribute.  shape: W4_WIDE 16 x 32-pixel blocks, W4_TALL 32 x 16, W4_HALF 8 x 32 (six waves), W4_PACK sixteen consecutive tiles of the
-// linear tile list (six waves; ConvLSTM / ConvP only)
+// instantiation sets its dynamic-LDS attribute.  shape: W4_WIDE 16 x 32-pixel blocks, W4_TALL 32 x 16, W4_HALF 8 x 32 (one region; six waves, twelve for 64-column ConvLSTMs / ConvPs),
+// W4_PACK half blocks of packed tiles for 16- / 20-column maps (ConvLSTM / ConvP only)
 enum { W4_WIDE = 0, W4_TALL = 1, W4_HALF = 2, W4_PACK = 3 };
 hipError_t launch_wino4(int NI, int epi, int shape, const ConvArgs& a, int grid, hipStream_t st);
 
