@@ -421,9 +421,9 @@ ok = True
 # (w, h, channels, batch): 16-channel gate groups at layers >= 1; ragged 16 x 16 tiles (40 x 24, 20 x 12 maps), a 4-layer net, a top
 # layer without an unpooled source, colour and gray image layers (which keep the direct operators); 48- / 96- / 192-channel ConvA and
 # ConvP (N-blocks of 48 and of 64 columns); the reference's own 160 x 120 with its 20 x 15 top layer (odd height)
-# and at three images (tiles of three images in one packed block's list: 60 tiles = 3.75 blocks); 128 x 128 with a 16 x 16 top layer of 48 channels (packed tiles, 4 x 4 per image,
-# ConvP in N-blocks of 48 columns)
-for (w, h, ch, B) in [(64, 64, [3, 16, 32], 3), (80, 48, [1, 16, 32, 48], 2), (96, 64, [3, 48, 96], 2), (160, 120, [3, 48, 96, 192], 3), (128, 128, [3, 16, 32, 48], 3)]:
+# and at three images (packed tiles: three main blocks + an edge block with one image missing); 128 x 128 with a 16 x 16 top layer of 48 channels (packed tiles, 4 x 4 per
+# image: main blocks only; ConvP in N-blocks of 48 columns); 160 x 104 gray at five images: a 20 x 13 top layer (13 rows of 16), a second edge block holding ONE image
+for (w, h, ch, B) in [(64, 64, [3, 16, 32], 3), (80, 48, [1, 16, 32, 48], 2), (96, 64, [3, 48, 96], 2), (160, 120, [3, 48, 96, 192], 3), (128, 128, [3, 16, 32, 48], 3), (160, 104, [1, 16, 32, 48], 5)]:
     rng = np.random.default_rng(11)
     img = rng.integers(0, 256, (B, ch[0], h, w), dtype=np.uint8)
     wts = weights.synthetic_prednet_weights(ch, w, h, seed=5)
@@ -473,7 +473,7 @@ def _wino_run(switch):
 @pytest.mark.parametrize("switch", _WINO_SWITCHES)
 def test_winograd_operators_frames_bit_exact(cuda, oracle_lib, switch):
     """The Winograd forms of the 3x3 convolutions against the oracle's statement of exactly that arithmetic (eig_oracle.c: wino_*, wino4_*; the oracle follows the
-    same environment switch): all frames of five small roll-outs, bit for bit -- incl. step-0 operators (one source), ragged tiles, a top layer without an unpooled
+    same environment switch): all frames of six small roll-outs, bit for bit -- incl. step-0 operators (one source), ragged tiles, a top layer without an unpooled
     source, the 20 x 15 top layer of 160 x 120 (odd height), N-blocks of 48 and 64 columns.
     None = THE DEFAULT (0x0FFFFFFE): every eligible ConvLSTM / ConvA / ConvP as Winograd F(4x4, 3x3) on the twelve-wave kernel (csrc/conv_wino4.h), the unpooled source
     inside the ConvLSTM's chains -- launches this small do not walk, and the block shape is picked per operator by map size (these roll-outs include 80 x 60 and 40 x 30
