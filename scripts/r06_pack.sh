@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 6: packed tiles (half blocks of sixteen consecutive tiles of the linear tile list) for 20 x 15 / 16 x 16 maps -- parity with the form forced on / off and as chosen,
-# then same-box A/Bs per shape (recipe kept as the record of how profiles/r06_w_* were taken)
+# round 6: packed tiles (half blocks whose sixteen MFMA rows are all real tiles of 20 x 15 / 16 x 16 maps; first as a linear tile list, then as main + edge blocks) -- parity with the
+# form forced on / off and as chosen, then same-box A/Bs per shape (recipe kept as the record of how profiles/r06_w_* were taken)
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 export TMPDIR=/tmp
 O=gpurun_out/${1:-r06_w}; mkdir -p $O
