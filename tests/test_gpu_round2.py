@@ -409,7 +409,7 @@ def test_bench_gpus_flag_launches_ranks(cuda):
     env_gloo = dict(env, EIGEN_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
     # the six launches are independent processes (tiny workloads sharing the one GPU): started three at a time, checked in order
     jobs = {
-        "one": ([sys.executable, bench, "--gpus", "1"] + small, env),
+        "one": ([sys.executable, bench, "--gpus", "1"] + small[:-2] + ["--no-cpu-baseline"], env),   # (WITH the roofline block: the plain single-rank path the driver runs)
         # the multi-rank reporting path (RCCL group, per-rank device times out of the all-gather, leaving the group before rank 0's
         # untimed legs) in a group of ONE rank: what a single-GPU box can run of `--gpus N`
         "single_rank_group": ([sys.executable, bench, "--gpus", "1"] + small[:-2] + ["--no-cpu-baseline"], dict(env, EIGEN_DIST_SINGLE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")),
@@ -435,6 +435,7 @@ def test_bench_gpus_flag_launches_ranks(cuda):
         return json.loads(lines[0])
     line = json_line(res["one"])
     assert line["n_gpus"] == 1 and line["config"]["global_pop"] == 8 and line["scaling"] == "strong" and line["value"] > 0
+    assert line["roofline"]["all_conv_kernels"]["launches"] > 0 and line["roofline"]["winograd_mask"] == "0x0FFFFFFE"
     line = json_line(res["single_rank_group"])
     assert "RCCL" in line["config"]["parallelism"] and len(line["multi_gpu"]["per_rank_device_ms"]) == 1 and line["multi_gpu"]["device_ms_max"] > 0
     assert line["multi_gpu"]["ranks_seen"] == [0] and line["multi_gpu"]["backend"] == "nccl" and line["multi_gpu"]["rccl_version"]
