@@ -720,13 +720,13 @@ def main():
         sup = {}
         fitness.clear_engines()
         torch.cuda.empty_cache()
-        for name, pop_s, steps_s, key in (("ref160", 50, 10, "ref160 (the reference's own default shape, pop 50)"), ("c1", 10, 20, "configs[0] (on the GPU path)"), ("c2", 50, 20, "configs[1]"),
+        for name, pop_s, steps_s, key in (("ref160", 50, 20, "ref160 (the reference's own default shape, pop 50)"), ("c1", 10, 100, "configs[0] (on the GPU path)"), ("c2", 50, 60, "configs[1]"),   # (5-50 ms generations: 0.5-1 s each, or the box's host shows in the number)
                                           ("ref640", 16, 4, "ref640 (the reference's `--size big`, 640x480 colour, pop 16)"),
                                           ("c4", 512, 2, "configs[3] (single-GPU: two device batches of 256)"), ("c5", 64, 2, "configs[4] (single-GPU sample: one device batch of 64)"),
                                           # configs[4] at ITS population once -- 1024 genomes at 512x512 = four device batches of 256, one generation
                                           ("c5_full", 1024, 1, "configs[4] at its stated population (single GPU: four device batches of 256, ONE generation, warm-up = one more)")):
             try:
-                r = supplementary_shape("c5" if name == "c5_full" else name, pop_s, steps_s, report_memory=(name == "c5_full"))
+                r = supplementary_shape("c5" if name == "c5_full" else name, pop_s, steps_s, warmup=3 if steps_s >= 20 else 1, report_memory=(name == "c5_full"))
                 r["config"] = key
                 sup[name] = r
             except Exception as e:  # noqa: BLE001  (a supplementary failure must not cost the headline line)
